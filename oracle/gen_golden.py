@@ -1,0 +1,181 @@
+"""Generate tests/golden/*.safetensors by running the REAL reference code (build container only).
+
+    python -m oracle.gen_golden            # needs /root/reference; writes tests/golden/
+
+Each fixture holds inputs ``in.*``, weights ``w.*`` (the reference module's state_dict) and outputs
+``out.*`` of ORV's own ``forward`` / ``__call__`` (see oracle/ref_harness.py for how the reference is
+imported).  Config and scalar arguments travel in the safetensors metadata as JSON.  All fp32,
+seed 1234.  Fixtures are data only - no reference source text is stored.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import torch
+from safetensors.torch import save_file
+
+from . import ref_harness
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+TINY = dict(num_attention_heads=2, attention_head_dim=64, in_channels=32, out_channels=16, time_embed_dim=64,
+            text_embed_dim=96, num_layers=2, sample_width=12, sample_height=8, sample_frames=9,
+            max_text_seq_length=8, modulate_encoder_hidden_states=True, num_control_blocks=2)
+
+
+def _randomize_zero_init(model):
+    """Make zero-initialised layers non-trivial, then snap every weight to a bf16-representable value so the
+    fixture can store weights losslessly as bf16 (the product runs bf16 weights)."""
+    g = torch.Generator().manual_seed(99)
+    for name, p in model.named_parameters():
+        if p.detach().abs().max() == 0:
+            p.data.copy_(torch.randn(p.shape, generator=g) * 0.05)
+        p.data.copy_(p.data.to(torch.bfloat16).to(torch.float32))
+
+
+def _q(x):
+    """bf16-representable fp32 (inputs are stored as bf16 too)."""
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _save(name, cfg, tensors, extra=None):
+    meta = {"config": json.dumps(cfg), "extra": json.dumps(extra or {})}
+    tensors = {k: v.detach().contiguous().clone() for k, v in tensors.items() if v is not None}
+    for k, v in tensors.items():
+        if (k.startswith("w.") or k.startswith("in.")) and v.dtype == torch.float32 and "rope" not in k:
+            assert torch.equal(v, _q(v)), k
+            tensors[k] = v.to(torch.bfloat16)
+    save_file(tensors, os.path.join(OUT, name + ".safetensors"), metadata=meta)
+    print(f"{name}: {sum(v.numel() * v.element_size() for v in tensors.values()) / 1e6:.2f} MB")
+
+
+def forward_case(cc, utils, name, cfg_over, b=2, t=3, n_act=8, mask=(False, False), cond=False, rope=False,
+                 ofs=None, num_views=1, training=False, actions=True, seed=1234):
+    torch.manual_seed(seed)
+    cfg = {**TINY, **cfg_over}
+    model = cc.CogVideoXTransformer3DModelTraj(**cfg)
+    _randomize_zero_init(model)
+    model.train(training)
+    h, w = cfg["sample_height"], cfg["sample_width"]
+    x = _q(torch.randn(b, t * num_views, cfg["in_channels"], h, w))
+    e = _q(torch.randn(b, cfg["max_text_seq_length"], cfg["text_embed_dim"]))
+    ts = torch.randint(0, 1000, (b,))
+    ctrl = {}
+    if actions:
+        ctrl["actions"] = _q(torch.randn(b, n_act, 7))
+    if cond:
+        ctrl["depths"] = _q(torch.randn(b, t * num_views, cfg["in_channels"], h, w))
+        ctrl["labels"] = _q(torch.randn(b, t * num_views, cfg["in_channels"], h, w))
+    rot = None
+    if rope:
+        rot = utils.prepare_rotary_positional_embeddings(
+            height=h * 8, width=w * 8, num_frames=t, vae_scale_factor_spatial=8, patch_size=cfg["patch_size"] if "patch_size" in cfg else 2,
+            patch_size_t=cfg.get("patch_size_t"), attention_head_dim=cfg["attention_head_dim"], device=None)
+    ofs_t = None if ofs is None else torch.full((1,), float(ofs))
+    with torch.no_grad(), ref_harness.forced_action_mask(list(mask)):
+        out, is_mask, recon = model(hidden_states=x, encoder_hidden_states=e, controls_or_guidances=dict(ctrl),
+                                    timestep=ts, ofs=ofs_t, image_rotary_emb=rot, return_dict=False,
+                                    num_views=num_views)
+    tensors = {"in.hidden_states": x, "in.encoder_hidden_states": e, "in.timestep": ts, "out.sample": out}
+    for k, v in ctrl.items():
+        tensors["in." + k] = v
+    if rot is not None:
+        tensors["in.rope_cos"], tensors["in.rope_sin"] = rot
+    if is_mask is not None:
+        tensors["out.is_action_mask"] = is_mask
+    if recon is not None:
+        tensors["out.actions_recon"] = recon
+    for k, v in model.state_dict().items():
+        tensors["w." + k] = v
+    full_cfg = {k: v for k, v in dict(model.config).items() if k != "kwargs"}
+    _save(name, full_cfg, tensors, dict(ofs=ofs, num_views=num_views, training=training, mask=list(mask)))
+
+
+def pipeline_case(cc, name, sched_cls, steps=3, guidance=1.0, seed=1234, with_actions=True):
+    from . import leaf
+    torch.manual_seed(seed)
+    cfg = {**TINY, "sample_frames": 9}
+    model = cc.CogVideoXTransformer3DModelTraj(**cfg)
+    _randomize_zero_init(model)
+    model.eval()
+    sched = sched_cls(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                      clip_sample=False, set_alpha_to_one=True, prediction_type="v_prediction",
+                      rescale_betas_zero_snr=True, snr_shift_scale=3.0, timestep_spacing="trailing")
+    pipe = ref_harness.make_pipeline(cc, model, sched)
+    b, h, w = 2, 8, 12
+    image = _q(torch.randn(b, 32, 1, h, w))         # un-sampled moments of the reference frame [B, 2C, F, H, W]
+    e = _q(torch.randn(b, 8, 96))
+    ne = _q(torch.randn(b, 8, 96))
+    actions = _q(torch.randn(b, 8, 7))
+    gen = torch.Generator().manual_seed(4321)
+    trace = []
+
+    def cb(pipe_, i, t, kw):
+        trace.append(kw["latents"].clone())
+        return {}
+
+    # NB: under CFG the reference doubles latents/prompts but NOT the actions (cogvideox_control.py:1409-1431),
+    # so guidance_scale > 1 only runs without action controls.
+    with ref_harness.forced_action_mask([False] * b):
+        out = pipe(image=image, prompt=None, negative_prompt=None, height=h * 8, width=w * 8, num_frames=9,
+                   num_inference_steps=steps, guidance_scale=guidance, generator=gen, prompt_embeds=e,
+                   negative_prompt_embeds=ne if guidance > 1 else None, output_type="latent",
+                   controls_or_guidances={"actions": actions} if with_actions else {}, callback_on_step_end=cb)
+    tensors = {"in.image": image, "in.prompt_embeds": e, "in.negative_prompt_embeds": ne, "in.actions": actions,
+               "out.latents": out.frames}
+    for i, tr in enumerate(trace):
+        tensors[f"out.step{i}"] = tr
+    for k, v in model.state_dict().items():
+        tensors["w." + k] = v
+    full_cfg = {k: v for k, v in dict(model.config).items() if k != "kwargs"}
+    _save(name, full_cfg, tensors, dict(steps=steps, guidance=guidance, gen_seed=4321, scheduler=sched_cls.__name__,
+                                         with_actions=with_actions))
+
+
+def misc_case(cc, comp, utils):
+    """Small standalone functions ORV authored: action padding + ActionEmbed/ActionRecon, crop-region helper."""
+    torch.manual_seed(1234)
+    ae = comp.ActionEmbed(state_dim=7, hidden_size=64, compress_ratio=4, patch_size_t=None, mask=True)
+    ar = comp.ActionRecon(state_dim=7, hidden_size=64, compress_ratio=4)
+    a = _q(torch.randn(3, 11, 7))
+    for p in list(ae.parameters()) + list(ar.parameters()):
+        p.data.copy_(_q(p.data))
+    with torch.no_grad(), ref_harness.forced_action_mask([True, False, False]):
+        emb, m = ae(a)
+        rec = ar(emb)
+    tensors = {"in.actions": a, "out.emb": emb, "out.mask": m, "out.recon": rec}
+    for k, v in ae.state_dict().items():
+        tensors["w.action_embed." + k] = v
+    for k, v in ar.state_dict().items():
+        tensors["w.action_recon." + k] = v
+    crops = {f"{h}x{w}": utils.get_resize_crop_region_for_grid((h, w), 45, 30) for h, w in [(20, 30), (30, 45), (16, 24), (30, 40)]}
+    _save("misc_actions", {}, tensors, dict(crops=crops))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    cc, comp, utils = ref_harness.load_reference()
+    forward_case(cc, utils, "fwd_actions", {})
+    forward_case(cc, utils, "fwd_actions_masked", {}, mask=(True, False))
+    forward_case(cc, utils, "fwd_cond", {"visual_guidance": True}, cond=True)
+    forward_case(cc, utils, "fwd_noactions", {}, actions=False)
+    forward_case(cc, utils, "fwd_nomod", {"modulate_encoder_hidden_states": False})
+    forward_case(cc, utils, "fwd_nomod_noactions", {"modulate_encoder_hidden_states": False}, actions=False)
+    forward_case(cc, utils, "fwd_rope", {"use_rotary_positional_embeddings": True}, rope=True)
+    forward_case(cc, utils, "fwd_pt2_ofs", {"use_rotary_positional_embeddings": True, "patch_size_t": 2,
+                                            "ofs_embed_dim": 64, "sample_frames": 13,
+                                            "loaded_pretrained_model_name_or_path": "THUDM/CogVideoX1.5-5b-I2V"},
+                 t=4, n_act=15, rope=True, ofs=2.0)
+    forward_case(cc, utils, "fwd_multiview", {"multiview": True, "max_n_view": 3}, num_views=2)
+    forward_case(cc, utils, "fwd_train_recon", {"recon_action": True}, training=True, n_act=6)
+    pipeline_case(cc, "pipe_ddim", __import__("oracle.leaf", fromlist=["x"]).CogVideoXDDIMScheduler)
+    pipeline_case(cc, "pipe_dpm", __import__("oracle.leaf", fromlist=["x"]).CogVideoXDPMScheduler)
+    pipeline_case(cc, "pipe_ddim_cfg", __import__("oracle.leaf", fromlist=["x"]).CogVideoXDDIMScheduler, guidance=3.0,
+                  with_actions=False)
+    misc_case(cc, comp, utils)
+
+
+if __name__ == "__main__":
+    sys.exit(main())
