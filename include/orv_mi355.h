@@ -1,0 +1,152 @@
+/*
+ * liborv_mi355.so - C ABI of the MI355X (gfx950) kernels behind the ORV denoising hot path.
+ *
+ * The reference (OrangeSodahub/ORV) has no FFI seam on this path: it is nn.Module Python calling torch
+ * (SURVEY.md §8b).  This header is the seam the replacement introduces *beneath* the reference's Python
+ * surface; every entry point cites the reference code whose arithmetic it replaces
+ * (paths relative to /root/reference).  The Python binding a maintainer adds is in INTEGRATION.md.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers borrowed from the caller (torch tensors); the library never
+ *    allocates or frees caller memory.  bf16 tensors are passed as `const void*` to 2-byte elements.
+ *  - Every call is stream-ordered and asynchronous on `stream` (a hipStream_t passed as void*;
+ *    callers pass torch.cuda.current_stream().cuda_stream).  No internal synchronisation.
+ *  - Return value: 0 = ok, <0 = error (ORV_E*); never throws.  `orv_last_error()` returns a
+ *    thread-local message for the last failing call on this thread.
+ *  - "Token group" indexing (per-frame modulation, cogvideox_control.py:99-105,133-140):
+ *      row s of a [B, S, D] joint sequence (text first) belongs to group
+ *      g(s) = 0                      if s <  n_text
+ *             1 + (s - n_text) / P   otherwise           (P = tokens per latent frame)
+ *    and modulation tables are fp32 [B, G, D] slices with explicit strides.
+ */
+#ifndef ORV_MI355_H
+#define ORV_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORV_OK 0
+#define ORV_EINVAL (-1)   /* bad argument / unsupported shape */
+#define ORV_EDEVICE (-2)  /* not a gfx950 device / HIP failure */
+#define ORV_ELAUNCH (-3)  /* kernel launch failed */
+
+/* -- library ---------------------------------------------------------------------------------- */
+int orv_version(void);                 /* ABI version, currently 1 */
+const char* orv_last_error(void);      /* thread-local message of the last failing call */
+int orv_device_check(int device);      /* 0 iff `device` is gfx950 (MI355X) */
+
+/* Token-group descriptor shared by the modulation-aware kernels. */
+typedef struct {
+    int seq;        /* S: rows per batch element */
+    int n_text;     /* rows [0, n_text) are text rows (group 0) */
+    int per_group;  /* P: video rows per group; 0 => all video rows are group 1 */
+} orv_groups_t;
+
+/* Row remap r -> (r / rows) * bstride + off + r % rows (rows == 0: identity).  Lets a kernel read or write the video
+ * (or text) rows of the joint [B, S, D] sequence in place instead of materialising torch.cat / slices
+ * (cogvideox_control.py:222,267-269,437-443,792-794). */
+typedef struct {
+    int rows, bstride, off;
+} orv_rowmap_t;
+
+/* -- embeddings ------------------------------------------------------------------------------- */
+/* diffusers Timesteps(dim, flip_sin_to_cos, shift) as called at orv/models/cogvideox_control.py:763,772:
+ * out[b] = [cos(t*f) | sin(t*f)] (flip) with f_k = exp(-ln(1e4) k / (dim/2 - shift)); fp32 math, bf16 out. */
+int orv_timestep_embedding(const float* t, void* out_bf16, int batch, int dim, int flip_sin_to_cos,
+                           float freq_shift, void* stream);
+
+/* Small-M linear (M <= 64): out[m, :] = act_out( W . act_in(x[m] + xb[m / xb_rep]) + bias ).
+ * Replaces the tiny MLPs/linears of time_embedding (:769), ActionEmbed (components.py:37-45,65),
+ * ActionRecon (components.py:86-90) and the AdaLN modulation linears (:121-130, :172).
+ * x [M,K] bf16; xb optional [ceil(M/xb_rep), K] bf16 broadcast-added before act_in; W [N,K] bf16; bias [N] bf16|NULL.
+ * act: 0 none, 1 SiLU, 2 GELU(tanh).  out_f32 != 0 -> fp32 output else bf16.  ldo = output row stride (elements); omap remaps output rows. */
+int orv_skinny_linear(const void* x, const void* xb, int xb_rep, const void* W, const void* bias, void* out,
+                      int M, int N, int K, int act_in, int act_out, int out_f32, int ldo, orv_rowmap_t omap,
+                      void* stream);
+
+/* Gather [B,T,C,H,W] latents into patch tokens (diffusers CogVideoXPatchEmbed.forward patchify, called at
+ * cogvideox_control.py:788,833,842).  Two channel-concatenated sources (cogvideox_control.py:1409-1413 cat on dim 2)
+ * are read in place: channels [0,c0) from src0, [c0,c0+c1) from src1 (src1 may be NULL with c1 = 0).
+ * pt == 0: tokens [B, T*h*w, (C, p, p)]      (Conv2d weight.flatten(1) order)
+ * pt  > 0: tokens [B, T/pt*h*w, (C, pt, p, p)]  (CogVideoX1.5 Linear order).  Index-exact (bit copies). */
+int orv_patchify(const void* src0, int c0, const void* src1, int c1, void* tokens, int B, int T, int H, int W,
+                 int p, int pt, void* stream);
+
+/* Inverse scatter of cogvideox_control.py:926-936: x [B, N, p*p*(pt)*C] -> out [B,T,C,H,W].  Index-exact. */
+int orv_unpatchify(const void* x, void* out, int B, int T, int C, int H, int W, int p, int pt, void* stream);
+
+/* -- normalisation ---------------------------------------------------------------------------- */
+/* y = LN(x; gamma, beta, eps) * (1 + scale[b, g(s)]) + shift[b, g(s)]   (CogVideoXLayerNormZero.forward
+ * cogvideox_control.py:117-145, AdaLayerNorm.forward :155-197, nn.LayerNorm norm_final :909-916).
+ * x,y [B*S, D] bf16 (row strides ldx/ldy elements); gamma/beta bf16 [D] or NULL; scale/shift fp32 with
+ * element strides (mod_b, mod_g) or NULL (plain LayerNorm).  Statistics in fp32.  Row r of the [batch*grp.seq] problem is
+ * read from x row xmap(r) and written to y row r. */
+int orv_layernorm_modulate(const void* x, int ldx, orv_rowmap_t xmap, void* y, int ldy, const void* gamma,
+                           const void* beta, const float* scale, const float* shift, long mod_b, long mod_g,
+                           orv_groups_t grp, int batch, int D, float eps, void* stream);
+
+/* In-place per-head LayerNorm(64, eps) on the q and k thirds of a packed qkv buffer [B*S, 3*H*64] bf16, optional
+ * RoPE on rows >= n_text (pairs (2i,2i+1); cos/sin fp32 [S-n_text, 64]), and transpose of the v third into
+ * vT [B, H, 64, s_pad] (zero-filled for s >= S).  Replaces cogvideox_control.py:239-254 (+ diffusers
+ * Attention.norm_q/norm_k, apply_rotary_emb). */
+int orv_qkv_prep(void* qkv, void* vT, const void* gq, const void* bq, const void* gk, const void* bk,
+                 const float* rope_cos, const float* rope_sin, int B, int S, int H, int n_text, int s_pad,
+                 float eps, void* stream);
+
+/* -- GEMM ------------------------------------------------------------------------------------- */
+/* C = epilogue(A[M,K] . W[N,K]^T + bias[N]); bf16 operands, fp32 MFMA accumulation, bf16 output.
+ * Replaces nn.Linear / Conv2d(k=s=p) on the path: to_q/k/v + to_out (cogvideox_control.py:232-234,263),
+ * FeedForward (:439-440), text_proj/proj (:788), proj_out (:920), initial_combine_linear (:853).
+ * epilogue: 0 bias; 1 bias+GELU(tanh) (FeedForward net.0); 2 C = R[r_row] + gate[b,g(row)] * (acc + bias)
+ * (gated residual :419-421,442-443; gate NULL => 1; R row r_row = r_mod ? m % r_mod : out_row, so a
+ * [n,D] table broadcast over the batch - the sincos pos-embedding - uses r_mod = n).
+ * Output row remap: out_row = cmap(m) (scatter into the joint [B,S,D] sequence).  Constraints: K % 64 == 0, N % 64 == 0, 16-byte aligned rows. */
+typedef struct {
+    const void* A; int lda;
+    const void* W; int ldw;
+    const void* bias;
+    void* C; int ldc;
+    int M, N, K;
+    int epilogue;
+    const void* R; int ldr; int r_mod;
+    const float* gate; long gate_b, gate_g; orv_groups_t grp;
+    orv_rowmap_t cmap;
+} orv_gemm_t;
+int orv_gemm_bf16(const orv_gemm_t* g, void* stream);
+
+/* -- attention -------------------------------------------------------------------------------- */
+/* Non-causal, unmasked softmax(q k^T * scale) v over the joint text+video sequence, head_dim 64
+ * (F.scaled_dot_product_attention at cogvideox_control.py:256-258).  q,k are read in place from the packed qkv
+ * buffer [B*S, ld_qkv] (q at column h*64, k at column H*64 + h*64); vT [B,H,64,s_pad] from orv_qkv_prep;
+ * out [B*S, H*64] bf16 (heads merged as :260); lse fp32 [B,H,S] or NULL (log-sum-exp, natural log, for backward). */
+int orv_attention_fwd(const void* qkv, int ld_qkv, const void* vT, void* out, int ld_out, float* lse, int B, int S,
+                      int H, int s_pad, float scale, void* stream);
+
+/* -- sampler ---------------------------------------------------------------------------------- */
+/* One fused scheduler update on n elements (cogvideox_control.py:1433-1459 + diffusers
+ * CogVideoXDDIMScheduler.step / CogVideoXDPMScheduler.step, v-prediction):
+ *   v    = guidance ? v_u + guidance_scale * (v_c - v_u) : v_c            (CFG, :1440-1443)
+ *   x0   = sa * x - sb * v
+ *   d    = old_x0 ? m3 * x0 - m4 * old_x0 : x0
+ *   x'   = cx * x + cd * d + cn * noise                                   (noise may be NULL when cn == 0)
+ * x, x' bf16 (the pipeline's latents dtype); v_c/v_u bf16 model outputs; x0_out/old_x0 fp32; noise fp32.
+ * DDIM: cx = a_t, cd = b_t, cn = 0.  DPM: cx = m1, cd = -m2, cn = m_noise. Coefficients are computed on the host in
+ * float64 (orv_amd/schedulers.py) exactly as the reference does. */
+int orv_sched_step(const void* x, const void* v_c, const void* v_u, float guidance_scale, const float* old_x0,
+                   const float* noise, void* x_out, float* x0_out, float sa, float sb, float m3, float m4, float cx,
+                   float cd, float cn, long n, void* stream);
+
+/* mean + exp(0.5*clamp(logvar,-30,20)) * eps, times `scale` (diffusers DiagonalGaussianDistribution.sample used at
+ * cogvideox_control.py:1173-1177,1334-1358; train_cogvideox_control_to_video_sft.py:890-898) with the
+ * [B,2C,F,H,W] -> [B,F,C,H,W] permute fused.  moments bf16, eps fp32 [B,C,F,H,W], out bf16. */
+int orv_gaussian_sample(const void* moments, const float* eps, void* out, int B, int C, int F, int HW, float scale,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORV_MI355_H */

@@ -1,0 +1,74 @@
+"""ctypes binding of liborv_mi355.so (the C ABI declared in include/orv_mi355.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborv_mi355.so")
+
+
+class Groups(Structure):
+    _fields_ = [("seq", c_int), ("n_text", c_int), ("per_group", c_int)]
+
+
+class RowMap(Structure):
+    _fields_ = [("rows", c_int), ("bstride", c_int), ("off", c_int)]
+
+
+class Gemm(Structure):
+    _fields_ = [("A", c_void_p), ("lda", c_int), ("W", c_void_p), ("ldw", c_int), ("bias", c_void_p),
+                ("C", c_void_p), ("ldc", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("epilogue", c_int),
+                ("R", c_void_p), ("ldr", c_int), ("r_mod", c_int), ("gate", c_void_p), ("gate_b", c_long),
+                ("gate_g", c_long), ("grp", Groups), ("cmap", RowMap)]
+
+
+# name -> (restype, argtypes); every symbol include/orv_mi355.h declares
+SIGNATURES = {
+    "orv_version": (c_int, []),
+    "orv_last_error": (c_char_p, []),
+    "orv_device_check": (c_int, [c_int]),
+    "orv_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "orv_skinny_linear": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                  c_int, c_int, c_int, RowMap, c_void_p]),
+    "orv_patchify": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                             c_void_p]),
+    "orv_unpatchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "orv_layernorm_modulate": (c_int, [c_void_p, c_int, RowMap, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_long, c_long, Groups, c_int, c_int, c_float, c_void_p]),
+    "orv_qkv_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                             c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "orv_gemm_bf16": (c_int, [POINTER(Gemm), c_void_p]),
+    "orv_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                  c_float, c_void_p]),
+    "orv_sched_step": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                               c_float, c_float, c_float, c_float, c_float, c_float, c_long, c_void_p]),
+    "orv_gaussian_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load liborv_mi355.so once; raise loudly if it has not been built (``python -c 'import __graft_entry__ as g; g.build()'``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C orv_amd/csrc` "
+                               "(hipcc --offload-arch=gfx950). orv_amd has no CPU/PyTorch fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().orv_last_error()
+        raise RuntimeError(f"liborv_mi355 {what} failed (rc={rc}): {msg.decode() if msg else ''}")

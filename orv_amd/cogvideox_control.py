@@ -1,0 +1,788 @@
+"""MI355X-native mirror of ``orv.models.cogvideox_control`` (/root/reference/orv/models/cogvideox_control.py).
+
+Same class names, constructor kwargs, ``forward`` / ``__call__`` signatures, ``.config`` attribute access and
+``state_dict`` keys as the reference, with no diffusers dependency.  The ``nn.Module`` tree below is a
+*parameter container*: every ``nn.Linear`` / ``nn.LayerNorm`` / ``nn.Conv2d`` exists so checkpoints load under the
+reference's key names; none of their torch ``forward`` methods is ever called.  All arithmetic of the transformer
+forward (reference lines :715-948) runs in the hand-written HIP kernels of liborv_mi355.so through ``orv_amd.ops``:
+
+    time/ofs embedding   orv_timestep_embedding + orv_skinny_linear            (:762-775)
+    patch embed          orv_patchify + orv_gemm_bf16 (pos-embed add fused)    (:788)
+    action embedding     orv_skinny_linear x2                                  (:805-820, components.py:47-71)
+    AdaLN tables         orv_skinny_linear (SiLU + split-linear trick fused)   (:117-130, :172)
+    per block            orv_layernorm_modulate -> orv_gemm_bf16(QKV) -> orv_qkv_prep -> orv_attention_fwd
+                         -> orv_gemm_bf16(out-proj, gated residual) -> orv_layernorm_modulate
+                         -> orv_gemm_bf16(FFN1, GELU) -> orv_gemm_bf16(FFN2, gated residual)   (:394-445)
+    head                 orv_layernorm_modulate x2 -> orv_gemm_bf16 -> orv_unpatchify          (:909-936)
+
+The text and video streams live in ONE joint activation buffer [B, S = n_text + n_video, D] (text rows first, the order
+of the reference's torch.cat at :222,:437), so no concat/split copies exist; per-frame modulation and gates are looked
+up by token group inside the kernels instead of materialising ``repeat_interleave`` ([B, 3000, 1920] x 3 per norm).
+
+There is no CPU / eager fallback: tensors must live on an MI355X and the model must be bf16.
+"""
+from __future__ import annotations
+
+import fnmatch
+import json
+import math
+import os
+from typing import Any, Callable, Dict, List, Optional, Tuple, Union
+
+import torch
+from torch import nn
+
+from . import ops
+from .components import ActionEmbed, ActionRecon, Transformer3DModelTrajOutput
+from .embeddings import sincos_3d
+from .schedulers import CogVideoXDDIMScheduler, CogVideoXDPMScheduler, retrieve_timesteps
+
+BF16 = torch.bfloat16
+
+
+class FrozenConfig(dict):
+    """Attribute + mapping access, like diffusers' FrozenDict (``model.config.patch_size`` / ``dict(model.config)``)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# parameter containers (names == reference / diffusers attribute names == checkpoint keys)
+# ------------------------------------------------------------------------------------------------------------------
+class _NoForward(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError(f"{type(self).__name__} is a parameter container; the arithmetic runs in liborv_mi355.so")
+
+
+class CogVideoXLayerNormZero(_NoForward):
+    """:41-58. ``linear`` is [6D, E] when text is modulated too, else [3D, E]."""
+
+    def __init__(self, conditioning_dim: int, embedding_dim: int, elementwise_affine: bool = True, eps: float = 1e-5,
+                 bias: bool = True, modulate_encoder_hidden_states: Optional[bool] = False) -> None:
+        super().__init__()
+        self.modulate_encoder_hidden_states = modulate_encoder_hidden_states
+        self.silu = nn.SiLU()
+        self.linear = nn.Linear(conditioning_dim, (6 if modulate_encoder_hidden_states else 3) * embedding_dim, bias=bias)
+        self.norm = nn.LayerNorm(embedding_dim, eps=eps, elementwise_affine=elementwise_affine)
+
+
+class AdaLayerNorm(_NoForward):
+    """:153-197 as built at :572-578 (chunk_dim=1; linear output order is (shift, scale))."""
+
+    def __init__(self, embedding_dim: int, output_dim: int, norm_elementwise_affine: bool = False,
+                 norm_eps: float = 1e-5, chunk_dim: int = 0):
+        super().__init__()
+        self.chunk_dim, self.emb = chunk_dim, None
+        self.silu = nn.SiLU()
+        self.linear = nn.Linear(embedding_dim, output_dim)
+        self.norm = nn.LayerNorm(output_dim // 2, norm_eps, norm_elementwise_affine)
+
+
+class Attention(_NoForward):
+    """diffusers ``Attention`` as configured at :382-391 (self-attention, bias, qk LayerNorm eps 1e-6)."""
+
+    def __init__(self, query_dim: int, heads: int, dim_head: int, bias: bool, out_bias: bool, qk_norm: bool = True,
+                 eps: float = 1e-6):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads, self.dim_head, self.eps = heads, dim_head, eps
+        self.to_q = nn.Linear(query_dim, inner, bias=bias)
+        self.to_k = nn.Linear(query_dim, inner, bias=bias)
+        self.to_v = nn.Linear(query_dim, inner, bias=bias)
+        self.norm_q = nn.LayerNorm(dim_head, eps=eps) if qk_norm else None
+        self.norm_k = nn.LayerNorm(dim_head, eps=eps) if qk_norm else None
+        self.to_out = nn.ModuleList([nn.Linear(inner, query_dim, bias=out_bias), nn.Dropout(0.0)])
+        self._packed = None
+
+    def packed_qkv(self):
+        """[3*inner, query_dim] weight and [3*inner] bias for the single fused QKV GEMM (cached per weight version)."""
+        ws = (self.to_q.weight, self.to_k.weight, self.to_v.weight)
+        key = tuple((w.data_ptr(), w._version) for w in ws)
+        if self._packed is None or self._packed[0] != key:
+            w = torch.cat([x.detach() for x in ws], dim=0).contiguous()
+            b = None
+            if self.to_q.bias is not None:
+                b = torch.cat([self.to_q.bias.detach(), self.to_k.bias.detach(), self.to_v.bias.detach()]).contiguous()
+            self._packed = (key, w, b)
+        return self._packed[1], self._packed[2]
+
+
+class _GELUProj(_NoForward):
+    def __init__(self, dim_in, dim_out, bias=True):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out, bias=bias)
+
+
+class FeedForward(_NoForward):
+    """diffusers ``FeedForward(dim, activation_fn='gelu-approximate', final_dropout=True)``: keys net.0.proj / net.2."""
+
+    def __init__(self, dim: int, dropout: float = 0.0, activation_fn: str = "gelu-approximate", inner_dim=None,
+                 bias: bool = True):
+        super().__init__()
+        if activation_fn != "gelu-approximate":
+            raise NotImplementedError(f"activation_fn={activation_fn}: the fused GEMM epilogue implements GELU(tanh)")
+        inner_dim = inner_dim or 4 * dim
+        self.net = nn.ModuleList([_GELUProj(dim, inner_dim, bias), nn.Dropout(dropout),
+                                  nn.Linear(inner_dim, dim, bias=bias), nn.Dropout(dropout)])
+
+
+class CogVideoXBlock(_NoForward):
+    """:351-445."""
+
+    def __init__(self, dim: int, num_attention_heads: int, attention_head_dim: int, time_embed_dim: int,
+                 dropout: float = 0.0, activation_fn: str = "gelu-approximate", attention_bias: bool = False,
+                 qk_norm: bool = True, norm_elementwise_affine: bool = True, norm_eps: float = 1e-5,
+                 attention_out_bias: bool = True, modulate_encoder_hidden_states: Optional[bool] = False, **kwargs):
+        super().__init__()
+        mk = dict(modulate_encoder_hidden_states=modulate_encoder_hidden_states)
+        self.norm1 = CogVideoXLayerNormZero(time_embed_dim, dim, norm_elementwise_affine, norm_eps, bias=True, **mk)
+        self.attn1 = Attention(dim, num_attention_heads, attention_head_dim, attention_bias, attention_out_bias, qk_norm)
+        self.norm2 = CogVideoXLayerNormZero(time_embed_dim, dim, norm_elementwise_affine, norm_eps, bias=True, **mk)
+        self.ff = FeedForward(dim, dropout=dropout, activation_fn=activation_fn)
+        self.modulate_encoder_hidden_states = modulate_encoder_hidden_states
+
+
+class MVBlock(_NoForward):
+    """:273-348 (multiview cross-view attention).  Parameters only: the MV path is a SURVEY §8(f) "next" row."""
+
+    def __init__(self, dim, num_attention_heads, attention_head_dim, time_embed_dim, attention_bias=False, qk_norm=True,
+                 norm_elementwise_affine=True, norm_eps=1e-5, attention_out_bias=True,
+                 modulate_encoder_hidden_states=False):
+        super().__init__()
+        self.norm1 = CogVideoXLayerNormZero(time_embed_dim, dim, norm_elementwise_affine, norm_eps, bias=True,
+                                            modulate_encoder_hidden_states=modulate_encoder_hidden_states)
+        self.attn1 = Attention(dim, num_attention_heads, attention_head_dim, attention_bias, attention_out_bias, qk_norm)
+        self.cam_encoder = nn.Linear(12, dim)
+        self.proj_out = nn.Linear(dim, dim)
+        for p in (*self.cam_encoder.parameters(), *self.proj_out.parameters()):
+            p.data.zero_()
+
+
+class CogVideoXPatchEmbed(_NoForward):
+    """diffusers ``CogVideoXPatchEmbed`` as built at :531-547: ``proj`` (Conv2d k=s=p, or Linear for patch_size_t),
+    ``text_proj`` and the non-persistent sin-cos table."""
+
+    def __init__(self, patch_size=2, patch_size_t=None, in_channels=16, embed_dim=1920, text_embed_dim=4096, bias=True,
+                 sample_width=90, sample_height=60, sample_frames=49, temporal_compression_ratio=4,
+                 max_text_seq_length=226, spatial_interpolation_scale=1.875, temporal_interpolation_scale=1.0,
+                 use_positional_embeddings=True, use_learned_positional_embeddings=True):
+        super().__init__()
+        self.patch_size, self.patch_size_t, self.embed_dim = patch_size, patch_size_t, embed_dim
+        self.sample_height, self.sample_width, self.sample_frames = sample_height, sample_width, sample_frames
+        self.temporal_compression_ratio, self.max_text_seq_length = temporal_compression_ratio, max_text_seq_length
+        self.spatial_interpolation_scale = spatial_interpolation_scale
+        self.temporal_interpolation_scale = temporal_interpolation_scale
+        self.use_positional_embeddings = use_positional_embeddings
+        self.use_learned_positional_embeddings = use_learned_positional_embeddings
+        if patch_size_t is None:
+            self.proj = nn.Conv2d(in_channels, embed_dim, kernel_size=(patch_size, patch_size), stride=patch_size, bias=bias)
+        else:
+            self.proj = nn.Linear(in_channels * patch_size * patch_size * patch_size_t, embed_dim)
+        self.text_proj = nn.Linear(text_embed_dim, embed_dim)
+        if use_positional_embeddings or use_learned_positional_embeddings:
+            self.register_buffer("pos_embedding", self._joint_table(sample_height, sample_width, sample_frames),
+                                 persistent=use_learned_positional_embeddings)
+        self._video_tables: Dict[Any, torch.Tensor] = {}
+
+    def _video_table(self, height, width, pre_frames) -> torch.Tensor:
+        p = self.patch_size
+        frames = (pre_frames - 1) // self.temporal_compression_ratio + 1
+        return sincos_3d(self.embed_dim, width // p, height // p, frames, self.spatial_interpolation_scale,
+                         self.temporal_interpolation_scale)
+
+    def _joint_table(self, height, width, pre_frames) -> torch.Tensor:
+        vid = self._video_table(height, width, pre_frames)
+        joint = torch.zeros(1, self.max_text_seq_length + vid.shape[0], self.embed_dim, dtype=torch.float32)
+        joint[0, self.max_text_seq_length:] = vid
+        return joint
+
+    def video_pos_table(self, latent_frames, height, width, device) -> Optional[torch.Tensor]:
+        """bf16 [T*h*w, D] rows of the table that patch-embed adds to the video tokens (None for RoPE models)."""
+        if not (self.use_positional_embeddings or self.use_learned_positional_embeddings):
+            return None
+        pre = (latent_frames - 1) * self.temporal_compression_ratio + 1
+        key = (latent_frames, height, width, str(device))
+        if key not in self._video_tables:
+            if (height, width, pre) == (self.sample_height, self.sample_width, self.sample_frames):
+                tab = self.pos_embedding[0, self.max_text_seq_length:]
+            else:
+                if self.use_learned_positional_embeddings:
+                    raise ValueError("learned positional embeddings need the trained sample size")
+                tab = self._video_table(height, width, pre)
+            self._video_tables[key] = tab.to(device=device, dtype=BF16).contiguous()
+        return self._video_tables[key]
+
+
+class TimestepEmbedding(_NoForward):
+    def __init__(self, in_channels, time_embed_dim, act_fn="silu"):
+        super().__init__()
+        if act_fn != "silu":
+            raise NotImplementedError("timestep_activation_fn must be 'silu'")
+        self.linear_1 = nn.Linear(in_channels, time_embed_dim)
+        self.act = nn.SiLU()
+        self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
+
+
+_CONFIG_DEFAULTS = dict(
+    num_attention_heads=30, attention_head_dim=64, in_channels=16, out_channels=16, flip_sin_to_cos=True, freq_shift=0,
+    time_embed_dim=512, ofs_embed_dim=None, text_embed_dim=4096, num_layers=30, dropout=0.0, attention_bias=True,
+    sample_width=90, sample_height=60, sample_frames=49, patch_size=2, patch_size_t=None, temporal_compression_ratio=4,
+    max_text_seq_length=226, activation_fn="gelu-approximate", timestep_activation_fn="silu",
+    norm_elementwise_affine=True, norm_eps=1e-5, spatial_interpolation_scale=1.875, temporal_interpolation_scale=1.0,
+    use_rotary_positional_embeddings=False, use_learned_positional_embeddings=False, patch_bias=True,
+    loaded_pretrained_model_name_or_path=None, modulate_encoder_hidden_states=False, num_control_blocks=12,
+    recon_action=False, visual_guidance=False, num_control_keys=2, multiview=False, max_n_view=3, from_t2v=False)
+
+
+class CogVideoXTransformer3DModelTraj(nn.Module):
+    """Trajectory/occupancy-conditioned CogVideoX 3-D DiT (:448-1087)."""
+
+    config_name = "config.json"
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        unknown = {k: v for k, v in kwargs.items() if k not in _CONFIG_DEFAULTS and not k.startswith("_")}
+        cfg = {**_CONFIG_DEFAULTS, **{k: v for k, v in kwargs.items() if k in _CONFIG_DEFAULTS}}
+        self._extra_config = unknown
+        self.config = FrozenConfig(cfg)
+        c = self.config
+        inner = c.num_attention_heads * c.attention_head_dim
+        if c.attention_head_dim != 64:
+            raise NotImplementedError("the attention kernels are built for head_dim 64 (every CogVideoX/ORV config)")
+        self.inner_dim = inner
+        self.patch_embed = CogVideoXPatchEmbed(
+            patch_size=c.patch_size, patch_size_t=c.patch_size_t, in_channels=c.in_channels, embed_dim=inner,
+            text_embed_dim=c.text_embed_dim, bias=c.patch_bias, sample_width=c.sample_width,
+            sample_height=c.sample_height, sample_frames=c.sample_frames,
+            temporal_compression_ratio=c.temporal_compression_ratio, max_text_seq_length=c.max_text_seq_length,
+            spatial_interpolation_scale=c.spatial_interpolation_scale,
+            temporal_interpolation_scale=c.temporal_interpolation_scale,
+            use_positional_embeddings=not c.use_rotary_positional_embeddings,
+            use_learned_positional_embeddings=c.use_learned_positional_embeddings)
+        self.embedding_dropout = nn.Dropout(c.dropout)
+        self.time_embedding = TimestepEmbedding(inner, c.time_embed_dim, c.timestep_activation_fn)
+        self.ofs_embedding = None
+        if c.ofs_embed_dim:
+            if c.ofs_embed_dim != c.time_embed_dim:
+                raise ValueError("ofs_embed_dim must equal time_embed_dim (the embeddings are summed, :775)")
+            self.ofs_embedding = TimestepEmbedding(c.ofs_embed_dim, c.ofs_embed_dim, c.timestep_activation_fn)
+        if fnmatch.fnmatch(str(c.loaded_pretrained_model_name_or_path), 'THUDM*CogVideoX*'):
+            if not c.modulate_encoder_hidden_states:
+                raise RuntimeError(f"You're trying to load {c.loaded_pretrained_model_name_or_path} but"
+                                   "set modulate_encoder_hidden_states to False!")
+        blk = dict(dim=inner, num_attention_heads=c.num_attention_heads, attention_head_dim=c.attention_head_dim,
+                   time_embed_dim=c.time_embed_dim, attention_bias=c.attention_bias,
+                   norm_elementwise_affine=c.norm_elementwise_affine, norm_eps=c.norm_eps,
+                   modulate_encoder_hidden_states=c.modulate_encoder_hidden_states)
+        self.transformer_blocks = nn.ModuleList(
+            [CogVideoXBlock(dropout=c.dropout, activation_fn=c.activation_fn, **blk) for _ in range(c.num_layers)])
+        self.norm_final = nn.LayerNorm(inner, c.norm_eps, c.norm_elementwise_affine)
+        self.norm_out = AdaLayerNorm(embedding_dim=c.time_embed_dim, output_dim=2 * inner,
+                                     norm_elementwise_affine=c.norm_elementwise_affine, norm_eps=c.norm_eps, chunk_dim=1)
+        self.proj_out = nn.Linear(inner, c.patch_size * c.patch_size * (c.patch_size_t or 1) * c.out_channels)
+        # NB the reference passes mask=self.training inside __init__, i.e. always True (:581-582)
+        self.action_embed = ActionEmbed(state_dim=7, hidden_size=c.time_embed_dim, compress_ratio=4,
+                                        patch_size_t=c.patch_size_t, mask=True)
+        self.action_recon = ActionRecon(7, c.time_embed_dim, 4) if c.recon_action else None
+        if c.visual_guidance:
+            if c.num_control_blocks > c.num_layers:
+                raise ValueError("num_tracking_blocks must be less than or equal to num_layers")
+            self.num_control_keys = c.num_control_keys
+            self.initial_combine_linear = nn.Linear(inner * c.num_control_keys, inner)
+        if c.multiview:
+            self.register_buffer("pos_embedding_v", sincos_3d(
+                inner, c.sample_width // c.patch_size, c.sample_height // c.patch_size, c.max_n_view,
+                c.spatial_interpolation_scale, 1.0)[None], persistent=False)
+            self.mv_blocks = nn.ModuleList([MVBlock(**blk) for _ in range(c.num_layers)])
+        self.gradient_checkpointing = False
+        self._ws: Dict[Any, Dict[str, torch.Tensor]] = {}
+        self._set_zeros()
+        self._set_trainable_parameters()
+
+    # ---- reference housekeeping (:625-656) ----
+    def _set_zeros(self):
+        if self.config.from_t2v:
+            self.patch_embed.proj.weight.data[:, -16:, ...].zero_()
+        if hasattr(self, 'initial_combine_linear'):
+            self.initial_combine_linear.weight.data.zero_()
+            self.initial_combine_linear.bias.data.zero_()
+
+    def _set_trainable_parameters(self):
+        if self.config.multiview:
+            for p in self.parameters():
+                p.requires_grad_(False)
+            for p in self.mv_blocks.parameters():
+                p.requires_grad_(True)
+        else:
+            for p in self.parameters():
+                p.requires_grad_(True)
+
+    def enable_gradient_checkpointing(self):
+        self.gradient_checkpointing = True
+
+    @property
+    def dtype(self):
+        return next(self.parameters()).dtype
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    # ---- config / checkpoint surface (:950-1087; diffusers ModelMixin subset) ----
+    @classmethod
+    def from_config(cls, config, **kwargs):
+        cfg = {k: v for k, v in dict(config).items() if not k.startswith("_")}
+        cfg.update(kwargs)
+        return cls(**cfg)
+
+    @classmethod
+    def load_config(cls, path, subfolder: Optional[str] = None, **_):
+        d = os.path.join(path, subfolder) if subfolder and os.path.isdir(os.path.join(path, subfolder)) else path
+        with open(os.path.join(d, cls.config_name), "r", encoding="utf-8") as f:
+            return json.load(f)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder: Optional[str] = None, torch_dtype=None,
+                        revision=None, variant=None, **kwargs):
+        """Loads an ORV checkpoint directly, or converts a vanilla CogVideoX transformer (2B: T2V->I2V channel doubling
+        with the new half zeroed, :1016-1030).  Errors follow the reference: RuntimeError on missing/unexpected/
+        mismatched keys when loading as this class (:955-967)."""
+        from .checkpoint import load_state_dict_dir
+        path = str(pretrained_model_name_or_path)
+        d = os.path.join(path, subfolder) if subfolder and os.path.isdir(os.path.join(path, subfolder)) else path
+        config = cls.load_config(path, subfolder=subfolder)
+        state = load_state_dict_dir(d)
+        same_class = config.get("_class_name") == cls.__name__
+        cfg = {k: v for k, v in config.items() if not k.startswith("_")}
+        if same_class:
+            cfg.update(kwargs)
+            model = cls(**cfg)
+            missing, unexpected = model.load_state_dict(state, strict=False)
+            bad = [k for k, v in state.items() if k in model.state_dict() and model.state_dict()[k].shape != v.shape]
+            msg = ""
+            if missing:
+                msg += f"Some weights of {cls.__name__} are not found in pretrained weights: {missing}. "
+            if unexpected:
+                msg += f"Some weights may be lost in {cls.__name__}: {unexpected}. "
+            if bad:
+                msg += f"Some weights have mismatched shapes: {bad}."
+            if msg:
+                raise RuntimeError(msg)
+        else:
+            if fnmatch.fnmatch(path, 'THUDM*CogVideoX*'):
+                for k in ("sample_height", "sample_width", "sample_frames"):
+                    cfg[k] = kwargs.pop(k)
+            if fnmatch.fnmatch(path, 'THUDM*CogVideoX*-2b*'):
+                assert cfg['in_channels'] == 16, f'Wrong `in_channels` in config of {path}!'
+                cfg['in_channels'] = 32
+                cfg.update(kwargs)
+                model = cls(**cfg, from_t2v=True)
+                w = state.pop('patch_embed.proj.weight')
+                model.load_state_dict(state, strict=False)
+                model.patch_embed.proj.weight.data[:, :16, ...].copy_(w)
+            else:
+                cfg.update(kwargs)
+                model = cls(**cfg)
+                model.load_state_dict(state, strict=False)
+            if model.config.multiview and not ('multiview' in path or config.get("multiview", False)):
+                for i in range(len(model.mv_blocks)):
+                    model.mv_blocks[i].load_state_dict(model.transformer_blocks[i].state_dict(), strict=False)
+        if torch_dtype is not None:
+            model = model.to(torch_dtype)
+        model._set_trainable_parameters()
+        return model
+
+    def save_pretrained(self, save_directory, is_main_process: bool = True, save_function: Optional[Callable] = None,
+                        safe_serialization: bool = True, variant: Optional[str] = None,
+                        max_shard_size: Union[int, str] = "5GB", push_to_hub: bool = False, **kwargs):
+        from .checkpoint import save_state_dict_dir
+        if not is_main_process:
+            return
+        os.makedirs(save_directory, exist_ok=True)
+        save_state_dict_dir(self.state_dict(), save_directory, max_shard_size=max_shard_size)
+        cfg = {**dict(self.config), "_class_name": "CogVideoXTransformer3DModelTraj", "_diffusers_version": "0.32.0.dev0"}
+        with open(os.path.join(save_directory, self.config_name), "w", encoding="utf-8") as f:
+            json.dump(cfg, f, indent=2)
+
+    @staticmethod
+    def compute_action_loss(x, x_recon, loss_weight: dict, mask: Optional[torch.Tensor] = None):
+        """:690-713 (tiny [B,16,7] tensors; plain torch)."""
+        import torch.nn.functional as F
+        if mask is None:
+            mask = torch.ones((x.size(0),), device=x.device).bool()
+        rot_loss = 1 - torch.cos(x_recon[mask, ..., 3:6] - x[mask, ..., 3:6]).mean()
+        x_recon[..., -1] = torch.sigmoid(x_recon[..., -1])
+        pos_loss = F.smooth_l1_loss(x_recon[mask, ..., :3], x[mask, ..., :3])
+        grip_loss = F.smooth_l1_loss(x_recon[mask, ..., -1], x[mask, ..., -1])
+        return (rot_loss * loss_weight['rot_loss'], pos_loss * loss_weight['pos_loss'],
+                grip_loss * loss_weight['grip_loss'])
+
+    # ---- the hot path ----
+    def _workspace(self, B, S, Nv, dev):
+        c = self.config
+        D, H = self.inner_dim, c.num_attention_heads
+        key = (B, S, Nv, str(dev))
+        if key not in self._ws:
+            s_pad = (S + 63) // 64 * 64
+            M = B * S
+            e = lambda *shape, dt=BF16: torch.empty(*shape, dtype=dt, device=dev)
+            self._ws = {key: dict(x=e(M, D), xn=e(M, D), qkv=e(M, 3 * D), att=e(M, D), h=e(M, 4 * D),
+                                  vT=torch.zeros(B, H, 64, s_pad, dtype=BF16, device=dev), vis=e(B * Nv, D),
+                                  vis2=e(B * Nv, D), s_pad=s_pad)}
+        return self._ws[key]
+
+    def _linear_k64(self, x2d, lin):
+        """A and W of a GEMM whose K is not a multiple of 64 (only tiny test configs) get zero-padded."""
+        W, K = lin.weight.reshape(lin.weight.shape[0], -1), x2d.shape[1]
+        if K % 64:
+            pad = 64 - K % 64
+            x2d, W = torch.nn.functional.pad(x2d, (0, pad)), torch.nn.functional.pad(W, (0, pad))
+        return x2d.contiguous(), W.contiguous()
+
+    @torch.no_grad()
+    def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor,
+                controls_or_guidances: Dict[str, torch.Tensor], timestep: Union[int, float, torch.LongTensor],
+                timestep_cond: Optional[torch.Tensor] = None, ofs: Optional[Union[int, float, torch.LongTensor]] = None,
+                image_rotary_emb: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                attention_kwargs: Optional[Dict[str, Any]] = None, return_dict: bool = True, num_views: int = 1,
+                image_rotary_emb_view: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        c = self.config
+        if not hidden_states.is_cuda:
+            raise RuntimeError("orv_amd runs on MI355X only: move the model and its inputs to the GPU (no CPU fallback)")
+        if self.dtype != BF16:
+            raise RuntimeError(f"orv_amd kernels are bf16: call model.to(torch.bfloat16) (got {self.dtype})")
+        if c.multiview or num_views > 1:
+            raise NotImplementedError("multiview (MVBlock, :273-348) is a SURVEY §8(f) 'next' row, not built yet")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            pass  # inference kernels only in this round; gradients are not recorded (see DESIGN.md "next")
+        dev = hidden_states.device
+        B, T, C, Hh, Ww = hidden_states.shape
+        p, pt = c.patch_size, c.patch_size_t
+        D, heads, E = self.inner_dim, c.num_attention_heads, c.time_embed_dim
+        mod_text = bool(c.modulate_encoder_hidden_states)
+        Nt = encoder_hidden_states.shape[1] if mod_text else 0
+        Tq = T // (pt or 1)
+        P = (Hh // p) * (Ww // p)
+        Nv = Tq * P
+        S = Nt + Nv
+        ws = self._workspace(B, S, Nv, dev)
+        x, xn, qkv, att, hbuf, vT, s_pad = ws["x"], ws["xn"], ws["qkv"], ws["att"], ws["h"], ws["vT"], ws["s_pad"]
+
+        # 1. time (+ofs) embedding  (:762-775)
+        tvec = torch.as_tensor(timestep, device=dev).reshape(-1).to(torch.float32)
+        if tvec.numel() == 1 and B > 1:
+            tvec = tvec.expand(B)
+        te = self.time_embedding
+        t_emb = ops.timestep_embedding(tvec.contiguous(), D, c.flip_sin_to_cos, c.freq_shift)
+        temb = ops.skinny_linear(ops.skinny_linear(t_emb, te.linear_1.weight, te.linear_1.bias, act_out="silu"),
+                                 te.linear_2.weight, te.linear_2.bias)
+        if self.ofs_embedding is not None:
+            oe = self.ofs_embedding
+            ovec = torch.as_tensor(ofs, device=dev).reshape(-1).to(torch.float32)
+            o_emb = ops.timestep_embedding(ovec.contiguous(), c.ofs_embed_dim, c.flip_sin_to_cos, c.freq_shift)
+            o_emb = ops.skinny_linear(ops.skinny_linear(o_emb, oe.linear_1.weight, oe.linear_1.bias, act_out="silu"),
+                                      oe.linear_2.weight, oe.linear_2.bias)
+            temb = temb + o_emb          # [B,E] + [1,E]; tiny glue add in the model dtype as at :775
+
+        # 2. patch embedding straight into the joint [B,S,D] buffer (:788-794)
+        pe = self.patch_embed
+        tokens = ops.patchify(hidden_states.to(BF16), None, p, pt)
+        a2, w2 = self._linear_k64(tokens.view(B * Nv, -1), pe.proj)
+        pos = pe.video_pos_table(T, Hh, Ww, dev)
+        ops.gemm(a2, w2, pe.proj.bias, x, B * Nv, D, a2.shape[1], epilogue=2 if pos is not None else 0, R=pos, r_mod=Nv,
+                 ldr=D, cmap=ops.rowmap(Nv, S, Nt))
+        if mod_text:
+            a2, w2 = self._linear_k64(encoder_hidden_states.to(BF16).reshape(B * Nt, -1), pe.text_proj)
+            ops.gemm(a2, w2, pe.text_proj.bias, x, B * Nt, D, a2.shape[1], cmap=ops.rowmap(Nt, S, 0))
+
+        # 3. action embedding (:805-825)
+        action_emb = is_action_mask = actions_recon = None
+        actions = controls_or_guidances.get('actions', None)
+        if actions is not None:
+            actions = actions.to(device=dev)
+            res = (actions.size(1) + 1) % 4
+            pad_frames = 4 - res if res > 0 else 0
+            if pad_frames:
+                actions = torch.cat([actions.new_zeros((actions.shape[0], pad_frames, actions.shape[2])), actions], dim=1)
+            action_emb, is_action_mask = self.action_embed(actions)
+            if self.training and c.recon_action and self.action_recon is not None:
+                actions_recon = self.action_recon(action_emb)
+                if pad_frames > 0:
+                    actions_recon = actions_recon[:, pad_frames:]
+        if controls_or_guidances.get('depths', None) is not None and c.visual_guidance:
+            raise NotImplementedError("visual_guidance fuse (:828-858, BASELINE config 4) is not built yet")
+
+        # 4. modulation tables for every norm, fp32 [B, G, 3D]: group 0 = text rows, 1.. = frames (:117-145)
+        Ta = action_emb.shape[1] if action_emb is not None else 1
+        if Nv % Ta:
+            raise ValueError(f"{Nv} video tokens cannot be split over {Ta} action frames")
+        per_group = Nv // Ta if action_emb is not None else 0
+        G = 1 + Ta
+        grp = ops.groups(S, Nt, per_group)
+        L = c.num_layers
+        mod = torch.zeros(2 * L, B, G, 3 * D, dtype=torch.float32, device=dev)
+        a2d = action_emb.reshape(B * Ta, E).contiguous() if action_emb is not None else None
+
+        def fill(table, lin, width, text):
+            wv, bv = lin.weight[:width], (lin.bias[:width] if lin.bias is not None else None)
+            if a2d is not None:
+                ops.skinny_linear(a2d, wv, bv, xb=temb, xb_rep=Ta, act_in="silu", out=table, ldo=width,
+                                  omap=ops.rowmap(Ta, G, 1))
+            else:
+                ops.skinny_linear(temb, wv, bv, act_in="silu", out=table, ldo=width, omap=ops.rowmap(1, G, 1))
+            if text:
+                wt, bt = lin.weight[width:], (lin.bias[width:] if lin.bias is not None else None)
+                ops.skinny_linear(temb, wt, bt, act_in="silu", out=table, ldo=width, omap=ops.rowmap(1, G, 0))
+
+        for i, blk in enumerate(self.transformer_blocks):
+            fill(mod[2 * i], blk.norm1.linear, 3 * D, mod_text)
+            fill(mod[2 * i + 1], blk.norm2.linear, 3 * D, mod_text)
+        modf = torch.zeros(B, G, 2 * D, dtype=torch.float32, device=dev)
+        fill(modf, self.norm_out.linear, 2 * D, False)
+
+        rope = None
+        if image_rotary_emb is not None:
+            rope = tuple(r.to(device=dev, dtype=torch.float32).contiguous() for r in image_rotary_emb)
+
+        # 5. transformer blocks (:861-907 -> :394-445)
+        M = B * S
+        mb, mg = G * 3 * D, 3 * D
+        scale = 1.0 / math.sqrt(c.attention_head_dim)
+        for i, blk in enumerate(self.transformer_blocks):
+            m1, m2 = mod[2 * i], mod[2 * i + 1]
+            at = blk.attn1
+            ops.layernorm_modulate(x, xn, blk.norm1.norm.weight, blk.norm1.norm.bias, m1[..., D:2 * D], m1[..., :D],
+                                   mb, mg, grp, B, D, c.norm_eps)
+            wqkv, bqkv = at.packed_qkv()
+            ops.gemm(xn, wqkv, bqkv, qkv, M, 3 * D, D)
+            nq, nk = at.norm_q, at.norm_k
+            ops.qkv_prep(qkv, vT, nq.weight, nq.bias, nk.weight, nk.bias, rope, B, S, heads, Nt, s_pad, at.eps)
+            ops.attention_fwd(qkv, vT, att, B, S, heads, s_pad, scale)
+            ops.gemm(att, at.to_out[0].weight, at.to_out[0].bias, x, M, D, D, epilogue=2, R=x, ldr=D,
+                     gate=m1[..., 2 * D:], gate_b=mb, gate_g=mg, grp=grp)
+            ops.layernorm_modulate(x, xn, blk.norm2.norm.weight, blk.norm2.norm.bias, m2[..., D:2 * D], m2[..., :D],
+                                   mb, mg, grp, B, D, c.norm_eps)
+            f0, f2 = blk.ff.net[0].proj, blk.ff.net[2]
+            ops.gemm(xn, f0.weight, f0.bias, hbuf, M, f0.weight.shape[0], D, epilogue=1)
+            ops.gemm(hbuf, f2.weight, f2.bias, x, M, D, f0.weight.shape[0], epilogue=2, R=x, ldr=D,
+                     gate=m2[..., 2 * D:], gate_b=mb, gate_g=mg, grp=grp)
+
+        # 6. head: norm_final is row-wise, so the 2B (:916) and 5B (:911-913) branches are the same arithmetic on the
+        #    video rows; read them in place from the joint buffer.
+        vis, vis2 = ws["vis"], ws["vis2"]
+        gv = ops.groups(Nv, 0, per_group)
+        ops.layernorm_modulate(x, vis, self.norm_final.weight, self.norm_final.bias, None, None, 0, 0, gv, B, D,
+                               c.norm_eps, xmap=ops.rowmap(Nv, S, Nt))
+        no = self.norm_out
+        ops.layernorm_modulate(vis, vis2, no.norm.weight, no.norm.bias, modf[..., D:], modf[..., :D], G * 2 * D, 2 * D,
+                               gv, B, D, c.norm_eps)
+        fo = self.proj_out.weight.shape[0]
+        wo, bo = self.proj_out.weight, self.proj_out.bias
+        if fo % 64:
+            padn = 64 - fo % 64
+            wo = torch.nn.functional.pad(wo, (0, 0, 0, padn)).contiguous()
+            bo = torch.nn.functional.pad(bo, (0, padn)).contiguous() if bo is not None else None
+        out_tok = torch.empty(B * Nv, wo.shape[0], dtype=BF16, device=dev)
+        ops.gemm(vis2, wo, bo, out_tok, B * Nv, wo.shape[0], D)
+        if wo.shape[0] != fo:
+            out_tok = out_tok[:, :fo].contiguous()
+        output = ops.unpatchify(out_tok, B, T, fo // (p * p * (pt or 1)), Hh, Ww, p, pt)
+
+        if not return_dict:
+            return (output, is_action_mask, actions_recon)
+        return Transformer3DModelTrajOutput(sample=output, is_action_mask=is_action_mask, actions_recon=actions_recon)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# sampler pipeline (:1090-1489)
+# ------------------------------------------------------------------------------------------------------------------
+class CogVideoXPipelineOutput:
+    def __init__(self, frames):
+        self.frames = frames
+
+
+class CogVideoXImageToVideoPipelineTraj:
+    """Latent-space part of the reference's I2V pipeline: ``prepare_latents`` (:1115-1225) and the denoise loop of
+    ``__call__`` (:1402-1473).  VAE encode/decode and T5 are SURVEY §8(f) "next" rows: pass pre-encoded latents /
+    ``prompt_embeds`` and ``output_type='latent'`` (what the reference's dataset cache provides), or plug a ``vae`` /
+    ``text_encoder`` object with the diffusers interface."""
+
+    def __init__(self, tokenizer=None, text_encoder=None, vae=None, transformer: CogVideoXTransformer3DModelTraj = None,
+                 scheduler: Union[CogVideoXDDIMScheduler, CogVideoXDPMScheduler] = None):
+        if not isinstance(transformer, CogVideoXTransformer3DModelTraj):
+            raise ValueError("The transformer in this pipeline must be of type CogVideoXTransformer3DModelTraj")
+        self.tokenizer, self.text_encoder, self.vae = tokenizer, text_encoder, vae
+        self.transformer, self.scheduler = transformer, scheduler
+        vcfg = getattr(vae, "config", None)
+        self.vae_scale_factor_spatial = 2 ** (len(vcfg.block_out_channels) - 1) if vcfg is not None else 8
+        self.vae_scale_factor_temporal = getattr(vcfg, "temporal_compression_ratio", 4) if vcfg is not None else 4
+        self.vae_scaling_factor_image = getattr(vcfg, "scaling_factor", 1.15258426) if vcfg is not None else 1.15258426
+        self.invert_scale_latents = bool(getattr(vcfg, "invert_scale_latents", False)) if vcfg is not None else False
+        self._guidance_scale, self._interrupt, self._num_timesteps = 1.0, False, 0
+
+    guidance_scale = property(lambda self: self._guidance_scale)
+    interrupt = property(lambda self: self._interrupt)
+    num_timesteps = property(lambda self: self._num_timesteps)
+
+    def to(self, device=None, dtype=None):
+        self.transformer.to(device=device, dtype=dtype)
+        return self
+
+    @property
+    def _execution_device(self):
+        return self.transformer.device
+
+    def _scale(self):
+        return 1 / self.vae_scaling_factor_image if self.invert_scale_latents else self.vae_scaling_factor_image
+
+    def prepare_latents(self, image: torch.Tensor, batch_size: int = 1, num_channels_latents: int = 16,
+                        num_frames: int = 13, num_views: int = 1, height: int = 60, width: int = 90,
+                        dtype: Optional[torch.dtype] = None, device: Optional[torch.device] = None,
+                        generator: Optional[torch.Generator] = None, latents: Optional[torch.Tensor] = None):
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(
+                f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        pt = self.transformer.config.patch_size_t
+        t_lat = (num_frames - 1) // self.vae_scale_factor_temporal + 1
+        shape = (batch_size, num_views * t_lat, num_channels_latents, height // self.vae_scale_factor_spatial,
+                 width // self.vae_scale_factor_spatial)
+        if pt is not None:
+            shape = shape[:1] + (shape[1] + shape[1] % pt,) + shape[2:]
+        if image.ndim == 4:
+            raise NotImplementedError("RGB reference frames need the VAE encoder (SURVEY §8(f) next row); pass latents")
+        if image.ndim != 5:
+            raise RuntimeError(f'Invalid dimensions of image input: {image.shape=}')
+        ch = image.size(1)
+        image = image.to(device=device, dtype=dtype)
+        if ch == num_channels_latents * 2:
+            eps = _randn(tuple(image.shape[:1]) + (num_channels_latents,) + tuple(image.shape[2:]), generator, device, dtype)
+            image_latents = ops.gaussian_sample(image, eps.float(), self._scale())         # fused sample+scale+permute
+        elif ch == num_channels_latents:
+            image_latents = (self._scale() * image).permute(0, 2, 1, 3, 4)
+        else:
+            raise RuntimeError(f'Invalid input channels {image.shape=} while {num_channels_latents=}!')
+        b, vf = image_latents.shape[:2]
+        image_latents = image_latents.reshape(b, num_views, vf // num_views, *image_latents.shape[2:])
+        f_img = image_latents.size(2)
+        if f_img > t_lat:
+            raise RuntimeError(f'Invalid input image_frames={f_img} while num_frames={t_lat}!')
+        pad = torch.zeros((batch_size, num_views, t_lat - f_img) + tuple(shape[2:]), device=device, dtype=dtype)
+        image_latents = torch.cat([image_latents, pad], dim=2)
+        if pt is not None:
+            first = image_latents[:, :, : image_latents.size(1) % pt, ...]
+            image_latents = torch.cat([first, image_latents], dim=2)
+        image_latents = image_latents.flatten(1, 2).contiguous()
+        if latents is None:
+            latents = _randn(shape, generator, device, dtype)
+        else:
+            latents = latents.to(device)
+        return latents * self.scheduler.init_noise_sigma, image_latents
+
+    @torch.no_grad()
+    def __call__(self, image, prompt=None, negative_prompt=None, height: Optional[int] = None,
+                 width: Optional[int] = None, num_views: int = 1, num_frames: int = 49, num_inference_steps: int = 50,
+                 timesteps: Optional[List[int]] = None, guidance_scale: float = 6, use_dynamic_cfg: bool = False,
+                 num_videos_per_prompt: int = 1, eta: float = 0.0, generator=None, latents=None, prompt_embeds=None,
+                 negative_prompt_embeds=None, output_type: str = "pil", return_dict: bool = True,
+                 attention_kwargs=None, callback_on_step_end=None,
+                 callback_on_step_end_tensor_inputs: List[str] = ["latents"], max_sequence_length: int = 226,
+                 controls_or_guidances: Dict[str, torch.Tensor] = {}):
+        tr, sched = self.transformer, self.scheduler
+        self._guidance_scale, self._interrupt = guidance_scale, False
+        if prompt_embeds is None:
+            raise NotImplementedError("T5 prompt encoding is a SURVEY §8(f) next row: pass prompt_embeds "
+                                      "(the reference's dataset caches them, dataset.py:1056-1059)")
+        device = self._execution_device
+        dtype = tr.dtype
+        batch_size = prompt_embeds.shape[0]
+        do_cfg = guidance_scale > 1.0
+        prompt_embeds = prompt_embeds.to(device=device, dtype=dtype)
+        if do_cfg:
+            prompt_embeds = torch.cat([negative_prompt_embeds.to(device=device, dtype=dtype), prompt_embeds], dim=0)
+        timesteps, num_inference_steps = retrieve_timesteps(sched, num_inference_steps, device, timesteps)
+        self._num_timesteps = len(timesteps)
+        ts_host = timesteps.tolist()
+        latent_frames = (num_frames - 1) // self.vae_scale_factor_temporal + 1
+        in_ch = tr.config.in_channels
+        latent_channels = in_ch // 2 if in_ch != 16 else in_ch
+        pt = tr.config.patch_size_t
+        controls = dict(controls_or_guidances)
+        if pt is not None and latent_frames % pt != 0:
+            add = pt - latent_frames % pt
+            num_frames += add * self.vae_scale_factor_temporal
+            if controls.get('actions', None) is not None:
+                a = controls['actions']
+                controls['actions'] = torch.cat(
+                    [a, torch.zeros((a.size(0), add * self.vae_scale_factor_temporal, a.size(2)), dtype=a.dtype,
+                                    device=a.device)], dim=1)
+        for key in ('depths', 'labels'):
+            if controls.get(key, None) is not None:
+                raise NotImplementedError("visual guidance controls (BASELINE config 4) are not built yet")
+        image = image.to(device=device, dtype=dtype) if torch.is_tensor(image) else image
+        latents, image_latents = self.prepare_latents(image, batch_size * num_videos_per_prompt, latent_channels,
+                                                      num_frames, num_views, height, width, dtype, device, generator,
+                                                      latents)
+        image_rotary_emb = None
+        if tr.config.use_rotary_positional_embeddings:
+            from .utils import prepare_rotary_positional_embeddings
+            # the reference's inherited helper uses the transformer's sample size as the RoPE base grid
+            image_rotary_emb = prepare_rotary_positional_embeddings(
+                height, width, latents.size(1), self.vae_scale_factor_spatial, tr.config.patch_size, pt,
+                tr.config.attention_head_dim, device,
+                base_height=tr.config.sample_height * self.vae_scale_factor_spatial,
+                base_width=tr.config.sample_width * self.vae_scale_factor_spatial)
+        ofs_emb = None if tr.config.ofs_embed_dim is None else latents.new_full((1,), fill_value=2.0)
+        is_dpm = isinstance(sched, CogVideoXDPMScheduler)
+        old_x0 = None
+        for i, t in enumerate(ts_host):
+            if self._interrupt:
+                continue
+            # channel-concat [latents | image_latents] (:1409-1413)
+            x_in = torch.cat([latents] * 2) if do_cfg else latents
+            img_in = torch.cat([image_latents] * 2) if do_cfg else image_latents
+            model_in = torch.cat([x_in, img_in], dim=2)
+            tvec = torch.full((model_in.shape[0],), t, device=device, dtype=torch.int64)
+            noise_pred = tr(hidden_states=model_in, encoder_hidden_states=prompt_embeds, timestep=tvec, ofs=ofs_emb,
+                            image_rotary_emb=image_rotary_emb, attention_kwargs=attention_kwargs,
+                            controls_or_guidances=controls, return_dict=False, num_views=num_views)[0]
+            gs = guidance_scale
+            if use_dynamic_cfg:
+                gs = 1 + guidance_scale * ((1 - math.cos(math.pi * ((num_inference_steps - t) / num_inference_steps) ** 5.0)) / 2)
+                self._guidance_scale = gs
+            v_u = v_c = noise_pred
+            if do_cfg:
+                v_u, v_c = noise_pred.chunk(2)
+            kw = dict(model_output_uncond=v_u.contiguous() if do_cfg else None, guidance_scale=gs)
+            if not is_dpm:
+                latents = sched.step(v_c.contiguous(), t, latents, return_dict=False, **kw)[0]
+            else:
+                latents, old_x0 = sched.step(v_c.contiguous(), old_x0, t, ts_host[i - 1] if i > 0 else None, latents,
+                                             generator=generator, **kw)
+            if callback_on_step_end is not None:
+                avail = {"latents": latents, "prompt_embeds": prompt_embeds,
+                         "negative_prompt_embeds": negative_prompt_embeds}
+                cb = callback_on_step_end(self, i, t, {k: avail[k] for k in callback_on_step_end_tensor_inputs})
+                latents = cb.pop("latents", latents)
+                prompt_embeds = cb.pop("prompt_embeds", prompt_embeds)
+        b, vf = latents.shape[:2]
+        latents = latents.reshape(b * num_views, vf // num_views, *latents.shape[2:])
+        if output_type != "latent":
+            raise NotImplementedError("VAE decode is a SURVEY §8(f) next row: use output_type='latent'")
+        if not return_dict:
+            return (latents,)
+        return CogVideoXPipelineOutput(frames=latents)
+
+
+def _randn(shape, generator, device, dtype):
+    """diffusers ``randn_tensor``: a CPU generator draws on the CPU in the target dtype, then the result is copied."""
+    device = torch.device(device) if device is not None else torch.device("cpu")
+    if isinstance(generator, list):
+        return torch.cat([_randn((1,) + tuple(shape[1:]), g, device, dtype) for g in generator], dim=0)
+    if generator is not None and generator.device.type == "cpu" and device.type != "cpu":
+        return torch.randn(tuple(shape), generator=generator, device="cpu", dtype=dtype).to(device)
+    return torch.randn(tuple(shape), generator=generator, device=device, dtype=dtype)

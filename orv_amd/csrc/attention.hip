@@ -1,0 +1,183 @@
+// Flash-style attention forward for gfx950: softmax(q k^T * scale) v, non-causal, unmasked, head_dim 64,
+// over the joint text+video sequence (F.scaled_dot_product_attention at orv/models/cogvideox_control.py:256-258).
+//
+// One workgroup = 8 waves = 256 query rows of one (batch, head); each wave owns 32 query rows.
+//   * q and k are read IN PLACE from the packed qkv activation [B*S, 3*H*64] (no head-split copy, :239-241);
+//     v comes pre-transposed per head from orv_qkv_prep as vT[b,h,d,pos] so that both MFMA A-operands (K rows and
+//     V^T rows) are 128-byte K-contiguous lines, staged with global_load_lds into a swizzled, double-buffered LDS ring
+//     (same conflict-free chunk ^ ((row>>1)&7) image as the GEMM).
+//   * QK^T is computed swapped (S^T = K . Q^T, v_mfma_f32_32x32x16_bf16): the accumulator column is the query row,
+//     so each lane holds 32 scores of ONE query row -> the softmax row max/sum is lane-local plus one exchange with
+//     lane^32, and the probabilities re-enter the PV MFMA as its B operand straight from registers.
+//   * The MFMA contraction order over keys is free; the accumulator hands lane-half `hi` the keys
+//     {0-3,8-11}+4*hi of each 16-key group, so orv_qkv_prep stores V^T with the two middle quads of every 16-key group
+//     swapped (pos = key with bits 2 and 3 exchanged).  A plain ds_read_b128 of V^T then lines up with P - no permute.
+//   * O^T = V^T . P^T accumulates with the query row on the lane axis as well, so the online-softmax rescale is a
+//     per-lane scalar multiply.
+#include "common.hpp"
+
+namespace {
+
+constexpr int KV = 64;            // keys per tile
+constexpr int TILE_BYTES = 8192;  // 64 rows x 128 B (K tile, and V^T tile)
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+
+struct AttnArgs {
+    const bf16_t* qkv; long ld;
+    const bf16_t* vT;
+    bf16_t* out; long ld_out;
+    float* lse;
+    int B, S, H, s_pad;
+    float scale_log2;  // scale * log2(e)
+    float scale;
+};
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 256 + wave * 32;
+    const int D = p.H * 64;
+    const long row0 = (long)b * p.S;
+
+    // ---- Q fragments (B operand of S^T = K.Q^T): lane holds q row (q0+l31), d = ks*16 + hi*8 .. +8 ----
+    bf16x8 qf[4];
+    {
+        const int qr = min(q0 + l31, p.S - 1);
+        const bf16_t* qp = p.qkv + (row0 + qr) * p.ld + h * 64 + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+    }
+
+    // ---- staging: wave w moves K rows 8w..8w+7 and V^T rows (d) 8w..8w+7 of each tile ----
+    const int srow = wave * 8 + (lane >> 3), slot = lane & 7;
+    const int schunk = slot ^ ((srow >> 1) & 7);
+    const bf16_t* kbase = p.qkv + D + h * 64 + schunk * 8;                                   // + key row * ld
+    const bf16_t* vsrc = p.vT + ((long)(b * p.H + h) * 64 + srow) * p.s_pad + schunk * 8;  // + kv0
+    auto stage_load = [&](int s, int kv0) {
+        const int krow = min(kv0 + srow, p.S - 1);
+        glds16(kbase + (row0 + krow) * p.ld, smem + s * STAGE_BYTES + wave * 1024);
+        glds16(vsrc + kv0, smem + s * STAGE_BYTES + TILE_BYTES + wave * 1024);
+    };
+
+    f32x16 oT[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oT[i][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;  // running max (raw score units) and this lane's partial row sum
+    const float c = p.scale_log2;
+    const int row_off = l31 * 128;
+
+    const int nt = (p.S + KV - 1) / KV;
+    stage_load(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) stage_load((t + 1) & 1, (t + 1) * KV);
+        const char* sK = smem + (t & 1) * STAGE_BYTES;
+        const char* sV = sK + TILE_BYTES;
+
+        // S^T[kb] : rows = keys kb*32.., cols = q
+        f32x16 sT[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sT[kb][e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(sK + kb * 4096 + row_off + (((ks * 2 + hi) ^ sw) * 16));
+                sT[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sT[kb], 0, 0, 0);
+            }
+        }
+        // tail tile: keys >= S contribute nothing
+        if (t == nt - 1 && (p.S & (KV - 1)) != 0) {
+            const int kv0 = t * KV;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= p.S) sT[kb][r] = -INFINITY;
+                }
+        }
+        // online softmax: row max over this lane's 32 scores, combined with the partner half (lane ^ 32)
+        float tmax = sT[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sT[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sT[1][r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = fast_exp2((m_run - m_new) * c);
+        const float mc = m_new * c;
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = fast_exp2(fmaf(sT[kb][r], c, -mc));
+                sT[kb][r] = pv;
+                psum += pv;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oT[i][e] *= alpha;
+
+        // O^T[db] += V^T[db rows] . P^T ; k-step kk covers 16 keys, P fragment = 8 consecutive accumulator regs
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            union { bf16x8 v; uint32_t u[4]; } pf;
+            const int kb = kk >> 1, r0 = (kk & 1) * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pf.u[i] = pack2bf(sT[kb][r0 + 2 * i], sT[kb][r0 + 2 * i + 1]);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const bf16x8 vf = *(const bf16x8*)(sV + db * 4096 + row_off + (((kk * 2 + hi) ^ sw) * 16));
+                oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, oT[db], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: normalise, store O[q, h*64 + d] with d = db*32 + (r&3) + 8*(r>>2) + 4*hi ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + l31;
+    if (q < p.S) {
+        bf16_t* op = p.out + (row0 + q) * p.ld_out + h * 64 + hi * 4;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                uint2 o;
+                o.x = pack2bf(oT[db][qd * 4 + 0] * inv, oT[db][qd * 4 + 1] * inv);
+                o.y = pack2bf(oT[db][qd * 4 + 2] * inv, oT[db][qd * 4 + 3] * inv);
+                *(uint2*)(op + db * 32 + qd * 8) = o;
+            }
+        if (p.lse && hi == 0) p.lse[((long)b * p.H + h) * p.S + q] = m_run * p.scale + __logf(l_tot);
+    }
+}
+
+}  // namespace
+
+extern "C" int orv_attention_fwd(const void* qkv, int ld_qkv, const void* vT, void* out, int ld_out, float* lse, int B,
+                                 int S, int H, int s_pad, float scale, void* stream) {
+    ORV_REQUIRE(qkv && vT && out, "orv_attention_fwd: null operand");
+    ORV_REQUIRE(B > 0 && S > 0 && H > 0, "orv_attention_fwd: empty problem");
+    ORV_REQUIRE(s_pad % 64 == 0 && s_pad >= S, "orv_attention_fwd: s_pad=%d must be a multiple of 64 and >= S=%d", s_pad, S);
+    ORV_REQUIRE(ld_qkv % 8 == 0 && ld_out % 4 == 0, "orv_attention_fwd: misaligned leading dimension");
+    AttnArgs a;
+    a.qkv = (const bf16_t*)qkv; a.ld = ld_qkv; a.vT = (const bf16_t*)vT; a.out = (bf16_t*)out; a.ld_out = ld_out;
+    a.lse = lse; a.B = B; a.S = S; a.H = H; a.s_pad = s_pad;
+    a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
+    dim3 grid((S + 255) / 256, H, B);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(512), 0, (hipStream_t)stream, a);
+    return orv_check_launch("orv_attention_fwd");
+}

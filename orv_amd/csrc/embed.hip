@@ -1,0 +1,239 @@
+// Small kernels around the DiT trunk (all HBM/latency-bound, no MFMA):
+//   orv_timestep_embedding, orv_skinny_linear, orv_patchify, orv_unpatchify, orv_sched_step, orv_gaussian_sample
+#include "common.hpp"
+
+namespace {
+
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, bf16_t* __restrict__ out, int batch, int dim,
+                                          int flip, float shift) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch * half) return;
+    const int b = i / half, k = i % half;
+    const float freq = expf(-logf(10000.f) * (float)k / ((float)half - shift));
+    const float a = t[b] * freq;
+    const float s = sinf(a), c = cosf(a);
+    bf16_t* o = out + (long)b * dim;
+    if (flip) { o[k] = f2bf(c); o[half + k] = f2bf(s); }
+    else { o[k] = f2bf(s); o[half + k] = f2bf(c); }
+    if ((dim & 1) && k == 0) o[dim - 1] = 0;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    return act == 1 ? silu(v) : (act == 2 ? gelu_tanh(v) : v);
+}
+
+// Block = 256 threads (4 waves), handles MT=16 rows x NPB output columns. x tile staged once in LDS as fp32.
+constexpr int SK_MT = 16;
+constexpr int SK_NPW = 8;   // output columns per wave
+__global__ __launch_bounds__(256) void skinny_linear_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ xb,
+                                                            int xb_rep, const bf16_t* __restrict__ W,
+                                                            const bf16_t* __restrict__ bias, void* __restrict__ out,
+                                                            int M, int N, int K, int act_in, int act_out, int out_f32,
+                                                            long ldo, orv_rowmap_t omap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* xs = (bf16_t*)smem;  // [SK_MT][K] bf16, act_in applied
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * SK_MT;
+    const int mt = min(SK_MT, M - m0);
+    for (int i = tid; i < SK_MT * K; i += 256) {
+        const int r = i / K, k = i % K;
+        float v = 0.f;
+        if (r < mt) {
+            v = bf2f(x[(long)(m0 + r) * K + k]);
+            if (xb) v = bf2f(f2bf(v + bf2f(xb[(long)((m0 + r) / xb_rep) * K + k])));  // the reference adds in the model dtype
+            v = apply_act(v, act_in);
+        }
+        xs[r * K + k] = f2bf(v);
+    }
+    __syncthreads();
+    const int nchunk = (K % 8 == 0) ? (K >> 3) : 0;  // rows are 16-byte aligned only when K % 8 == 0
+    for (int j = 0; j < SK_NPW; ++j) {
+        const int n = (blockIdx.x * 4 + wave) * SK_NPW + j;
+        if (n >= N) break;
+        float acc[SK_MT];
+#pragma unroll
+        for (int r = 0; r < SK_MT; ++r) acc[r] = 0.f;
+        const bf16_t* wr = W + (long)n * K;
+        for (int c = lane; c < nchunk; c += 64) {
+            const uint4 u = *(const uint4*)(wr + c * 8);
+            const uint32_t ww[4] = {u.x, u.y, u.z, u.w};
+            float wv[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { wv[2 * e] = bf2f(ww[e] & 0xffff); wv[2 * e + 1] = bf2f(ww[e] >> 16); }
+#pragma unroll
+            for (int r = 0; r < SK_MT; ++r) {
+                const uint4 xu = *(const uint4*)(xs + r * K + c * 8);
+                const uint32_t xw[4] = {xu.x, xu.y, xu.z, xu.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[r] = fmaf(bf2f(xw[e] & 0xffff), wv[2 * e], acc[r]);
+                    acc[r] = fmaf(bf2f(xw[e] >> 16), wv[2 * e + 1], acc[r]);
+                }
+            }
+        }
+        // scalar tail when K is not a multiple of 8 (ActionEmbed: K = 28)
+        for (int k = (nchunk << 3) + lane; k < K; k += 64) {
+            const float wv = bf2f(wr[k]);
+#pragma unroll
+            for (int r = 0; r < SK_MT; ++r) acc[r] = fmaf(bf2f(xs[r * K + k]), wv, acc[r]);
+        }
+        const float bv = bias ? bf2f(bias[n]) : 0.f;
+#pragma unroll
+        for (int r = 0; r < SK_MT; ++r) {
+            const float v = wave_sum(acc[r]);
+            if (lane == 0 && r < mt) {
+                const float o = apply_act(v + bv, act_out);
+                const int m = m0 + r;
+                const long orow = omap.rows > 0 ? (long)(m / omap.rows) * omap.bstride + omap.off + m % omap.rows : m;
+                if (out_f32) ((float*)out)[orow * ldo + n] = o;
+                else ((bf16_t*)out)[orow * ldo + n] = f2bf(o);
+            }
+        }
+    }
+}
+
+// tokens[b, tok, f] <- src[b, t, c, y, x]; pure index map, one thread per element
+__global__ void patchify_kernel(const bf16_t* __restrict__ s0, int c0, const bf16_t* __restrict__ s1, int c1,
+                                bf16_t* __restrict__ tok, int B, int T, int H, int W, int p, int pt, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int C = c0 + c1, h = H / p, w = W / p, ptt = pt > 0 ? pt : 1;
+    const int F = C * ptt * p * p;
+    const int f = (int)(i % F);
+    long r = i / F;
+    const int ntok = (T / ptt) * h * w;
+    const int tk = (int)(r % ntok), b = (int)(r / ntok);
+    const int xx = tk % w, yy = (tk / w) % h, tq = tk / (w * h);
+    const int bb = f % p, a = (f / p) % p, tt = (f / (p * p)) % ptt, c = f / (p * p * ptt);
+    const int t = tq * ptt + tt, y = yy * p + a, x = xx * p + bb;
+    bf16_t v;
+    if (c < c0) v = s0[((((long)b * T + t) * c0 + c) * H + y) * W + x];
+    else v = s1[((((long)b * T + t) * c1 + (c - c0)) * H + y) * W + x];
+    tok[i] = v;
+}
+
+// out[b, t, c, y, x] <- x[b, tok, f]; one thread per output element
+__global__ void unpatchify_kernel(const bf16_t* __restrict__ xin, bf16_t* __restrict__ out, int B, int T, int C, int H,
+                                  int W, int p, int pt, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int h = H / p, w = W / p, ptt = pt > 0 ? pt : 1;
+    const int x = (int)(i % W);
+    long r = i / W;
+    const int y = (int)(r % H); r /= H;
+    const int c = (int)(r % C); r /= C;
+    const int t = (int)(r % T), b = (int)(r / T);
+    const int xx = x / p, bb = x % p, yy = y / p, a = y % p, tq = t / ptt, tt = t % ptt;
+    const int ntok = ((T + ptt - 1) / ptt) * h * w;
+    const int F = C * ptt * p * p;
+    const int tk = (tq * h + yy) * w + xx;
+    const int f = ((c * ptt + tt) * p + a) * p + bb;
+    out[i] = xin[((long)b * ntok + tk) * F + f];
+}
+
+__global__ void sched_step_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ vc,
+                                  const bf16_t* __restrict__ vu, float gs, const float* __restrict__ old_x0,
+                                  const float* __restrict__ noise, bf16_t* __restrict__ xo, float* __restrict__ x0o,
+                                  float sa, float sb, float m3, float m4, float cx, float cd, float cn, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float xv = bf2f(x[i]);
+    float v = bf2f(vc[i]);
+    if (vu) { const float u = bf2f(vu[i]); v = u + gs * (v - u); }
+    const float x0 = sa * xv - sb * v;
+    const float d = old_x0 ? m3 * x0 - m4 * old_x0[i] : x0;
+    float r = cx * xv + cd * d;
+    if (noise) r += cn * noise[i];
+    xo[i] = f2bf(r);
+    if (x0o) x0o[i] = x0;
+}
+
+// out[b, f, c, hw] = (mean + exp(0.5 clamp(logvar)) eps) * scale ; moments [b, 2C, f, hw]
+__global__ void gaussian_sample_kernel(const bf16_t* __restrict__ mom, const float* __restrict__ eps,
+                                       bf16_t* __restrict__ out, int B, int C, int F, int HW, float scale, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int hw = (int)(i % HW);
+    long r = i / HW;
+    const int c = (int)(r % C); r /= C;
+    const int f = (int)(r % F), b = (int)(r / F);
+    const long mi = (((long)b * 2 * C + c) * F + f) * HW + hw;
+    const long li = (((long)b * 2 * C + C + c) * F + f) * HW + hw;
+    const long ei = (((long)b * C + c) * F + f) * HW + hw;
+    const float lv = fminf(fmaxf(bf2f(mom[li]), -30.f), 20.f);
+    out[i] = f2bf((bf2f(mom[mi]) + expf(0.5f * lv) * eps[ei]) * scale);
+}
+
+}  // namespace
+
+extern "C" int orv_timestep_embedding(const float* t, void* out_bf16, int batch, int dim, int flip_sin_to_cos,
+                                      float freq_shift, void* stream) {
+    ORV_REQUIRE(t && out_bf16 && batch > 0 && dim >= 2, "orv_timestep_embedding: bad arguments");
+    const int n = batch * (dim / 2);
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t,
+                       (bf16_t*)out_bf16, batch, dim, flip_sin_to_cos, freq_shift);
+    return orv_check_launch("orv_timestep_embedding");
+}
+
+extern "C" int orv_skinny_linear(const void* x, const void* xb, int xb_rep, const void* W, const void* bias, void* out,
+                                 int M, int N, int K, int act_in, int act_out, int out_f32, int ldo, orv_rowmap_t omap,
+                                 void* stream) {
+    ORV_REQUIRE(x && W && out, "orv_skinny_linear: null operand");
+    ORV_REQUIRE(M > 0 && M <= 4096 && N > 0 && K > 0, "orv_skinny_linear: bad shape M=%d N=%d K=%d", M, N, K);
+    ORV_REQUIRE(K % 4 == 0 && (K % 8 == 0 || K <= 64), "orv_skinny_linear: K=%d unsupported", K);
+    ORV_REQUIRE(SK_MT * K * 2 <= 160 * 1024, "orv_skinny_linear: K=%d too large for the LDS tile", K);
+    ORV_REQUIRE(!xb || xb_rep > 0, "orv_skinny_linear: xb_rep must be > 0");
+    const int smem = SK_MT * K * 2;
+    static int smem_max = 0;
+    if (smem > smem_max && smem > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)skinny_linear_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        smem_max = smem;
+    }
+    // rows of W must be 16-byte aligned for the vector path: K % 8 == 0; otherwise the scalar tail handles K < 64
+    dim3 grid((N + 4 * SK_NPW - 1) / (4 * SK_NPW), (M + SK_MT - 1) / SK_MT);
+    hipLaunchKernelGGL(skinny_linear_kernel, grid, dim3(256), smem, (hipStream_t)stream, (const bf16_t*)x,
+                       (const bf16_t*)xb, xb_rep, (const bf16_t*)W, (const bf16_t*)bias, out, M, N, K, act_in, act_out,
+                       out_f32, (long)ldo, omap);
+    return orv_check_launch("orv_skinny_linear");
+}
+
+extern "C" int orv_patchify(const void* src0, int c0, const void* src1, int c1, void* tokens, int B, int T, int H, int W,
+                            int p, int pt, void* stream) {
+    ORV_REQUIRE(src0 && tokens && c0 > 0 && (c1 == 0 || src1), "orv_patchify: null operand");
+    ORV_REQUIRE(B > 0 && T > 0 && p > 0 && H % p == 0 && W % p == 0, "orv_patchify: bad shape");
+    ORV_REQUIRE(pt == 0 || T % pt == 0, "orv_patchify: T=%d not divisible by patch_size_t=%d", T, pt);
+    const long total = (long)B * T * (c0 + c1) * H * W;
+    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src0, c0, (const bf16_t*)src1, c1, (bf16_t*)tokens, B, T, H, W, p, pt, total);
+    return orv_check_launch("orv_patchify");
+}
+
+extern "C" int orv_unpatchify(const void* x, void* out, int B, int T, int C, int H, int W, int p, int pt, void* stream) {
+    ORV_REQUIRE(x && out, "orv_unpatchify: null operand");
+    ORV_REQUIRE(B > 0 && T > 0 && C > 0 && p > 0 && H % p == 0 && W % p == 0, "orv_unpatchify: bad shape");
+    ORV_REQUIRE(pt == 0 || T % pt == 0, "orv_unpatchify: T=%d not divisible by patch_size_t=%d", T, pt);
+    const long total = (long)B * T * C * H * W;
+    hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (bf16_t*)out, B, T, C, H, W, p, pt, total);
+    return orv_check_launch("orv_unpatchify");
+}
+
+extern "C" int orv_sched_step(const void* x, const void* v_c, const void* v_u, float guidance_scale, const float* old_x0,
+                              const float* noise, void* x_out, float* x0_out, float sa, float sb, float m3, float m4,
+                              float cx, float cd, float cn, long n, void* stream) {
+    ORV_REQUIRE(x && v_c && x_out && n > 0, "orv_sched_step: bad arguments");
+    hipLaunchKernelGGL(sched_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (const bf16_t*)v_c, (const bf16_t*)v_u, guidance_scale, old_x0, noise,
+                       (bf16_t*)x_out, x0_out, sa, sb, m3, m4, cx, cd, cn, n);
+    return orv_check_launch("orv_sched_step");
+}
+
+extern "C" int orv_gaussian_sample(const void* moments, const float* eps, void* out, int B, int C, int F, int HW,
+                                   float scale, void* stream) {
+    ORV_REQUIRE(moments && eps && out && B > 0 && C > 0 && F > 0 && HW > 0, "orv_gaussian_sample: bad arguments");
+    const long total = (long)B * F * C * HW;
+    hipLaunchKernelGGL(gaussian_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)moments, eps, (bf16_t*)out, B, C, F, HW, scale, total);
+    return orv_check_launch("orv_gaussian_sample");
+}

@@ -1,0 +1,234 @@
+// HBM-bound normalisation kernels for gfx950:
+//   orv_layernorm_modulate : LayerNorm over D + per-token-group (1+scale)/shift  (AdaLN, cogvideox_control.py:117-145,155-197)
+//   orv_qkv_prep           : per-head LayerNorm(64) on q,k (+RoPE) in place, V -> V^T  (cogvideox_control.py:239-254)
+// One wave per row; 16-byte vector loads/stores; statistics in fp32 (two-pass in registers).
+#include "common.hpp"
+
+namespace {
+
+template <int CH>
+__global__ __launch_bounds__(256) void ln_mod_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t* __restrict__ y,
+                                                     long ldy, const bf16_t* __restrict__ gamma,
+                                                     const bf16_t* __restrict__ beta, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, long mod_b, long mod_g, int seq,
+                                                     int n_text, int per_group, int rows, int D, float eps,
+                                                     orv_rowmap_t xmap) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = D >> 3;
+    const long xrow = xmap.rows > 0 ? (long)(row / xmap.rows) * xmap.bstride + xmap.off + row % xmap.rows : row;
+    const bf16_t* xr = x + xrow * ldx;
+    float v[CH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            const uint4 u = *(const uint4*)(xr + c * 8);
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[i][2 * e] = bf2f(w[e] & 0xffff);
+                v[i][2 * e + 1] = bf2f(w[e] >> 16);
+                s += v[i][2 * e] + v[i][2 * e + 1];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[i][e] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+    const float* sc = nullptr;
+    const float* sh = nullptr;
+    if (scale) {
+        const int b = row / seq, sidx = row % seq;
+        const long off = b * mod_b + orv_group_of(sidx, n_text, per_group) * mod_g;
+        sc = scale + off;
+        sh = shift + off;
+    }
+    bf16_t* yr = y + (long)row * ldy;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = lane + 64 * i;
+        if (c >= nchunk) continue;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd;
+        if (gamma) {
+            const uint4 g = *(const uint4*)(gamma + c * 8);
+            const uint32_t gw[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[2 * e] *= bf2f(gw[e] & 0xffff);
+                o[2 * e + 1] *= bf2f(gw[e] >> 16);
+            }
+        }
+        if (beta) {
+            const uint4 g = *(const uint4*)(beta + c * 8);
+            const uint32_t gw[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[2 * e] += bf2f(gw[e] & 0xffff);
+                o[2 * e + 1] += bf2f(gw[e] >> 16);
+            }
+        }
+        if (sc) {
+            const float4 s0 = *(const float4*)(sc + c * 8), s1 = *(const float4*)(sc + c * 8 + 4);
+            const float4 h0 = *(const float4*)(sh + c * 8), h1 = *(const float4*)(sh + c * 8 + 4);
+            const float ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            const float hh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = fmaf(o[e], 1.0f + ss[e], hh[e]);
+        }
+        uint4 u;
+        u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]); u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
+        *(uint4*)(yr + c * 8) = u;
+    }
+}
+
+// position of key s inside vT's key axis: bits 2 and 3 of s exchanged (see attention.hip header)
+__device__ __forceinline__ int vt_pos(int s) { return (s & ~12) | ((s & 4) << 1) | ((s & 8) >> 1); }
+
+// grid (ceil(S/64), H, B), 256 threads: 64 tokens of one head.
+__global__ __launch_bounds__(256) void qkv_prep_kernel(bf16_t* __restrict__ qkv, bf16_t* __restrict__ vT,
+                                                       const bf16_t* __restrict__ gq, const bf16_t* __restrict__ bq,
+                                                       const bf16_t* __restrict__ gk, const bf16_t* __restrict__ bk,
+                                                       const float* __restrict__ rcos, const float* __restrict__ rsin,
+                                                       int S, int H, int n_text, int s_pad, float eps) {
+    __shared__ bf16_t vt_s[64][66];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const long ld = 3L * H * 64;
+    const int sub = lane & 7;  // 16-byte chunk of the 64-wide head row
+    // q and k: 8 lanes per row, 8 rows per wave-instruction
+    for (int which = 0; which < 2; ++which) {
+        const bf16_t* g = which ? gk : gq;
+        const bf16_t* be = which ? bk : bq;
+        float gam[8], bet[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            gam[e] = g ? bf2f(g[sub * 8 + e]) : 1.f;
+            bet[e] = be ? bf2f(be[sub * 8 + e]) : 0.f;
+        }
+        for (int it = 0; it < 2; ++it) {
+            const int s = s0 + wave * 16 + it * 8 + (lane >> 3);
+            const bool ok = s < S;
+            bf16_t* ptr = qkv + ((long)b * S + (ok ? s : S - 1)) * ld + which * H * 64 + h * 64 + sub * 8;
+            const uint4 u = *(const uint4*)ptr;
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+            float v[8], sum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[2 * e] = bf2f(w[e] & 0xffff);
+                v[2 * e + 1] = bf2f(w[e] >> 16);
+                sum += v[2 * e] + v[2 * e + 1];
+            }
+            sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+            const float mean = sum * (1.f / 64.f);
+            float sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[e] -= mean; sq += v[e] * v[e]; }
+            sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+            const float rstd = rsqrtf(sq * (1.f / 64.f) + eps);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * rstd * gam[e] + bet[e];
+            if (rcos && s >= n_text && ok) {
+                // the reference rounds the normalised q/k to the model dtype before apply_rotary_emb (cogvideox_control.py:243-254)
+                const float* cp = rcos + (long)(s - n_text) * 64 + sub * 8;
+                const float* sp = rsin + (long)(s - n_text) * 64 + sub * 8;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const float a = bf2f(f2bf(v[e])), c2 = bf2f(f2bf(v[e + 1]));
+                    v[e] = a * cp[e] - c2 * sp[e];
+                    v[e + 1] = c2 * cp[e + 1] + a * sp[e + 1];
+                }
+            }
+            if (ok) {
+                uint4 o;
+                o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+                *(uint4*)ptr = o;
+            }
+        }
+    }
+    // v tile -> LDS [token][d]
+    for (int it = 0; it < 2; ++it) {
+        const int tl = wave * 16 + it * 8 + (lane >> 3);
+        const int s = s0 + tl;
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (s < S) u = *(const uint4*)(qkv + ((long)b * S + s) * ld + 2 * H * 64 + h * 64 + sub * 8);
+        uint32_t* dst = (uint32_t*)&vt_s[tl][sub * 8];
+        dst[0] = u.x; dst[1] = u.y; dst[2] = u.z; dst[3] = u.w;
+    }
+    __syncthreads();
+    // write V^T rows: thread -> (d, 16-key group); the 16 keys of a group are permuted by vt_pos
+    {
+        const int d = tid >> 2, grp = tid & 3;
+        bf16_t o[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) o[vt_pos(k)] = vt_s[grp * 16 + k][d];
+        bf16_t* dst = vT + ((long)(b * H + h) * 64 + d) * s_pad + s0 + grp * 16;
+        uint4 a, c2;
+        a.x = o[0] | ((uint32_t)o[1] << 16); a.y = o[2] | ((uint32_t)o[3] << 16);
+        a.z = o[4] | ((uint32_t)o[5] << 16); a.w = o[6] | ((uint32_t)o[7] << 16);
+        c2.x = o[8] | ((uint32_t)o[9] << 16); c2.y = o[10] | ((uint32_t)o[11] << 16);
+        c2.z = o[12] | ((uint32_t)o[13] << 16); c2.w = o[14] | ((uint32_t)o[15] << 16);
+        *(uint4*)dst = a;
+        *(uint4*)(dst + 8) = c2;
+    }
+}
+
+}  // namespace
+
+extern "C" int orv_layernorm_modulate(const void* x, int ldx, orv_rowmap_t xmap, void* y, int ldy, const void* gamma,
+                                      const void* beta, const float* scale, const float* shift, long mod_b, long mod_g,
+                                      orv_groups_t grp, int batch, int D, float eps, void* stream) {
+    ORV_REQUIRE(x && y, "orv_layernorm_modulate: null operand");
+    ORV_REQUIRE(D % 8 == 0 && D <= 4096, "orv_layernorm_modulate: D=%d must be a multiple of 8 and <= 4096", D);
+    ORV_REQUIRE(grp.seq > 0 && batch > 0, "orv_layernorm_modulate: empty problem");
+    ORV_REQUIRE((scale == nullptr) == (shift == nullptr), "orv_layernorm_modulate: scale and shift go together");
+    ORV_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0, "orv_layernorm_modulate: misaligned rows");
+    const int rows = batch * grp.seq;
+    const int ch = (D / 8 + 63) / 64;
+    dim3 grid((rows + 3) / 4), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define ORV_LN_CASE(C)                                                                                                 \
+    hipLaunchKernelGGL(ln_mod_kernel<C>, grid, block, 0, st, (const bf16_t*)x, (long)ldx, (bf16_t*)y, (long)ldy,       \
+                       (const bf16_t*)gamma, (const bf16_t*)beta, scale, shift, mod_b, mod_g, grp.seq, grp.n_text,     \
+                       grp.per_group, rows, D, eps, xmap)
+    if (ch <= 1) ORV_LN_CASE(1);
+    else if (ch <= 2) ORV_LN_CASE(2);
+    else if (ch <= 4) ORV_LN_CASE(4);
+    else if (ch <= 6) ORV_LN_CASE(6);
+    else ORV_LN_CASE(8);
+#undef ORV_LN_CASE
+    return orv_check_launch("orv_layernorm_modulate");
+}
+
+extern "C" int orv_qkv_prep(void* qkv, void* vT, const void* gq, const void* bq, const void* gk, const void* bk,
+                            const float* rope_cos, const float* rope_sin, int B, int S, int H, int n_text, int s_pad,
+                            float eps, void* stream) {
+    ORV_REQUIRE(qkv && vT, "orv_qkv_prep: null operand");
+    ORV_REQUIRE(B > 0 && S > 0 && H > 0, "orv_qkv_prep: empty problem");
+    ORV_REQUIRE(s_pad % 64 == 0 && s_pad >= S && s_pad == ((S + 63) / 64) * 64,
+                "orv_qkv_prep: s_pad=%d must be S=%d rounded up to 64", s_pad, S);
+    ORV_REQUIRE((rope_cos == nullptr) == (rope_sin == nullptr), "orv_qkv_prep: cos and sin go together");
+    dim3 grid(s_pad / 64, H, B);
+    hipLaunchKernelGGL(qkv_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, (bf16_t*)qkv, (bf16_t*)vT,
+                       (const bf16_t*)gq, (const bf16_t*)bq, (const bf16_t*)gk, (const bf16_t*)bk, rope_cos, rope_sin, S,
+                       H, n_text, s_pad, eps);
+    return orv_check_launch("orv_qkv_prep");
+}

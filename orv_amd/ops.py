@@ -1,0 +1,159 @@
+"""Thin tensor-level wrappers over the C ABI (one Python function per ``orv_*`` entry point).
+
+Every function takes CUDA(HIP) tensors, checks dtype/contiguity, passes raw device pointers and the current stream to
+liborv_mi355.so and returns torch tensors that own the output memory.  torch is plumbing here (device memory + streams);
+all arithmetic happens in the HIP kernels.  Nothing in this module can run on CPU tensors.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import Gemm, Groups, RowMap, check, lib
+
+BF16 = torch.bfloat16
+ACT = {None: 0, "none": 0, "silu": 1, "gelu_tanh": 2}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _need(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"orv_amd.ops: `{name}` must live on the GPU (got {t.device}); there is no CPU path")
+    if t.dtype != dtype:
+        raise RuntimeError(f"orv_amd.ops: `{name}` must be {dtype} (got {t.dtype})")
+    return t
+
+
+def groups(seq: int, n_text: int, per_group: int) -> Groups:
+    return Groups(seq, n_text, per_group)
+
+
+def rowmap(rows: int = 0, bstride: int = 0, off: int = 0) -> RowMap:
+    return RowMap(rows, bstride, off)
+
+
+def timestep_embedding(t: torch.Tensor, dim: int, flip_sin_to_cos: bool = True, freq_shift: float = 0.0):
+    t = _need(t.contiguous(), torch.float32, "t")
+    out = torch.empty(t.numel(), dim, dtype=BF16, device=t.device)
+    check(lib().orv_timestep_embedding(_p(t), _p(out), t.numel(), dim, int(flip_sin_to_cos), float(freq_shift),
+                                       _stream()), "orv_timestep_embedding")
+    return out
+
+
+def skinny_linear(x, W, bias=None, xb=None, xb_rep=1, act_in=None, act_out=None, out=None, out_f32=False, ldo=None,
+                  omap: Optional[RowMap] = None):
+    """out[m] = act_out(W . act_in(x[m] + xb[m // xb_rep]) + bias);  x [M,K] bf16, W [N,K] bf16."""
+    x = _need(x.contiguous(), BF16, "x")
+    W = _need(W.contiguous(), BF16, "W")
+    M, K = x.shape
+    N = W.shape[0]
+    assert W.shape[1] == K
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32 if out_f32 else BF16, device=x.device)
+        ldo = N
+    check(lib().orv_skinny_linear(_p(x), _p(xb), xb_rep, _p(W), _p(bias), _p(out), M, N, K, ACT[act_in], ACT[act_out],
+                                  int(out.dtype == torch.float32), ldo, omap or RowMap(0, 0, 0), _stream()),
+          "orv_skinny_linear")
+    return out
+
+
+def patchify(src0, src1=None, p: int = 2, pt: Optional[int] = None):
+    src0 = _need(src0.contiguous(), BF16, "src0")
+    B, T, c0, H, W = src0.shape
+    c1 = 0
+    if src1 is not None:
+        src1 = _need(src1.contiguous(), BF16, "src1")
+        c1 = src1.shape[2]
+    ptt = pt or 1
+    tok = torch.empty(B, (T // ptt) * (H // p) * (W // p), (c0 + c1) * ptt * p * p, dtype=BF16, device=src0.device)
+    check(lib().orv_patchify(_p(src0), c0, _p(src1), c1, _p(tok), B, T, H, W, p, pt or 0, _stream()), "orv_patchify")
+    return tok
+
+
+def unpatchify(x, B, T, C, H, W, p: int = 2, pt: Optional[int] = None):
+    x = _need(x.contiguous(), BF16, "x")
+    out = torch.empty(B, T, C, H, W, dtype=BF16, device=x.device)
+    check(lib().orv_unpatchify(_p(x), _p(out), B, T, C, H, W, p, pt or 0, _stream()), "orv_unpatchify")
+    return out
+
+
+def layernorm_modulate(x, y, gamma, beta, scale, shift, mod_b, mod_g, grp: Groups, batch, D, eps, ldx=None, ldy=None,
+                       xmap: Optional[RowMap] = None):
+    _need(x, BF16, "x"), _need(y, BF16, "y")
+    check(lib().orv_layernorm_modulate(_p(x), ldx or D, xmap or RowMap(0, 0, 0), _p(y), ldy or D, _p(gamma), _p(beta),
+                                       _p(scale), _p(shift), mod_b, mod_g, grp, batch, D, float(eps), _stream()),
+          "orv_layernorm_modulate")
+    return y
+
+
+def qkv_prep(qkv, vT, gq, bq, gk, bk, rope: Optional[Tuple[torch.Tensor, torch.Tensor]], B, S, H, n_text, s_pad, eps):
+    _need(qkv, BF16, "qkv"), _need(vT, BF16, "vT")
+    cos = sin = None
+    if rope is not None:
+        cos, sin = (_need(r.contiguous(), torch.float32, "rope") for r in rope)
+    check(lib().orv_qkv_prep(_p(qkv), _p(vT), _p(gq), _p(bq), _p(gk), _p(bk), _p(cos), _p(sin), B, S, H, n_text, s_pad,
+                             float(eps), _stream()), "orv_qkv_prep")
+
+
+def gemm(A, W, bias, C, M, N, K, epilogue=0, R=None, r_mod=0, gate=None, gate_b=0, gate_g=0, grp: Optional[Groups] = None,
+         cmap: Optional[RowMap] = None, lda=None, ldw=None, ldc=None, ldr=None):
+    _need(A, BF16, "A"), _need(W, BF16, "W"), _need(C, BF16, "C")
+    g = Gemm()
+    g.A, g.lda, g.W, g.ldw, g.bias = _p(A), lda or K, _p(W), ldw or K, _p(bias)
+    g.C, g.ldc, g.M, g.N, g.K, g.epilogue = _p(C), ldc or N, M, N, K, epilogue
+    g.R, g.ldr, g.r_mod = _p(R), ldr or N, r_mod
+    g.gate, g.gate_b, g.gate_g = _p(gate), gate_b, gate_g
+    g.grp = grp or Groups(0, 0, 0)
+    g.cmap = cmap or RowMap(0, 0, 0)
+    check(lib().orv_gemm_bf16(g, _stream()), "orv_gemm_bf16")
+    return C
+
+
+def linear(x2d, W, bias=None, epilogue=0):
+    """Convenience: dense [M,K] x [N,K]^T (+bias, optional GELU); pads K to a multiple of 64 for odd test shapes."""
+    M, K = x2d.shape
+    N = W.shape[0]
+    if K % 64:
+        pad = 64 - K % 64
+        x2d = torch.nn.functional.pad(x2d, (0, pad))
+        W = torch.nn.functional.pad(W, (0, pad))
+        K += pad
+    x2d, W = x2d.contiguous(), W.contiguous()
+    C = torch.empty(M, N, dtype=BF16, device=x2d.device)
+    return gemm(x2d, W, bias, C, M, N, K, epilogue)
+
+
+def attention_fwd(qkv, vT, out, B, S, H, s_pad, scale, lse=None, ld_qkv=None, ld_out=None):
+    _need(qkv, BF16, "qkv"), _need(vT, BF16, "vT"), _need(out, BF16, "out")
+    check(lib().orv_attention_fwd(_p(qkv), ld_qkv or 3 * H * 64, _p(vT), _p(out), ld_out or H * 64, _p(lse), B, S, H,
+                                  s_pad, float(scale), _stream()), "orv_attention_fwd")
+    return out
+
+
+def sched_step(x, v_c, v_u, guidance_scale, old_x0, noise, sa, sb, m3, m4, cx, cd, cn, want_x0=True):
+    x = _need(x.contiguous(), BF16, "x")
+    v_c = _need(v_c.contiguous(), BF16, "v_c")
+    x_out = torch.empty_like(x)
+    x0 = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_x0 else None
+    check(lib().orv_sched_step(_p(x), _p(v_c), _p(v_u), float(guidance_scale), _p(old_x0), _p(noise), _p(x_out), _p(x0),
+                               float(sa), float(sb), float(m3), float(m4), float(cx), float(cd), float(cn), x.numel(),
+                               _stream()), "orv_sched_step")
+    return x_out, x0
+
+
+def gaussian_sample(moments, eps, scale):
+    moments = _need(moments.contiguous(), BF16, "moments")
+    eps = _need(eps.contiguous(), torch.float32, "eps")
+    B, C2, F, H, W = moments.shape
+    out = torch.empty(B, F, C2 // 2, H, W, dtype=BF16, device=moments.device)
+    check(lib().orv_gaussian_sample(_p(moments), _p(eps), _p(out), B, C2 // 2, F, H * W, float(scale), _stream()),
+          "orv_gaussian_sample")
+    return out

@@ -1,0 +1,265 @@
+"""GPU parity of each HIP kernel (through the C ABI via orv_amd.ops) against the CPU oracle / a plain fp32 restatement.
+
+Tolerances: bit-exact for index work (patchify/unpatchify); bf16 kernels vs fp32 reference:
+|err| <= 1.6e-2*|ref| + 1e-2*max|ref|.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dit, leaf  # noqa: E402  (checker only)
+
+BF = torch.bfloat16
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def q(x):
+    return x.to(BF).float()
+
+
+def close(got, ref, rtol=1.6e-2, afrac=1e-2):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    atol = afrac * ref.abs().max().item() + 1e-6
+    bad = (got - ref).abs() > (rtol * ref.abs() + atol)
+    assert not bad.any(), f"max err {(got - ref).abs().max().item():.4g} vs atol {atol:.4g} ({int(bad.sum())} bad)"
+
+
+def test_library_targets_gfx950():
+    from orv_amd._lib import lib, check
+    check(lib().orv_device_check(0), "orv_device_check")
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(64, 128, 128, 0), (300, 192, 256, 1), (777, 384, 512, 2), (3226, 1920, 1920, 2),
+                                       (700, 64, 1920, 0), (1000, 640, 7680, 1)])
+def test_gemm_epilogues(M, N, K, epi):
+    from orv_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W = q(torch.randn(M, K, generator=g)), q(torch.randn(N, K, generator=g) * 0.05)
+    bias, R = q(torch.randn(N, generator=g)), q(torch.randn(M, N, generator=g))
+    seq, nt, P = (M + 1) // 2, 17, 50
+    B = math.ceil(M / seq)
+    G = 1 + math.ceil((seq - nt) / P)
+    gate = torch.randn(B, G, N, generator=g)
+    ref = A @ W.t() + bias
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref, approximate="tanh")
+    if epi == 2:
+        rows = torch.arange(M)
+        s = rows % seq
+        grp = torch.where(s < nt, torch.zeros_like(s), 1 + (s - nt) // P)
+        ref = R + gate[rows // seq, grp] * ref
+    C = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+    ops.gemm(A.to(dev, BF), W.to(dev, BF), bias.to(dev, BF), C, M, N, K, epilogue=epi, R=R.to(dev, BF), ldr=N,
+             gate=gate.to(dev), gate_b=G * N, gate_g=N, grp=ops.groups(seq, nt, P))
+    close(C, ref)
+
+
+def test_gemm_row_remap_and_table_residual():
+    """patch-embed form: rows scattered into a joint [B,S,D] buffer + [n,D] table added (r_mod)."""
+    from orv_amd import ops
+    dev = _dev()
+    B, Nv, Nt, D, K = 3, 100, 9, 128, 128
+    S = Nt + Nv
+    g = torch.Generator().manual_seed(3)
+    A, W, bias = q(torch.randn(B * Nv, K, generator=g)), q(torch.randn(D, K, generator=g) * 0.1), q(torch.randn(D, generator=g))
+    pos = q(torch.randn(Nv, D, generator=g))
+    x = torch.zeros(B * S, D, dtype=BF, device=dev)
+    ops.gemm(A.to(dev, BF), W.to(dev, BF), bias.to(dev, BF), x, B * Nv, D, K, epilogue=2, R=pos.to(dev, BF), r_mod=Nv, ldr=D,
+             cmap=ops.rowmap(Nv, S, Nt))
+    ref = (A @ W.t() + bias).view(B, Nv, D) + pos
+    got = x.view(B, S, D)
+    close(got[:, Nt:], ref)
+    assert torch.all(got[:, :Nt] == 0)          # text rows untouched
+
+
+@pytest.mark.parametrize("D", [128, 1920, 3072])
+def test_layernorm_modulate(D):
+    from orv_amd import ops
+    dev = _dev()
+    B, S, nt, P = 2, 75, 7, 17
+    G = 1 + (S - nt) // P
+    g = torch.Generator().manual_seed(D)
+    x = q(torch.randn(B * S, D, generator=g) * 2 + 0.5)
+    gamma, beta = q(torch.randn(D, generator=g)), q(torch.randn(D, generator=g))
+    mod = torch.randn(B, G, 2 * D, generator=g)
+    rows = torch.arange(B * S)
+    s = rows % S
+    grp = torch.where(s < nt, torch.zeros_like(s), 1 + (s - nt) // P)
+    ln = torch.nn.functional.layer_norm(x, (D,), gamma, beta, 1e-5)
+    ref = ln * (1 + mod[rows // S, grp, D:]) + mod[rows // S, grp, :D]
+    y = torch.empty(B * S, D, dtype=BF, device=dev)
+    md = mod.to(dev)
+    ops.layernorm_modulate(x.to(dev, BF), y, gamma.to(dev, BF), beta.to(dev, BF), md[..., D:], md[..., :D], G * 2 * D,
+                           2 * D, ops.groups(S, nt, P), B, D, 1e-5)
+    close(y, ref)
+    # plain LayerNorm reading only the video rows (row map)
+    nv = S - nt
+    y2 = torch.empty(B * nv, D, dtype=BF, device=dev)
+    ops.layernorm_modulate(x.to(dev, BF), y2, gamma.to(dev, BF), beta.to(dev, BF), None, None, 0, 0, ops.groups(nv, 0, 0),
+                           B, D, 1e-5, xmap=ops.rowmap(nv, S, nt))
+    close(y2, ln.view(B, S, D)[:, nt:].reshape(B * nv, D))
+
+
+def _attention_reference(qkv, B, S, H, gq, bq, gk, bk, rope, nt):
+    D = H * 64
+    x = qkv.view(B, S, 3, H, 64).permute(2, 0, 3, 1, 4)      # [3,B,H,S,64]
+    qq = torch.nn.functional.layer_norm(x[0], (64,), gq, bq, 1e-6)
+    kk = torch.nn.functional.layer_norm(x[1], (64,), gk, bk, 1e-6)
+    if rope is not None:
+        qq = torch.cat([qq[:, :, :nt], leaf.apply_rotary_emb(q(qq[:, :, nt:]), rope)], dim=2)
+        kk = torch.cat([kk[:, :, :nt], leaf.apply_rotary_emb(q(kk[:, :, nt:]), rope)], dim=2)
+    qq, kk = q(qq), q(kk)                                     # the kernel stores normalised q/k as bf16
+    p = torch.softmax(qq @ kk.transpose(-1, -2) / 8.0, dim=-1)
+    o = p @ x[2]
+    lse = torch.logsumexp(qq @ kk.transpose(-1, -2) / 8.0, dim=-1)
+    return o.transpose(1, 2).reshape(B * S, D), lse, qq, kk
+
+
+@pytest.mark.parametrize("B,S,H,nt,use_rope", [(2, 200, 2, 8, False), (1, 3226, 3, 226, False), (2, 333, 2, 13, True),
+                                                (1, 64, 1, 0, False), (1, 257, 2, 1, True)])
+def test_qkv_prep_and_attention(B, S, H, nt, use_rope):
+    from orv_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(S)
+    D = H * 64
+    qkv = q(torch.randn(B * S, 3 * D, generator=g) * 1.5)
+    gq, bq, gk, bk = (q(torch.randn(64, generator=g) * 0.5 + (1 if i % 2 == 0 else 0)) for i in range(4))
+    rope = None
+    if use_rope:
+        ang = torch.rand(S - nt, 32, generator=g) * 6.28
+        rope = (ang.cos().repeat_interleave(2, 1).contiguous(), ang.sin().repeat_interleave(2, 1).contiguous())
+    ref, lse_ref, q_ref, k_ref = _attention_reference(qkv, B, S, H, gq, bq, gk, bk, rope, nt)
+    s_pad = (S + 63) // 64 * 64
+    dq = qkv.to(dev, BF).clone()
+    vT = torch.full((B, H, 64, s_pad), float("nan"), dtype=BF, device=dev)
+    ops.qkv_prep(dq, vT, gq.to(dev, BF), bq.to(dev, BF), gk.to(dev, BF), bk.to(dev, BF),
+                 None if rope is None else tuple(r.to(dev) for r in rope), B, S, H, nt, s_pad, 1e-6)
+    got = dq.float().cpu().view(B, S, 3, H, 64)
+    close(got[:, :, 0].transpose(1, 2), q_ref)
+    close(got[:, :, 1].transpose(1, 2), k_ref)
+    assert torch.equal(got[:, :, 2], qkv.view(B, S, 3, H, 64)[:, :, 2])          # v third untouched
+    # vT layout: pos = key with bits 2 and 3 swapped inside each 16-key group; zero padding (bit-exact copy)
+    key = torch.arange(s_pad)
+    pos = (key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1)
+    want = torch.zeros(B, H, 64, s_pad)
+    want[..., pos[:S]] = qkv.view(B, S, 3, H, 64)[:, :, 2].permute(0, 2, 3, 1)
+    assert torch.equal(vT.float().cpu(), want)
+    out = torch.full((B * S, D), float("nan"), dtype=BF, device=dev)
+    lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+    ops.attention_fwd(dq, vT, out, B, S, H, s_pad, 0.125, lse=lse)
+    close(out, ref)
+    close(lse, lse_ref, rtol=2e-2, afrac=5e-3)
+
+
+def test_attention_online_softmax_rescale_branch():
+    """A key far above the rest, late in the sequence, forces a large running-max jump (the rescale path)."""
+    from orv_amd import ops
+    dev = _dev()
+    B, S, H = 1, 320, 1
+    g = torch.Generator().manual_seed(11)
+    qkv = q(torch.randn(B * S, 192, generator=g))
+    qkv[300, 64:128] = qkv[5, 0:64] * 8           # k[300] aligned with q[5]
+    ident = (torch.ones(64), torch.zeros(64))
+    s_pad = 320
+    dq = qkv.to(dev, BF).clone()
+    vT = torch.zeros(B, H, 64, s_pad, dtype=BF, device=dev)
+    # no LayerNorm here: build vT by hand through qkv_prep with unit gamma on pre-normalised rows is not the point;
+    # feed q,k through the same LN as the reference
+    ref, _, _, _ = _attention_reference(qkv, B, S, H, ident[0], ident[1], ident[0], ident[1], None, 0)
+    ops.qkv_prep(dq, vT, ident[0].to(dev, BF), ident[1].to(dev, BF), ident[0].to(dev, BF), ident[1].to(dev, BF), None, B, S,
+                 H, 0, s_pad, 1e-6)
+    out = torch.empty(B * S, 64, dtype=BF, device=dev)
+    ops.attention_fwd(dq, vT, out, B, S, H, s_pad, 0.125)
+    close(out, ref)
+
+
+@pytest.mark.parametrize("pt", [None, 2])
+def test_patchify_unpatchify_bit_exact(pt):
+    from orv_amd import ops
+    dev = _dev()
+    B, T, C, H, W = 2, 4, 32, 8, 12
+    x = q(torch.randn(B, T, C, H, W))
+    tok = ops.patchify(x.to(dev, BF), None, 2, pt)
+    assert torch.equal(tok.float().cpu(), dit.patchify(x, 2, pt))
+    a, b = x[:, :, :16].contiguous(), x[:, :, 16:].contiguous()          # channel-concat read in place
+    tok2 = ops.patchify(a.to(dev, BF), b.to(dev, BF), 2, pt)
+    assert torch.equal(tok2, tok)
+    Fo = 2 * 2 * (pt or 1) * 16
+    y = q(torch.randn(B, tok.shape[1], Fo))
+    out = ops.unpatchify(y.to(dev, BF), B, T, 16, H, W, 2, pt)
+    assert torch.equal(out.float().cpu(), dit.unpatchify(y, B, T, H, W, 2, pt))
+
+
+def test_skinny_linear_and_timestep_embedding():
+    from orv_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    for M, N, K in [(2, 512, 1920), (10, 5760, 512), (20, 2048, 28), (37, 28, 2048)]:
+        x, W, b = q(torch.randn(M, K, generator=g)), q(torch.randn(N, K, generator=g) * 0.05), q(torch.randn(N, generator=g))
+        ref = torch.nn.functional.gelu(x @ W.t() + b, approximate="tanh")
+        got = ops.skinny_linear(x.to(dev, BF), W.to(dev, BF), b.to(dev, BF), act_out="gelu_tanh")
+        close(got, ref)
+    # broadcast add + SiLU on the input, fp32 output with a row map (the AdaLN table form)
+    B, T, E, N = 2, 5, 512, 384
+    a, t = q(torch.randn(B * T, E, generator=g)), q(torch.randn(B, E, generator=g))
+    W, b = q(torch.randn(N, E, generator=g) * 0.05), q(torch.randn(N, generator=g))
+    ref = torch.nn.functional.silu(q(a.view(B, T, E) + t[:, None])) @ W.t() + b
+    table = torch.zeros(B, T + 1, N, dtype=torch.float32, device=dev)
+    ops.skinny_linear(a.to(dev, BF), W.to(dev, BF), b.to(dev, BF), xb=t.to(dev, BF), xb_rep=T, act_in="silu", out=table,
+                      ldo=N, omap=ops.rowmap(T, T + 1, 1))
+    close(table[:, 1:], ref, rtol=1e-2, afrac=5e-3)
+    assert torch.all(table[:, 0] == 0)
+    ts = torch.tensor([999.0, 19.0, 500.0])
+    emb = ops.timestep_embedding(ts.to(dev), 1920, True, 0.0)
+    close(emb, leaf.get_timestep_embedding(ts, 1920, True, 0), rtol=1e-2, afrac=1e-2)
+
+
+def test_sched_step_matches_scheduler_math():
+    from orv_amd import schedulers
+    dev = _dev()
+    kw = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+              clip_sample=False, set_alpha_to_one=True, prediction_type="v_prediction", rescale_betas_zero_snr=True,
+              snr_shift_scale=3.0, timestep_spacing="trailing")
+    g = torch.Generator().manual_seed(9)
+    x, v = q(torch.randn(2, 5, 16, 8, 12, generator=g)), q(torch.randn(2, 5, 16, 8, 12, generator=g))
+    for n in (50, 3):
+        ours, ref = schedulers.CogVideoXDDIMScheduler(**kw), leaf.CogVideoXDDIMScheduler(**kw)
+        ours.set_timesteps(n), ref.set_timesteps(n)
+        for t in ref.timesteps.tolist()[:3] + ref.timesteps.tolist()[-2:]:
+            want = ref.step(v, t, x, return_dict=False)[0]
+            got = ours.step(v.to(dev, BF), t, x.to(dev, BF), return_dict=False)[0]
+            close(got, want, rtol=8e-3, afrac=1e-3)
+        ours, ref = schedulers.CogVideoXDPMScheduler(**kw), leaf.CogVideoXDPMScheduler(**kw)
+        ours.set_timesteps(n), ref.set_timesteps(n)
+        ts = ref.timesteps.tolist()
+        old_o = old_r = None
+        xo, xr = x.to(dev, BF), x.clone()
+        for i, t in enumerate(ts):
+            go, gr = torch.Generator().manual_seed(100 + i), torch.Generator().manual_seed(100 + i)
+            # fp32 restatement of leaf.CogVideoXDPMScheduler.step with the noise drawn like the reference does for a
+            # bf16 pipeline (randn_tensor in the sample dtype; two draws on second-order steps, the second one used)
+            prev = t - 1000 // n
+            a_t, a_p = ref.alphas_cumprod[t], (ref.alphas_cumprod[prev] if prev >= 0 else ref.final_alpha_cumprod)
+            a_b = ref.alphas_cumprod[ts[i - 1]] if i else None
+            m1, m2, mn, m3, m4 = ref.coefficients(a_t, a_p, a_b)
+            x0 = (a_t ** 0.5).float() * xr - ((1 - a_t) ** 0.5).float() * v
+            noise = torch.randn(x.shape, generator=gr, dtype=BF).float()
+            d = x0
+            if not (old_r is None or prev < 0):
+                d = m3.float() * x0 - m4.float() * old_r
+                noise = torch.randn(x.shape, generator=gr, dtype=BF).float()
+            nr = m1.float() * xr - m2.float() * d + mn.float() * noise
+            no, old_o = ours.step(v.to(dev, BF), old_o, t, ts[i - 1] if i else None, xo, generator=go)
+            close(no, nr, rtol=8e-3, afrac=1e-3)
+            close(old_o, x0, rtol=1e-4, afrac=1e-5)
+            xr, old_r, xo = no.float().cpu(), x0, no
+            if i == 3 and n == 50:
+                break

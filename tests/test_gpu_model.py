@@ -1,0 +1,116 @@
+"""GPU parity of the whole HIP path (model forward + denoise loop) against the reference's golden vectors and the oracle.
+
+bf16 kernels vs the fp32 reference: whole forward rel-L2 <= 2e-2, multi-step latents rel-L2 <= 5e-2.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import load_golden  # noqa: E402
+from oracle import dit  # noqa: E402  (checker only)
+
+BF = torch.bfloat16
+FWD = ["fwd_actions", "fwd_actions_masked", "fwd_noactions", "fwd_nomod", "fwd_nomod_noactions", "fwd_rope", "fwd_pt2_ofs",
+       "fwd_train_recon"]
+
+
+def rel_l2(got, ref):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    return ((got - ref).norm() / ref.norm()).item()
+
+
+def build(cfg, weights, dev):
+    from orv_amd.cogvideox_control import CogVideoXTransformer3DModelTraj
+    m = CogVideoXTransformer3DModelTraj(**cfg)
+    m.load_state_dict(weights, strict=True)
+    return m.to(dev, BF).eval()
+
+
+@pytest.mark.parametrize("name", FWD)
+def test_forward_matches_reference_golden(name):
+    dev = torch.device("cuda:0")
+    cfg, extra, ins, w, outs = load_golden(name)
+    m = build(cfg, w, dev)
+    m.train(extra["training"])
+    ctrl = {}
+    if "actions" in ins:
+        ctrl["actions"] = ins["actions"].to(dev)
+        m.action_embed.forced_mask = torch.tensor(extra["mask"])
+    rope = (ins["rope_cos"].to(dev), ins["rope_sin"].to(dev)) if "rope_cos" in ins else None
+    ofs = None if extra["ofs"] is None else torch.full((1,), float(extra["ofs"]), device=dev)
+    out, is_mask, recon = m(ins["hidden_states"].to(dev, BF), ins["encoder_hidden_states"].to(dev, BF), ctrl,
+                            ins["timestep"].to(dev), ofs=ofs, image_rotary_emb=rope, return_dict=False)
+    assert out.shape == outs["sample"].shape and out.dtype == BF
+    assert rel_l2(out, outs["sample"]) <= 2e-2
+    if "is_action_mask" in outs:
+        assert torch.equal(is_mask.cpu(), outs["is_action_mask"])
+    if "actions_recon" in outs:
+        assert rel_l2(recon, outs["actions_recon"]) <= 2e-2
+
+
+@pytest.mark.parametrize("name", ["pipe_ddim", "pipe_dpm", "pipe_ddim_cfg"])
+def test_denoise_loop_matches_reference_golden(name):
+    from orv_amd import schedulers
+    from orv_amd.cogvideox_control import CogVideoXImageToVideoPipelineTraj
+    dev = torch.device("cuda:0")
+    cfg, extra, ins, w, outs = load_golden(name)
+    m = build(cfg, w, dev)
+    m.action_embed.forced_mask = torch.zeros(ins["image"].shape[0], dtype=torch.bool)
+    cls = getattr(schedulers, extra["scheduler"])
+    sched = cls(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                clip_sample=False, set_alpha_to_one=True, prediction_type="v_prediction", rescale_betas_zero_snr=True,
+                snr_shift_scale=3.0, timestep_spacing="trailing")
+    pipe = CogVideoXImageToVideoPipelineTraj(transformer=m, scheduler=sched)
+    gen = torch.Generator().manual_seed(extra["gen_seed"])
+    trace = []
+    # the golden run is fp32: draw the same CPU noise in fp32 and hand it over (a bf16 draw consumes the generator differently)
+    b = ins["image"].shape[0]
+    eps = torch.randn(b, 16, 1, 8, 12, generator=gen)
+    lat0 = torch.randn(b, 3, 16, 8, 12, generator=gen)
+    mean, logvar = ins["image"].chunk(2, dim=1)
+    image_lat = (mean + torch.exp(0.5 * logvar.clamp(-30, 20)) * eps)          # pre-sampled [B,16,1,h,w]
+    if extra["scheduler"] == "CogVideoXDPMScheduler":
+        pytest.skip("DPM noise is drawn per step in the sample dtype; covered by test_sched_step_matches_scheduler_math "
+                    "and the oracle-level golden test")
+    out = pipe(image=image_lat.to(dev, BF), height=64, width=96, num_frames=9, num_inference_steps=extra["steps"],
+               guidance_scale=extra["guidance"], generator=None, latents=lat0.to(dev, BF),
+               prompt_embeds=ins["prompt_embeds"].to(dev, BF), negative_prompt_embeds=ins["negative_prompt_embeds"].to(dev, BF),
+               output_type="latent", controls_or_guidances={"actions": ins["actions"].to(dev)} if extra["with_actions"] else {},
+               callback_on_step_end=lambda p, i, t, kw: (trace.append(kw["latents"].clone()), {})[1])
+    for i, tr in enumerate(trace):
+        assert rel_l2(tr, outs[f"step{i}"]) <= 5e-2, i
+    assert rel_l2(out.frames, outs["latents"]) <= 5e-2
+
+
+def test_full_width_single_layer_vs_oracle():
+    """CogVideoX-2B widths (D=1920, 30 heads, S=3226, 5x40x60 latents), one block, B=1: kernel tiling at real shapes."""
+    dev = torch.device("cuda:0")
+    from orv_amd.cogvideox_control import CogVideoXTransformer3DModelTraj
+    torch.manual_seed(42)
+    cfg = dict(num_layers=1, in_channels=32, sample_height=40, sample_width=60, sample_frames=17,
+               modulate_encoder_hidden_states=True)
+    m = CogVideoXTransformer3DModelTraj(**cfg)
+    for p in m.parameters():
+        if p.ndim >= 2:
+            p.data.normal_(0, 0.02)
+        p.data.copy_(p.data.to(BF).float())
+    x = torch.randn(1, 5, 32, 40, 60).to(BF).float()
+    e = (torch.randn(1, 226, 4096) * 0.2).to(BF).float()
+    a = torch.randn(1, 16, 7).to(BF).float()
+    ts = torch.tensor([500])
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = dit.dit_forward(sd, dict(m.config), x, e, ts, actions=a, is_mask=torch.zeros(1, dtype=torch.bool))[0]
+    m = m.to(dev, BF).eval()
+    m.action_embed.forced_mask = torch.zeros(1, dtype=torch.bool)
+    out = m(x.to(dev, BF), e.to(dev, BF), {"actions": a.to(dev)}, ts.to(dev), return_dict=False)[0]
+    assert rel_l2(out, ref) <= 2e-2
+
+
+def test_no_cpu_fallback():
+    from orv_amd.cogvideox_control import CogVideoXTransformer3DModelTraj
+    cfg, extra, ins, w, outs = load_golden("fwd_noactions")
+    m = CogVideoXTransformer3DModelTraj(**cfg)
+    with pytest.raises(RuntimeError):
+        m(ins["hidden_states"], ins["encoder_hidden_states"], {}, ins["timestep"])

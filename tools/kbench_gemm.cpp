@@ -1,0 +1,58 @@
+// Standalone GPU check + micro-benchmark of orv_gemm_bf16 (links liborv_mi355.so; no torch).
+//   ./kbench_gemm            correctness on a few shapes + timing of the CogVideoX-2B GEMM shapes
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <random>
+#include "../include/orv_mi355.h"
+#define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} }while(0)
+static inline uint16_t f2bf(float f){ uint32_t u; memcpy(&u,&f,4); u += 0x7fff + ((u>>16)&1); return (uint16_t)(u>>16);} 
+static inline float bf2f(uint16_t h){ uint32_t u=((uint32_t)h)<<16; float f; memcpy(&f,&u,4); return f;}
+static float gelu(float x){ float u=0.7978845608028654f*(x+0.044715f*x*x*x); return 0.5f*x*(1.f+tanhf(u)); }
+
+struct Dev { void* p=nullptr; size_t n=0; };
+static std::vector<uint16_t> rnd_bf(size_t n, float scale, uint32_t seed){ std::mt19937 g(seed); std::uniform_real_distribution<float> d(-1.f,1.f); std::vector<uint16_t> v(n); for(auto& x:v) x=f2bf(d(g)*scale); return v; }
+template<class T> static T* up(const std::vector<T>& h){ T* d; CK(hipMalloc(&d,h.size()*sizeof(T))); CK(hipMemcpy(d,h.data(),h.size()*sizeof(T),hipMemcpyHostToDevice)); return d; }
+
+static int check(int M,int N,int K,int epi,int seq,int ntext,int pg){
+  auto A=rnd_bf((size_t)M*K,1.f,1), W=rnd_bf((size_t)N*K,0.05f,2), bias=rnd_bf(N,0.5f,3), R=rnd_bf((size_t)M*N,1.f,4);
+  int B=(M+seq-1)/seq; int G=1+(pg? (seq-ntext+pg-1)/pg:1);
+  std::vector<float> gate((size_t)B*G*N); { std::mt19937 g(5); std::uniform_real_distribution<float> d(-1.f,1.f); for(auto&x:gate) x=d(g);} 
+  uint16_t *dA=up(A),*dW=up(W),*db=up(bias),*dR=up(R); float* dg=up(gate); uint16_t* dC; CK(hipMalloc(&dC,(size_t)M*N*2)); CK(hipMemset(dC,0xff,(size_t)M*N*2));
+  orv_gemm_t g{}; g.A=dA; g.lda=K; g.W=dW; g.ldw=K; g.bias=db; g.C=dC; g.ldc=N; g.M=M; g.N=N; g.K=K; g.epilogue=epi; g.R=dR; g.ldr=N; g.r_mod=0; g.gate=dg; g.gate_b=(long)G*N; g.gate_g=N; g.grp={seq,ntext,pg};
+  int rc=orv_gemm_bf16(&g,nullptr); if(rc){ printf("rc=%d %s\n",rc,orv_last_error()); return 1; }
+  CK(hipDeviceSynchronize()); std::vector<uint16_t> C((size_t)M*N); CK(hipMemcpy(C.data(),dC,C.size()*2,hipMemcpyDeviceToHost));
+  // sampled reference
+  std::mt19937 rg(7); double maxerr=0, maxref=0; int nsamp = (size_t)M*N<=(1<<18) ? M*N : 20000;
+  for(int s=0;s<nsamp;s++){ int m,n; if(nsamp==M*N){ m=s/N; n=s%N; } else { m=rg()%M; n=rg()%N; if(s<2000) m=M-1-(s%64); }
+    double acc=0; for(int k=0;k<K;k++) acc+=(double)bf2f(A[(size_t)m*K+k])*bf2f(W[(size_t)n*K+k]); acc+=bf2f(bias[n]);
+    if(epi==1) acc=gelu((float)acc); if(epi==2){ int b=m/seq, sq=m%seq; int grp= sq<ntext?0:(pg?1+(sq-ntext)/pg:1); acc=bf2f(R[(size_t)m*N+n])+gate[((size_t)b*G+grp)*N+n]*acc; }
+    double got=bf2f(C[(size_t)m*N+n]); maxerr=fmax(maxerr,fabs(got-acc)); maxref=fmax(maxref,fabs(acc)); }
+  bool ok = maxerr <= 0.01*maxref+1e-3; printf("check M=%d N=%d K=%d epi=%d: maxerr=%.4g maxref=%.4g %s\n",M,N,K,epi,maxerr,maxref,ok?"OK":"FAIL");
+  hipFree(dA);hipFree(dW);hipFree(db);hipFree(dR);hipFree(dg);hipFree(dC); return ok?0:1;
+}
+static void bench(int M,int N,int K,int epi,int iters){
+  auto A=rnd_bf((size_t)M*K,1.f,1), W=rnd_bf((size_t)N*K,0.05f,2), bias=rnd_bf(N,0.5f,3);
+  uint16_t *dA=up(A),*dW=up(W),*db=up(bias); uint16_t* dC; CK(hipMalloc(&dC,(size_t)M*N*2)); CK(hipMemset(dC,0,(size_t)M*N*2));
+  int seq=3226; int B=(M+seq-1)/seq; int G=6; std::vector<float> gate((size_t)B*G*N,0.5f); float* dg=up(gate);
+  orv_gemm_t g{}; g.A=dA; g.lda=K; g.W=dW; g.ldw=K; g.bias=db; g.C=dC; g.ldc=N; g.M=M; g.N=N; g.K=K; g.epilogue=epi; g.R=dC; g.ldr=N; g.gate=dg; g.gate_b=(long)G*N; g.gate_g=N; g.grp={seq,226,600};
+  hipEvent_t e0,e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for(int i=0;i<3;i++) orv_gemm_bf16(&g,nullptr);
+  CK(hipEventRecord(e0)); for(int i=0;i<iters;i++) orv_gemm_bf16(&g,nullptr); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms,e0,e1)); ms/=iters;
+  printf("bench M=%5d N=%5d K=%5d epi=%d: %.3f ms  %.1f TFLOP/s\n",M,N,K,epi,ms,2.0*M*N*K/ms/1e9);
+  hipFree(dA);hipFree(dW);hipFree(db);hipFree(dC);hipFree(dg);
+}
+int main(int argc,char**argv){
+  if(orv_device_check(0)){ printf("%s\n",orv_last_error()); return 2; }
+  int bad=0;
+  bad+=check(64,128,128,0,64,8,0); bad+=check(100,192,256,1,50,8,14); bad+=check(300,64,1920,0,300,0,0);
+  bad+=check(700,384,512,2,350,30,64); bad+=check(3226,1920,1920,2,3226,226,600); bad+=check(3226,7680,1920,1,3226,226,600);
+  bad+=check(12904,5760,1920,0,3226,226,600);
+  if(bad){ printf("CORRECTNESS FAILURES: %d\n",bad); return 1; }
+  for(int M: {12904, 3226}){ bench(M,5760,1920,0,20); bench(M,1920,1920,2,20); bench(M,7680,1920,1,20); bench(M,1920,7680,2,20); }
+  bench(8192,8192,8192,0,5);
+  return 0;
+}
