@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""Headline benchmark of the ORV denoising hot path on MI355X (contract: see the task brief / DESIGN.md "Measurement").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+
+A "step" is ONE denoise step of BASELINE.json configs[1] - CogVideoX-2B (ORV "1.7b": D=1920, 30 heads x 64, 30 layers,
+FFN 7680) on 320x480x17-frame clips = latents [B,5,32,40,60] (16 noisy + 16 image-condition channels), 226 text tokens +
+3000 video tokens, per-frame action (trajectory) modulation, guidance 1.0, bf16: channel-concat -> 3-D DiT forward ->
+fused DDIM update, for a batch of B clips (B = 4 = the reference's eval batch, config/eval_traj_image_2b_finetune.yaml:32).
+Inputs are synthetic (seed 42), weights random N(0, 0.02^2) of the real architecture, all resident in HBM
+before the timed region.  N > 1 = N independent replicas (inference has no collective, evaluation_control_to_video.py:212-222);
+value = N*B*K / max-over-ranks(wall).
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: algorithmic FLOPs / live HIP-event duration vs the
+2.5 PFLOP/s dense bf16 MFMA peak) and, at N=1, `cpu_baseline` (the CPU oracle timed on the host cores - a reported
+baseline, not the target).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+CFG_2B = dict(num_attention_heads=30, attention_head_dim=64, in_channels=32, out_channels=16, time_embed_dim=512,
+              text_embed_dim=4096, num_layers=30, sample_width=60, sample_height=40, sample_frames=17, patch_size=2,
+              max_text_seq_length=226, modulate_encoder_hidden_states=True,
+              loaded_pretrained_model_name_or_path="THUDM/CogVideoX-2b")
+SCHED = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+             clip_sample=False, set_alpha_to_one=True, prediction_type="v_prediction", rescale_betas_zero_snr=True,
+             snr_shift_scale=3.0, timestep_spacing="trailing")
+
+
+def flops_per_sample(cfg, S):
+    """Algorithmic forward FLOPs per sample per step of attention + FFN (the north-star numerator)."""
+    D, L = cfg["num_attention_heads"] * cfg["attention_head_dim"], cfg["num_layers"]
+    return L * (24 * S * D * D + 4 * S * S * D)
+
+
+def synthetic_inputs(B, dev, dtype):
+    g = torch.Generator().manual_seed(42)
+    latents = torch.randn(B, 5, 16, 40, 60, generator=g)
+    image_latents = torch.zeros(B, 5, 16, 40, 60)
+    image_latents[:, 0] = torch.randn(B, 16, 40, 60, generator=g) * 1.15258426
+    prompt = torch.randn(B, 226, 4096, generator=g) * 0.2
+    actions = torch.randn(B, 16, 7, generator=g) * torch.tensor([20.0] * 6 + [1.0])
+    actions[..., 6].clamp_(0, 1)
+    return (latents.to(dev, dtype), image_latents.to(dev, dtype), prompt.to(dev, dtype), actions.to(dev))
+
+
+def build_model(cfg, dev):
+    from orv_amd.cogvideox_control import CogVideoXTransformer3DModelTraj
+    torch.manual_seed(42)
+    with torch.device(dev):
+        m = CogVideoXTransformer3DModelTraj(**cfg)
+    g = torch.Generator(device=dev).manual_seed(42)
+    for name, p in m.named_parameters():
+        if p.ndim >= 2:
+            p.data.normal_(0, 0.02, generator=g)          # also makes zero-init layers non-trivial
+        elif name.endswith("bias"):
+            p.data.normal_(0, 0.02, generator=g)
+    m = m.to(torch.bfloat16).eval()
+    m.action_embed.forced_mask = torch.zeros(64, dtype=torch.bool)[:0]   # placeholder, set per batch below
+    return m
+
+
+def cpu_baseline(cfg, layers, threads):
+    """Oracle (kind 'port': the reference's own Python cannot run without diffusers) timed on the host cores: ONE fp32
+    denoise-step forward for ONE clip through `layers` of the 30 blocks, scaled to 30 layers."""
+    from oracle import dit
+    torch.set_num_threads(threads)
+    c = {**cfg, "num_layers": layers}
+    D, E = 1920, 512
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+
+    def lin(name, o, i):
+        sd[name + ".weight"] = torch.randn(o, i, generator=g) * 0.02
+        sd[name + ".bias"] = torch.zeros(o)
+
+    def ln(name, d):
+        sd[name + ".weight"], sd[name + ".bias"] = torch.ones(d), torch.zeros(d)
+
+    sd["patch_embed.proj.weight"] = torch.randn(D, 32, 2, 2, generator=g) * 0.02
+    sd["patch_embed.proj.bias"] = torch.zeros(D)
+    lin("patch_embed.text_proj", D, 4096), lin("time_embedding.linear_1", E, D), lin("time_embedding.linear_2", E, E)
+    for i in range(layers):
+        p = f"transformer_blocks.{i}."
+        lin(p + "norm1.linear", 6 * D, E), ln(p + "norm1.norm", D), lin(p + "norm2.linear", 6 * D, E), ln(p + "norm2.norm", D)
+        for n in ("to_q", "to_k", "to_v", "to_out.0"):
+            lin(p + "attn1." + n, D, D)
+        ln(p + "attn1.norm_q", 64), ln(p + "attn1.norm_k", 64)
+        lin(p + "ff.net.0.proj", 4 * D, D), lin(p + "ff.net.2", D, 4 * D)
+    ln("norm_final", D), lin("norm_out.linear", 2 * D, E), ln("norm_out.norm", D), lin("proj_out", 64, D)
+    lin("action_embed.mlp.0", 4 * E, 28), lin("action_embed.mlp.3", E, 4 * E)
+    sd["action_embed.mask_embed.weight"] = torch.zeros(1, E)
+    x = torch.randn(1, 5, 32, 40, 60, generator=g)
+    e = torch.randn(1, 226, 4096, generator=g) * 0.2
+    a = torch.randn(1, 16, 7, generator=g)
+    t = torch.tensor([500])
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        dit.dit_forward(sd, c, x, e, t, actions=a, is_mask=torch.zeros(1, dtype=torch.bool))
+        dt = time.perf_counter() - t0
+    per_step = dt * 30.0 / layers
+    return {"value": 1.0 / per_step, "unit": "denoise-steps/s", "cores": threads, "kind": "port",
+            "sample": f"1 clip x 1 step, fp32 eager PyTorch oracle, {layers}/30 blocks timed ({dt:.2f} s) and scaled to 30",
+            "s_per_step": per_step}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4, help="clips per GPU per step (reference eval batch = 4, demo = 1)")
+    ap.add_argument("--layers", type=int, default=30, help="debug only; anything but 30 marks the line INVALID")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-layers", type=int, default=6)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))      # RCCL; only used for barrier/max
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from orv_amd import ops, schedulers
+    from orv_amd._lib import check, lib
+    check(lib().orv_device_check(local), "orv_device_check")
+
+    cfg = {**CFG_2B, "num_layers": args.layers}
+    B = args.batch
+    model = build_model(cfg, dev)
+    model.action_embed.forced_mask = torch.zeros(B, dtype=torch.bool)       # is_mask forced False
+    latents, image_latents, prompt, actions = synthetic_inputs(B, dev, torch.bfloat16)
+    sched = schedulers.CogVideoXDDIMScheduler(**SCHED)
+    sched.set_timesteps(50)
+    ts = sched.timesteps.tolist()
+    controls = {"actions": actions}
+
+    def step(i, lat):
+        t = ts[i % len(ts)]
+        model_in = torch.cat([lat, image_latents], dim=2)                   # cogvideox_control.py:1409-1413
+        tvec = torch.full((B,), t, device=dev, dtype=torch.int64)
+        v = model(hidden_states=model_in, encoder_hidden_states=prompt, timestep=tvec,
+                  controls_or_guidances=controls, return_dict=False)[0]
+        return sched.step(v, t, lat, return_dict=False)[0]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    lat = latents
+    for i in range(args.warmup):
+        lat = step(i, lat)
+    barrier()
+    ops.start_timeline()
+    t0 = time.perf_counter()
+    lat = latents
+    for i in range(args.steps):
+        lat = step(i, lat)
+    barrier()
+    wall = time.perf_counter() - t0
+    timeline = ops.stop_timeline()
+    assert torch.isfinite(lat.float()).all(), "non-finite latents"
+    if world > 1:
+        w = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        wall = float(w.item())
+
+    if rank == 0:
+        S = 226 + 3000
+        total_steps = world * B * args.steps
+        value = total_steps / wall
+        fl = flops_per_sample(cfg, S)
+        # per-kernel live timings -> dominant kernel roofline
+        kernels = []
+        for key, ms in timeline.items():
+            if key[0] == "gemm":
+                _, M, N, K, epi = key
+                flop, name = 2.0 * M * N * K, f"gemm_kernel<{256 if M * N >= 224 * 256 * 192 else 128},{192 if N % 192 == 0 else (128 if N % 128 == 0 else 64)},{epi}> M={M} N={N} K={K}"
+            else:
+                _, b, s, h = key
+                flop, name = 4.0 * b * h * s * s * 64, f"attn_fwd_kernel B={b} S={s} H={h}"
+            avg = sum(ms) / len(ms)
+            kernels.append({"kernel": name, "launches": len(ms), "avg_ms": round(avg, 4), "total_ms": round(sum(ms), 2),
+                            "tflops": round(flop / avg / 1e9, 1)})
+        kernels.sort(key=lambda k: -k["total_ms"])
+        dom = kernels[0] if kernels else None
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if dom and os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get(dom["kernel"].split(" ")[0])
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "denoise-steps/sec", "value": round(value, 3), "unit": "steps/s (clips x denoise steps per second)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "frames_per_sec": round(17.0 * world * B * args.steps / 50.0 / wall, 3),
+            "achieved_tflops_attn_ffn": round(value * fl / 1e12, 1),
+            "frac_mfma_peak_attn_ffn": round(value * fl / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),
+            "config": {"workload": "configs[1]: CogVideoX-2B singleview 320x480x17f (latents [B,5,32,40,60], S=3226), "
+                                   "DDIM 50-step schedule, guidance 1.0, trajectory-conditioned",
+                       "batch_per_gpu": B, "num_layers": args.layers, "parallelism": f"replica x{world} (no collective)",
+                       "valid": args.layers == 30},
+            "roofline": None if dom is None else {
+                "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "launches": dom["launches"], "avg_ms": dom["avg_ms"]},
+            "kernels": kernels[:8],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = max(1, (os.cpu_count() or 2) // 2)
+            line["cpu_baseline"] = cpu_baseline(CFG_2B, args.cpu_baseline_layers, threads)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -20,6 +20,39 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional live per-launch timing (bench.py's roofline leg): when a dict is installed here, gemm/attention launches are
+# bracketed by HIP events recorded on the launch stream (torch's current stream), keyed by kernel + shape.
+_TIMELINE = None
+
+
+def start_timeline():
+    global _TIMELINE
+    _TIMELINE = {}
+
+
+def stop_timeline():
+    """-> {key: [ms, ...]} of every bracketed launch since start_timeline()."""
+    global _TIMELINE
+    tl, _TIMELINE = _TIMELINE, None
+    torch.cuda.synchronize()
+    return {k: [a.elapsed_time(b) for a, b in v] for k, v in (tl or {}).items()}
+
+
+class _timed:
+    def __init__(self, key):
+        self.key = key
+
+    def __enter__(self):
+        if _TIMELINE is not None:
+            self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if _TIMELINE is not None:
+            self.b.record()
+            _TIMELINE.setdefault(self.key, []).append((self.a, self.b))
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -113,7 +146,8 @@ def gemm(A, W, bias, C, M, N, K, epilogue=0, R=None, r_mod=0, gate=None, gate_b=
     g.gate, g.gate_b, g.gate_g = _p(gate), gate_b, gate_g
     g.grp = grp or Groups(0, 0, 0)
     g.cmap = cmap or RowMap(0, 0, 0)
-    check(lib().orv_gemm_bf16(g, _stream()), "orv_gemm_bf16")
+    with _timed(("gemm", M, N, K, epilogue)):
+        check(lib().orv_gemm_bf16(g, _stream()), "orv_gemm_bf16")
     return C
 
 
@@ -133,8 +167,9 @@ def linear(x2d, W, bias=None, epilogue=0):
 
 def attention_fwd(qkv, vT, out, B, S, H, s_pad, scale, lse=None, ld_qkv=None, ld_out=None):
     _need(qkv, BF16, "qkv"), _need(vT, BF16, "vT"), _need(out, BF16, "out")
-    check(lib().orv_attention_fwd(_p(qkv), ld_qkv or 3 * H * 64, _p(vT), _p(out), ld_out or H * 64, _p(lse), B, S, H,
-                                  s_pad, float(scale), _stream()), "orv_attention_fwd")
+    with _timed(("attention", B, S, H)):
+        check(lib().orv_attention_fwd(_p(qkv), ld_qkv or 3 * H * 64, _p(vT), _p(out), ld_out or H * 64, _p(lse), B, S,
+                                      H, s_pad, float(scale), _stream()), "orv_attention_fwd")
     return out
 
 
