@@ -89,6 +89,16 @@ int orv_layernorm_modulate(const void* x, int ldx, orv_rowmap_t xmap, void* y, i
                            const void* beta, const float* scale, const float* shift, long mod_b, long mod_g,
                            orv_groups_t grp, int batch, int D, float eps, void* stream);
 
+/* All AdaLN modulation linears of one forward in a single launch (CogVideoXLayerNormZero "partially forward self.linear
+ * twice" cogvideox_control.py:117-130, and AdaLayerNorm :172): for tab in [0, n_tab)
+ *   out[tab][b][1+t][:] = W[tab][0:width]       . SiLU(temb[b] + action_emb[b,t]) + bias[tab][0:width]
+ *   out[tab][b][0][:]   = W[tab][width:2*width] . SiLU(temb[b])                   + bias[tab][width:2*width]   (if text)
+ * temb [B,E] bf16, action_emb [B,T,E] bf16 or NULL (then T must be 1 and the video rows use SiLU(temb)); W/bias are DEVICE
+ * arrays of n_tab device pointers to bf16 [width*(1+text), E] / [width*(1+text)] (bias array or entries may be NULL);
+ * out fp32 [n_tab, B, 1+T, width].  E in {64,128,256,512}, width % 32 == 0.  Streams every weight once (HBM-bound). */
+int orv_modulation_tables(const void* temb, const void* action_emb, const void* const* W, const void* const* bias,
+                          float* out, int n_tab, int B, int T, int E, int width, int text, void* stream);
+
 /* In-place per-head LayerNorm(64, eps) on the q and k thirds of a packed qkv buffer [B*S, 3*H*64] bf16, optional
  * RoPE on rows >= n_text (pairs (2i,2i+1); cos/sin fp32 [S-n_text, 64]), and transpose of the v third into
  * vT [B, H, 64, s_pad] (zero-filled for s >= S).  Replaces cogvideox_control.py:239-254 (+ diffusers

@@ -435,6 +435,18 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
                                   vis2=e(B * Nv, D), s_pad=s_pad)}
         return self._ws[key]
 
+    def _pointer_tables(self, dev):
+        """Device arrays of weight/bias pointers of every AdaLN linear (norm1, norm2 of each block; norm_out), built once."""
+        lins = [n.linear for blk in self.transformer_blocks for n in (blk.norm1, blk.norm2)]
+        key = (str(dev),) + tuple(l.weight.data_ptr() for l in lins) + (self.norm_out.linear.weight.data_ptr(),)
+        if getattr(self, "_ptr_tables", None) is None or self._ptr_tables[0] != key:
+            def arr(ts):
+                return torch.tensor([0 if t is None else t.data_ptr() for t in ts], dtype=torch.int64, device=dev)
+            no = self.norm_out.linear
+            self._ptr_tables = (key, dict(w_blk=arr([l.weight for l in lins]), b_blk=arr([l.bias for l in lins]),
+                                          w_out=arr([no.weight]), b_out=arr([no.bias])))
+        return self._ptr_tables[1]
+
     def _linear_k64(self, x2d, lin):
         """A and W of a GEMM whose K is not a multiple of 64 (only tiny test configs) get zero-padded."""
         W, K = lin.weight.reshape(lin.weight.shape[0], -1), x2d.shape[1]
@@ -524,25 +536,10 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         G = 1 + Ta
         grp = ops.groups(S, Nt, per_group)
         L = c.num_layers
-        mod = torch.zeros(2 * L, B, G, 3 * D, dtype=torch.float32, device=dev)
-        a2d = action_emb.reshape(B * Ta, E).contiguous() if action_emb is not None else None
-
-        def fill(table, lin, width, text):
-            wv, bv = lin.weight[:width], (lin.bias[:width] if lin.bias is not None else None)
-            if a2d is not None:
-                ops.skinny_linear(a2d, wv, bv, xb=temb, xb_rep=Ta, act_in="silu", out=table, ldo=width,
-                                  omap=ops.rowmap(Ta, G, 1))
-            else:
-                ops.skinny_linear(temb, wv, bv, act_in="silu", out=table, ldo=width, omap=ops.rowmap(1, G, 1))
-            if text:
-                wt, bt = lin.weight[width:], (lin.bias[width:] if lin.bias is not None else None)
-                ops.skinny_linear(temb, wt, bt, act_in="silu", out=table, ldo=width, omap=ops.rowmap(1, G, 0))
-
-        for i, blk in enumerate(self.transformer_blocks):
-            fill(mod[2 * i], blk.norm1.linear, 3 * D, mod_text)
-            fill(mod[2 * i + 1], blk.norm2.linear, 3 * D, mod_text)
-        modf = torch.zeros(B, G, 2 * D, dtype=torch.float32, device=dev)
-        fill(modf, self.norm_out.linear, 2 * D, False)
+        a3d = action_emb.contiguous() if action_emb is not None else None
+        ptr = self._pointer_tables(dev)
+        mod = ops.modulation_tables(temb, a3d, ptr["w_blk"], ptr["b_blk"], 2 * L, B, Ta, E, 3 * D, mod_text)
+        modf = ops.modulation_tables(temb, a3d, ptr["w_out"], ptr["b_out"], 1, B, Ta, E, 2 * D, False)[0]
 
         rope = None
         if image_rotary_emb is not None:

@@ -232,3 +232,120 @@ extern "C" int orv_qkv_prep(void* qkv, void* vT, const void* gq, const void* bq,
                        H, n_text, s_pad, eps);
     return orv_check_launch("orv_qkv_prep");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// orv_modulation_tables: every AdaLN modulation linear of the forward in ONE launch.
+//   out[tab][b][1+t][:] = W_tab[0:width]      . silu(temb[b] + a[b,t]) + bias[0:width]       (video rows, per frame)
+//   out[tab][b][0][:]   = W_tab[width:2width] . silu(temb[b])          + bias[width:2width]  (text rows, if `text`)
+// (cogvideox_control.py:117-130 "partially forward self.linear twice", :172).  temb/a are the same for all 61 norms of a
+// step, so this is a [rows<=32, E] x [E, 61*6D] GEMM that streams ~0.7 GB of weights once: HBM-bound.  Each wave keeps
+// the conditioning fragments (B operand, rows on the lane axis) in registers and walks 32-column weight blocks with
+// v_mfma_f32_32x32x16_bf16, weight fragments loaded straight from global (each weight byte is used exactly once).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct ModArgs {
+    const bf16_t* temb;       // [B, E]
+    const bf16_t* act;        // [B, T, E] or null (then T == 1 and the video rows use silu(temb))
+    const bf16_t* const* W;   // n_tab pointers to [width * (1 + text), E]
+    const bf16_t* const* bias;
+    float* out;               // [n_tab, B, 1 + T, width]
+    int n_tab, B, T, E, width, text;
+    int vis_tiles;            // ceil(B*T / 32)
+};
+
+template <int KS>  // KS = E / 16 k-steps
+__global__ __launch_bounds__(256) void mod_tables_kernel(const ModArgs p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int tab = blockIdx.y;
+    const bool is_text = (int)blockIdx.z >= p.vis_tiles;
+    const int rtile = is_text ? blockIdx.z - p.vis_tiles : blockIdx.z;
+    const int nrows = is_text ? p.B : p.B * p.T;
+    const int r = rtile * 32 + l31;
+    const bool rvalid = r < nrows;
+    const int b = rvalid ? (is_text ? r : r / p.T) : 0;
+    const int t = rvalid && !is_text ? r % p.T : 0;
+    // conditioning fragments: lane holds cond[r][ks*16 + hi*8 .. +8]
+    bf16x8 cf[KS];
+    {
+        const bf16_t* tp = p.temb + (long)b * p.E + hi * 8;
+        const bf16_t* ap = (!is_text && p.act) ? p.act + ((long)b * p.T + t) * p.E + hi * 8 : nullptr;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const uint4 tu = *(const uint4*)(tp + ks * 16);
+            uint4 au = make_uint4(0, 0, 0, 0);
+            if (ap) au = *(const uint4*)(ap + ks * 16);
+            const uint32_t tw[4] = {tu.x, tu.y, tu.z, tu.w}, aw[4] = {au.x, au.y, au.z, au.w};
+            union { bf16x8 v; uint32_t u[4]; } c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float lo = bf2f(tw[e] & 0xffff), hi2 = bf2f(tw[e] >> 16);
+                if (ap) {  // the reference adds in the model dtype (bf16) before SiLU
+                    lo = bf2f(f2bf(lo + bf2f(aw[e] & 0xffff)));
+                    hi2 = bf2f(f2bf(hi2 + bf2f(aw[e] >> 16)));
+                }
+                c.u[e] = rvalid ? pack2bf(silu(lo), silu(hi2)) : 0u;
+            }
+            cf[ks] = c.v;
+        }
+    }
+    const bf16_t* Wt = p.W[tab] + (is_text ? (long)p.width * p.E : 0);
+    const bf16_t* bt = p.bias ? (p.bias[tab] ? p.bias[tab] + (is_text ? p.width : 0) : nullptr) : nullptr;
+    const int G = 1 + p.T;
+    float* orow = p.out + (((long)tab * p.B + b) * G + (is_text ? 0 : 1 + t)) * p.width;
+    const int nblocks = p.width / 32;
+    for (int nb = blockIdx.x * 4 + wave; nb < nblocks; nb += gridDim.x * 4) {
+        const bf16_t* wp = Wt + (long)(nb * 32 + l31) * p.E + hi * 8;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        constexpr int HALF = KS >= 16 ? 16 : KS;
+#pragma unroll
+        for (int k0 = 0; k0 < KS; k0 += HALF) {
+            bf16x8 wf[HALF];
+#pragma unroll
+            for (int j = 0; j < HALF; ++j) wf[j] = *(const bf16x8*)(wp + (k0 + j) * 16);
+#pragma unroll
+            for (int j = 0; j < HALF; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], cf[k0 + j], acc, 0, 0, 0);
+        }
+        if (rvalid) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = nb * 32 + q * 8 + hi * 4;
+                float4 o = make_float4(acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]);
+                if (bt) {
+                    const uint2 bb = *(const uint2*)(bt + n);
+                    o.x += bf2f(bb.x & 0xffff); o.y += bf2f(bb.x >> 16); o.z += bf2f(bb.y & 0xffff); o.w += bf2f(bb.y >> 16);
+                }
+                *(float4*)(orow + n) = o;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int orv_modulation_tables(const void* temb, const void* action_emb, const void* const* W,
+                                     const void* const* bias, float* out, int n_tab, int B, int T, int E, int width,
+                                     int text, void* stream) {
+    ORV_REQUIRE(temb && W && out, "orv_modulation_tables: null operand");
+    ORV_REQUIRE(n_tab > 0 && B > 0 && T > 0 && width > 0, "orv_modulation_tables: empty problem");
+    ORV_REQUIRE(width % 32 == 0, "orv_modulation_tables: width=%d must be a multiple of 32", width);
+    ORV_REQUIRE(E == 64 || E == 128 || E == 256 || E == 512, "orv_modulation_tables: E=%d unsupported (64/128/256/512)", E);
+    ModArgs a;
+    a.temb = (const bf16_t*)temb; a.act = (const bf16_t*)action_emb; a.W = (const bf16_t* const*)W;
+    a.bias = (const bf16_t* const*)bias; a.out = out; a.n_tab = n_tab; a.B = B; a.T = T; a.E = E; a.width = width;
+    a.text = text; a.vis_tiles = (B * T + 31) / 32;
+    const int txt_tiles = text ? (B + 31) / 32 : 0;
+    const int nblocks = width / 32;
+    dim3 grid(max(1, min((nblocks + 11) / 12, 64)), n_tab, a.vis_tiles + txt_tiles);
+    hipStream_t st = (hipStream_t)stream;
+    switch (E) {
+        case 64: hipLaunchKernelGGL(mod_tables_kernel<4>, grid, dim3(256), 0, st, a); break;
+        case 128: hipLaunchKernelGGL(mod_tables_kernel<8>, grid, dim3(256), 0, st, a); break;
+        case 256: hipLaunchKernelGGL(mod_tables_kernel<16>, grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL(mod_tables_kernel<32>, grid, dim3(256), 0, st, a); break;
+    }
+    return orv_check_launch("orv_modulation_tables");
+}

@@ -127,6 +127,16 @@ def layernorm_modulate(x, y, gamma, beta, scale, shift, mod_b, mod_g, grp: Group
     return y
 
 
+def modulation_tables(temb, action_emb, w_ptrs, b_ptrs, n_tab, B, T, E, width, text, out=None):
+    """All AdaLN tables of a forward: out fp32 [n_tab, B, 1+T, width]; w_ptrs/b_ptrs int64 device tensors of pointers."""
+    _need(temb, BF16, "temb")
+    if out is None:
+        out = torch.zeros(n_tab, B, 1 + T, width, dtype=torch.float32, device=temb.device)
+    check(lib().orv_modulation_tables(_p(temb), _p(action_emb), _p(w_ptrs), _p(b_ptrs), _p(out), n_tab, B, T, E, width,
+                                      int(text), _stream()), "orv_modulation_tables")
+    return out
+
+
 def qkv_prep(qkv, vT, gq, bq, gk, bk, rope: Optional[Tuple[torch.Tensor, torch.Tensor]], B, S, H, n_text, s_pad, eps):
     _need(qkv, BF16, "qkv"), _need(vT, BF16, "vT")
     cos = sin = None

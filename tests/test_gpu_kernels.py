@@ -263,3 +263,30 @@ def test_sched_step_matches_scheduler_math():
             xr, old_r, xo = no.float().cpu(), x0, no
             if i == 3 and n == 50:
                 break
+
+
+@pytest.mark.parametrize("B,T,E,width,text,with_act", [(2, 5, 512, 5760, True, True), (4, 5, 512, 3840, False, True),
+                                                        (3, 1, 64, 384, True, False), (9, 5, 512, 384, True, True)])
+def test_modulation_tables(B, T, E, width, text, with_act):
+    """All AdaLN linears in one launch vs F.linear(silu(temb + a)) / F.linear(silu(temb)) (cogvideox_control.py:117-130)."""
+    from orv_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(B * 100 + T)
+    n_tab = 3
+    temb = q(torch.randn(B, E, generator=g))
+    act = q(torch.randn(B, T, E, generator=g)) if with_act else None
+    Ws = [q(torch.randn(width * (2 if text else 1), E, generator=g) * 0.05) for _ in range(n_tab)]
+    bs = [q(torch.randn(width * (2 if text else 1), generator=g)) for _ in range(n_tab)]
+    dW, db = [w.to(dev, BF) for w in Ws], [b.to(dev, BF) for b in bs]
+    wp = torch.tensor([w.data_ptr() for w in dW], dtype=torch.int64, device=dev)
+    bp = torch.tensor([b.data_ptr() for b in db], dtype=torch.int64, device=dev)
+    out = ops.modulation_tables(temb.to(dev, BF), None if act is None else act.to(dev, BF), wp, bp, n_tab, B, T, E, width, text)
+    cond_v = torch.nn.functional.silu(q(temb[:, None] + act)) if with_act else torch.nn.functional.silu(temb)[:, None]
+    for i in range(n_tab):
+        ref_v = q(cond_v) @ Ws[i][:width].t() + bs[i][:width]
+        close(out[i, :, 1:], ref_v, rtol=1e-2, afrac=5e-3)
+        if text:
+            ref_t = q(torch.nn.functional.silu(temb)) @ Ws[i][width:].t() + bs[i][width:]
+            close(out[i, :, 0], ref_t, rtol=1e-2, afrac=5e-3)
+        else:
+            assert torch.all(out[i, :, 0] == 0)
