@@ -31,15 +31,26 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+// two fp32 -> packed bf16x2, RNE: clang lowers the __bf16 vector convert to one v_cvt_pk_bf16_f32 on gfx950
+typedef float orv_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 orv_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    orv_f32x2 v;
+    v.x = lo;
+    v.y = hi;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, orv_bf16x2));
+}
 
 __device__ __forceinline__ float gelu_tanh(float x) {
     // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))),  tanh(u) = 1 - 2 / (1 + exp(2u))
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    const float t = 1.0f - 2.0f / (1.0f + __expf(2.0f * u));
-    return 0.5f * x * (1.0f + t);
+    // 0.5 x (1 + tanh(u)) = x - x / (1 + exp(2u));  exp(2u) = exp2(u * 2 log2 e), reciprocal via v_rcp_f32
+    const float u2 = (2.0f * 0.7978845608028654f * 1.4426950408889634f) * (x + 0.044715f * x * x * x);
+    const float e = __builtin_amdgcn_exp2f(u2);
+    return x - x * __builtin_amdgcn_rcpf(1.0f + e);
 }
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -15,8 +15,21 @@
 //   * workgroup -> tile map is XCD-aware (block b runs on XCD b % 8): each XCD gets a contiguous chunk of the
 //     tile list, ordered in GM x 8 super-tiles so the 32 CUs of an XCD share A row-panels and W column-panels in L2.
 #include "common.hpp"
+#include <type_traits>
+#include <stdlib.h>
 
 namespace {
+
+int orv_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
 
 struct GemmArgs {
     const bf16_t* A; long lda;
@@ -29,10 +42,78 @@ struct GemmArgs {
     int seq, n_text, per_group;
     int c_rows, c_bstride, c_off;
     int tiles_m, tiles_n;
+    int dbg;  // ORV_GEMM_DBG: 1 = skip main-loop loads, 2 = skip MFMAs (ablation only)
 };
 
 constexpr int BK = 64;
 constexpr int GM = 4;  // super-tile height in tiles
+
+// Epilogue shared by both kernels.  acc[i][j][4q+e] = C[m][n] with m = mbase + j*32 + (lane&31),
+// n = nbase + i*32 + 8q + 4*(lane>>5) + e  (C^T accumulator layout: 4 consecutive columns per register quad).
+template <int NB, int MB, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[NB][MB], int mbase, int nbase, int lane) {
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+        const int m = mbase + j * 32 + l31;
+        if (m >= p.M) continue;
+        long orow = m;
+        if (p.c_rows > 0) orow = (long)(m / p.c_rows) * p.c_bstride + p.c_off + m % p.c_rows;
+        bf16_t* crow = p.C + orow * p.ldc;
+        const bf16_t* rrow = nullptr;
+        const float* grow = nullptr;
+        if (EPI == 2) {
+            const long rr = p.r_mod > 0 ? m % p.r_mod : orow;
+            rrow = p.R + rr * p.ldr;
+            if (p.gate) {
+                const int bidx = (int)(orow / p.seq), s = (int)(orow % p.seq);
+                grow = p.gate + bidx * p.gate_b + orv_group_of(s, p.n_text, p.per_group) * p.gate_g;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = nbase + i * 32 + q * 8 + hi * 4;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
+                if (p.bias) {
+                    const uint2 bb = *(const uint2*)(p.bias + n);
+                    v[0] += bf2f(bb.x & 0xffff); v[1] += bf2f(bb.x >> 16);
+                    v[2] += bf2f(bb.y & 0xffff); v[3] += bf2f(bb.y >> 16);
+                }
+                if (EPI == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+                }
+                if (EPI == 2) {
+                    const uint2 rr = *(const uint2*)(rrow + n);
+                    float g[4] = {1.f, 1.f, 1.f, 1.f};
+                    if (grow) { const float4 gg = *(const float4*)(grow + n); g[0] = gg.x; g[1] = gg.y; g[2] = gg.z; g[3] = gg.w; }
+                    v[0] = bf2f(rr.x & 0xffff) + g[0] * v[0]; v[1] = bf2f(rr.x >> 16) + g[1] * v[1];
+                    v[2] = bf2f(rr.y & 0xffff) + g[2] * v[2]; v[3] = bf2f(rr.y >> 16) + g[3] * v[3];
+                }
+                uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+                *(uint2*)(crow + n) = o;
+            }
+        }
+    }
+}
+
+// XCD-aware tile mapping (bijective for any grid size): block b runs on XCD b % 8; each XCD gets a contiguous chunk of the
+// tile list, ordered in GM x (tiles_n) groups walked m-fastest so concurrent CUs of an XCD share A and W panels in L2.
+__device__ __forceinline__ void tile_of_index(const GemmArgs& p, int b, int nb, int& tm, int& tn) {
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7, j = b >> 3;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    const int per = GM * p.tiles_n;
+    const int gid = L / per, rem = L % per;
+    const int first_m = gid * GM;
+    const int gsize = min(p.tiles_m - first_m, GM);
+    tm = first_m + rem % gsize;
+    tn = rem / gsize;
+}
+__device__ __forceinline__ void tile_of_block(const GemmArgs& p, int& tm, int& tn) { tile_of_index(p, blockIdx.x, gridDim.x, tm, tn); }
 
 template <int BM, int BN, int EPI>
 __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs p) {
@@ -80,13 +161,12 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs p) {
         const int chunk = slot ^ ((row >> 1) & 7);
         b_src[j] = p.W + (long)(n0 + row) * p.ldw + chunk * 8;
     }
-    auto stage_load = [&](int s) {
-        char* sa = smem + s * STAGE + wave * A_LD * 1024;
-        char* sb = smem + s * STAGE + A_BYTES + wave * B_LD * 1024;
-#pragma unroll
-        for (int j = 0; j < A_LD; ++j) { glds16(a_src[j], sa + j * 1024); a_src[j] += BK; }
-#pragma unroll
-        for (int j = 0; j < B_LD; ++j) { glds16(b_src[j], sb + j * 1024); b_src[j] += BK; }
+    // One glds "piece" = 8 tile rows (1 KiB).  Pieces of the NEXT K-tile are issued between the MFMAs of the current one
+    // (an LDS-DMA issue costs ~100 cycles of the wave's issue slot; back-to-back after the barrier they idle the matrix pipe).
+    constexpr int NP = A_LD + B_LD;
+    auto issue_piece = [&](int pc, int s, long koff) {
+        if (pc < A_LD) glds16(a_src[pc] + koff, smem + s * STAGE + (wave * A_LD + pc) * 1024);
+        else glds16(b_src[pc - A_LD] + koff, smem + s * STAGE + A_BYTES + (wave * B_LD + (pc - A_LD)) * 1024);
     };
 
     // ---- fragment read offsets ----
@@ -103,78 +183,262 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    auto read_frags = [&](const char* sbase, int ks, bf16x8 (&af)[MB], bf16x8 (&bf)[NB]) {
+        const int coff = ((ks * 2 + hi) ^ sw) * 16;
+#pragma unroll
+        for (int j = 0; j < MB; ++j) af[j] = *(const bf16x8*)(sbase + a_row_off + j * 32 * 128 + coff);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) bf[i] = *(const bf16x8*)(sbase + b_row_off + i * 32 * 128 + coff);
+    };
+
     const int nk = p.K / BK;
-    stage_load(0);
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) issue_piece(pc, 0, 0);
     for (int t = 0; t < nk; ++t) {
         // tile t has landed for this wave; after the barrier it has landed for all waves and nobody still
         // reads stage (t+1)&1 (those reads were consumed by the MFMAs of iteration t-1).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t + 1 < nk) stage_load((t + 1) & 1);
         const char* sbase = smem + (t & 1) * STAGE;
+        const int ns = (t + 1) & 1;
+        const long koff = (long)((t + 1 < nk) ? (t + 1) : 0) * BK;   // last iteration re-fetches tile 0 (never read)
+        bf16x8 af[2][MB], bf[2][NB];
+        read_frags(sbase, 0, af[0], bf[0]);
+        auto kstep = [&](auto ks_c) {
+            constexpr int ks = decltype(ks_c)::value;
+            constexpr int NM = NB * MB;
+            constexpr int NPC = ((ks + 1) * NP + 2) / 3 - (ks * NP + 2) / 3;   // pieces pc with pc*3/NP == ks
+            if constexpr (ks < 3) read_frags(sbase, ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int coff = ((ks * 2 + hi) ^ sw) * 16;
-            bf16x8 af[MB], bf[NB];
-#pragma unroll
-            for (int j = 0; j < MB; ++j) af[j] = *(const bf16x8*)(sbase + a_row_off + j * 32 * 128 + coff);
-#pragma unroll
-            for (int i = 0; i < NB; ++i) bf[i] = *(const bf16x8*)(sbase + b_row_off + i * 32 * 128 + coff);
+            for (int pc = 0; pc < NP; ++pc)
+                if (pc * 3 / NP == ks) { if (p.dbg != 1) issue_piece(pc, ns, koff); }
 #pragma unroll
             for (int i = 0; i < NB; ++i)
 #pragma unroll
                 for (int j = 0; j < MB; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[i], af[j], acc[i][j], 0, 0, 0);
-        }
+                    if (p.dbg != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks & 1][i], af[ks & 1][j], acc[i][j], 0, 0, 0);
+                    else { asm volatile("" :: "v"(bf[ks & 1][i]), "v"(af[ks & 1][j])); }
+            // schedule: next k-step's LDS reads first, then MFMAs with the DMA issues spread between them
+            if constexpr (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, MB + NB, 0);
+            constexpr int PER = NPC > 0 ? (NM / (NPC + 1) > 0 ? NM / (NPC + 1) : 1) : NM;
+            if constexpr (NPC >= 1) { __builtin_amdgcn_sched_group_barrier(0x8, PER, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); }
+            if constexpr (NPC >= 2) { __builtin_amdgcn_sched_group_barrier(0x8, PER, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); }
+            if constexpr (NPC >= 3) { __builtin_amdgcn_sched_group_barrier(0x8, PER, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); }
+            if constexpr (NPC >= 4) { __builtin_amdgcn_sched_group_barrier(0x8, PER, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); }
+            constexpr int LEFT = NM - (NPC > 4 ? 4 : NPC) * PER;
+            if constexpr (LEFT > 0) __builtin_amdgcn_sched_group_barrier(0x8, LEFT, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        kstep(std::integral_constant<int, 0>{});
+        kstep(std::integral_constant<int, 1>{});
+        kstep(std::integral_constant<int, 2>{});
+        kstep(std::integral_constant<int, 3>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    gemm_epilogue<NB, MB, EPI>(p, acc, m0 + wm * (BM / 4), n0 + wn * (BN / 2), lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ring kernel for the large shapes (BM = 256, persistent: one workgroup per CU walks the tile list).
+//   * Operands stream through a ring of NSLOT sub-stages of (256 + BN) rows x 32 K (64-byte rows; 16-byte chunk c of row
+//     r lives at slot c ^ ((r >> 2) & 3): conflict-free ds_read_b128), filled by global_load_lds NSLOT-1 sub-stages
+//     ahead of the reader.  The DMA stream is continuous across tile boundaries (the next tile's first sub-stages are
+//     in flight while the current tile's epilogue runs) and is throttled only by counted s_waitcnt vmcnt(N): it never
+//     drains at a barrier.
+//   * ONE s_barrier per sub-stage.  Each wave holds the fragments of sub-stage g in registers (read during sub-stage
+//     g-1), so after the barrier both waves of a SIMD have MFMAs ready at once: the matrix pipe never waits for LDS.
+//     The ds_reads of sub-stage g+1 and the wave's DMA pieces of sub-stage g+NSLOT-1 are issued between the 12
+//     v_mfma_f32_32x32x16_bf16 of sub-stage g.
+//   * Measured alternatives on this chip (tools/abl.sh, tools/trace_gemm.cpp): a 2-stage BK=64 double buffer with one
+//     vmcnt(0)+barrier per tile, and a strict ping-pong of two 4-wave groups (one computing, one reading LDS, a barrier
+//     per phase) both stall the matrix pipe ~45 % of the time - the first on lock-step LDS latency + DMA issue bursts,
+//     the second on the barrier itself (only one wave per SIMD ever has MFMAs to issue).
+// ---------------------------------------------------------------------------------------------------------------
+template <int BN, int NSLOT, int EPI, int NPC>
+__device__ __forceinline__ void gemm_ring_body(const GemmArgs& p, char* smem, const int wave, const int lane) {
+    constexpr int BM = 256;
+    constexpr int MB = 2, NB = BN / 64;            // wave sub-tile: 64 rows x BN/2 cols as 32x32 blocks
+    constexpr int ROWS = BM + BN;
+    constexpr int SLOT = ROWS * 64;                // bytes per sub-stage (32 bf16 per row)
+    constexpr int NM = 2 * NB * MB;                // MFMAs per sub-stage per wave
+    constexpr int PER = NM / (NPC + 1);
+    const int grp = wave >> 2, wq = wave & 3;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int nsub = p.K / 32;
+
+    // ---- DMA side: a continuous stream of sub-stages over ALL tiles of this (persistent) workgroup ----
+    // piece q = wave + 8i covers rows [16q, 16q+16) of the stacked [A tile; W tile]; lane -> (row, 16-B slot)
+    const bf16_t* src[NPC];
+    int it_tile = blockIdx.x;      // tile the DMA stream is currently fetching
+    int it_sub = 0;                // next sub-stage of that tile
+    int it_slot = 0;               // ring slot of the next sub-stage
+#define ORV_SETUP_SRC(TILE)                                                                                          \
+    {                                                                                                                \
+        int tm_, tn_;                                                                                                \
+        tile_of_index(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                                                 \
+        _Pragma("unroll") for (int i = 0; i < NPC; ++i) {                                                            \
+            const int row = (wave + 8 * i) * 16 + (lane >> 2);                                                       \
+            const int chunk = (lane & 3) ^ ((lane >> 4) & 3); /* slot = lane & 3 = chunk ^ ((row >> 2) & 3) */       \
+            if (row < BM) src[i] = p.A + (long)min(tm_ * BM + row, p.M - 1) * p.lda + chunk * 8;                     \
+            else src[i] = p.W + (long)(tn_ * BN + min(row - BM, BN - 1)) * p.ldw + chunk * 8;                        \
+        }                                                                                                            \
+    }
+    // advance the stream.  Past the last tile it re-fetches the final sub-stage into free ring slots (never read): the DMA
+    // count per sub-stage stays uniform, so the counted vmcnt waits need no tail case and the MFMA stream no branches.
+#define ORV_ADVANCE()                                                                                                \
+    {                                                                                                                \
+        it_slot = (it_slot + 1 == NSLOT) ? 0 : it_slot + 1;                                                          \
+        if (++it_sub == nsub) {                                                                                      \
+            it_tile += gridDim.x;                                                                                    \
+            if (it_tile < ntiles) { it_sub = 0; ORV_SETUP_SRC(it_tile) }                                             \
+            else it_sub = nsub - 1;                                                                                  \
+        }                                                                                                            \
+    }
+#define ORV_ISSUE_PIECES()                                                                                           \
+    _Pragma("unroll") for (int g = 0; g < NPC; ++g)                                                                  \
+        glds16(src[g] + (long)it_sub * 32, smem + it_slot * SLOT + (wave + 8 * g) * 1024);
+    ORV_SETUP_SRC(it_tile)
+
+    // ---- fragment addressing ----
+    const int l31 = lane & 31, hi = lane >> 5, sw = (l31 >> 2) & 3;
+    const int a_off = (wq * 64 + l31) * 64;
+    const int b_off = (BM + grp * (BN / 2) + l31) * 64;
+    const int coff0 = ((0 * 2 + hi) ^ sw) * 16, coff1 = ((1 * 2 + hi) ^ sw) * 16;
+    bf16x8 fa0[2][MB], fb0[2][NB], fa1[2][MB], fb1[2][NB];   // two fragment sets [k-step][block]
+    int rd_slot = 0;               // ring slot of the next sub-stage to read
+#define ORV_READ_FRAGS(FA, FB)                                                                                       \
+    {                                                                                                                \
+        const char* sb_ = smem + rd_slot * SLOT;                                                                     \
+        _Pragma("unroll") for (int j = 0; j < MB; ++j) {                                                             \
+            FA[0][j] = *(const bf16x8*)(sb_ + a_off + j * 32 * 64 + coff0);                                          \
+            FA[1][j] = *(const bf16x8*)(sb_ + a_off + j * 32 * 64 + coff1);                                          \
+        }                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                             \
+            FB[0][i] = *(const bf16x8*)(sb_ + b_off + i * 32 * 64 + coff0);                                          \
+            FB[1][i] = *(const bf16x8*)(sb_ + b_off + i * 32 * 64 + coff1);                                          \
+        }                                                                                                            \
+        rd_slot = (rd_slot + 1 == NSLOT) ? 0 : rd_slot + 1;                                                          \
     }
 
-    // ---- epilogue: acc[i][j][4q+e] = C[m][n], m = m0 + wm*BM/4 + j*32 + l31, n = n0 + wn*BN/2 + i*32 + 8q + 4hi + e
+    f32x16 acc[NB][MB];
 #pragma unroll
-    for (int j = 0; j < MB; ++j) {
-        const int m = m0 + wm * (BM / 4) + j * 32 + l31;
-        if (m >= p.M) continue;
-        long orow = m;
-        if (p.c_rows > 0) orow = (long)(m / p.c_rows) * p.c_bstride + p.c_off + m % p.c_rows;
-        bf16_t* crow = p.C + orow * p.ldc;
-        const bf16_t* rrow = nullptr;
-        const float* grow = nullptr;
-        if (EPI == 2) {
-            const long rr = p.r_mod > 0 ? m % p.r_mod : orow;
-            rrow = p.R + rr * p.ldr;
-            if (p.gate) {
-                const int bidx = (int)(orow / p.seq), s = (int)(orow % p.seq);
-                grow = p.gate + bidx * p.gate_b + orv_group_of(s, p.n_text, p.per_group) * p.gate_g;
-            }
-        }
+    for (int i = 0; i < NB; ++i)
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
+        for (int j = 0; j < MB; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * (BN / 2) + i * 32 + q * 8 + hi * 4;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
-                if (p.bias) {
-                    const uint2 bb = *(const uint2*)(p.bias + n);
-                    v[0] += bf2f(bb.x & 0xffff); v[1] += bf2f(bb.x >> 16);
-                    v[2] += bf2f(bb.y & 0xffff); v[3] += bf2f(bb.y >> 16);
-                }
-                if (EPI == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-                }
-                if (EPI == 2) {
-                    const uint2 rr = *(const uint2*)(rrow + n);
-                    float g[4] = {1.f, 1.f, 1.f, 1.f};
-                    if (grow) { const float4 gg = *(const float4*)(grow + n); g[0] = gg.x; g[1] = gg.y; g[2] = gg.z; g[3] = gg.w; }
-                    v[0] = bf2f(rr.x & 0xffff) + g[0] * v[0]; v[1] = bf2f(rr.x >> 16) + g[1] * v[1];
-                    v[2] = bf2f(rr.y & 0xffff) + g[2] * v[2]; v[3] = bf2f(rr.y >> 16) + g[3] * v[3];
-                }
-                uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-                *(uint2*)(crow + n) = o;
-            }
-        }
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#ifdef ORV_GEMM_ABLATE_NOMFMA
+#define ORV_MFMA(FA, FB, kk, i, j) asm volatile("" ::"v"(FB[kk][i]), "v"(FA[kk][j]));
+#else
+#define ORV_MFMA(FA, FB, kk, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[kk][i], FA[kk][j], acc[i][j], 0, 0, 0);
+#endif
+#ifdef ORV_GEMM_ABLATE_NOLOAD
+#define ORV_ISSUE_MAIN()
+#else
+#define ORV_ISSUE_MAIN() ORV_ISSUE_PIECES()
+#endif
+    // one sub-stage: counted DMA wait + barrier (sub-stage g+1 is complete in LDS, slot g-1 is free), then
+    //   ds_reads of g+1 -> fragment set NXT | MFMAs of g on fragment set CUR | DMA pieces of g+NSLOT-1 -> slot g-1
+#define ORV_SUBSTAGE(FA_CUR, FB_CUR, FA_NXT, FB_NXT)                                                                 \
+    {                                                                                                                \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 3) * NPC) : "memory");                                     \
+        __builtin_amdgcn_s_barrier();                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        ORV_READ_FRAGS(FA_NXT, FB_NXT)                                                                               \
+        ORV_ISSUE_MAIN()                                                                                             \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                             \
+            _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                           \
+                _Pragma("unroll") for (int j = 0; j < MB; ++j) { ORV_MFMA(FA_CUR, FB_CUR, kk, i, j) }                \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                             \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MB + NB), 0);                                               \
+        if constexpr (NPC >= 1) { __builtin_amdgcn_sched_group_barrier(0x8, PER, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); } \
+        if constexpr (NPC >= 2) { __builtin_amdgcn_sched_group_barrier(0x8, PER, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); } \
+        if constexpr (NPC >= 3) { __builtin_amdgcn_sched_group_barrier(0x8, PER, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); } \
+        if constexpr (NPC >= 4) { __builtin_amdgcn_sched_group_barrier(0x8, PER, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); } \
+        __builtin_amdgcn_sched_group_barrier(0x8, NM - 1 - NPC * PER, 0);                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        ORV_ADVANCE()                                                                                                \
     }
+
+    // prologue: stream sub-stages 0 .. NSLOT-2, then fragments of sub-stage 0
+#pragma unroll
+    for (int s2 = 0; s2 < NSLOT - 1; ++s2) {
+        ORV_ISSUE_PIECES()
+        ORV_ADVANCE()
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 2) * NPC) : "memory");
+    __builtin_amdgcn_s_barrier();
+    ORV_READ_FRAGS(fa0, fb0)
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        for (int j = 0; j < nsub; j += 2) {            // K % 64 == 0, so nsub is even: static fragment-set names
+            ORV_SUBSTAGE(fa0, fb0, fa1, fb1)
+            ORV_SUBSTAGE(fa1, fb1, fa0, fb0)
+        }
+        // finished tile -> memory, then drain: the stores (vmcnt counts them, out of order with the DMA loads) must not
+        // be mistaken for landed DMA pieces by the counted waits that follow.  Everything else outstanding here is old.
+        int tm, tn;
+        tile_of_index(p, tile, ntiles, tm, tn);
+        gemm_epilogue<NB, MB, EPI>(p, acc, tm * BM + wq * 64, tn * BN + grp * (BN / 2), lane);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j2 = 0; j2 < MB; ++j2)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j2][e] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef ORV_SETUP_SRC
+#undef ORV_ADVANCE
+#undef ORV_ISSUE_PIECES
+#undef ORV_READ_FRAGS
+#undef ORV_MFMA
+#undef ORV_ISSUE_MAIN
+#undef ORV_SUBSTAGE
+}
+
+template <int BN, int NSLOT, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs p) {
+    constexpr int PIECES = (256 + BN) / 16;        // 1-KiB DMA pieces (16 rows) per sub-stage
+    constexpr int P0 = (PIECES + 7) / 8;
+    // pieces per wave are uniform within each half of the workgroup: waves 0-3 own pieces q = w + 8i, waves 4-7 likewise
+    constexpr int NP_G0 = (3 + 8 * (P0 - 1) < PIECES) ? P0 : P0 - 1;
+    constexpr int NP_G1 = (7 + 8 * (P0 - 1) < PIECES) ? P0 : P0 - 1;
+    static_assert((0 + 8 * (P0 - 1) < PIECES) == (3 + 8 * (P0 - 1) < PIECES) &&
+                      (4 + 8 * (P0 - 1) < PIECES) == (7 + 8 * (P0 - 1) < PIECES),
+                  "piece split must be uniform per wave group");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave < 4) gemm_ring_body<BN, NSLOT, EPI, NP_G0>(p, smem, wave, lane);
+    else gemm_ring_body<BN, NSLOT, EPI, NP_G1>(p, smem, wave, lane);
+}
+
+template <int BN, int NSLOT>
+int launch_pp(const GemmArgs& a, int epi, hipStream_t st) {
+    const int smem = NSLOT * (256 + BN) * 64;
+    const int grid = min(a.tiles_m * a.tiles_n, orv_num_cus());   // persistent: one workgroup per CU walks the tile list
+#define ORV_GEMM_CASE(E)                                                                                    \
+    case E: {                                                                                               \
+        static bool attr_done = false;                                                                      \
+        if (!attr_done) {                                                                                   \
+            (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<BN, NSLOT, E>,                            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);                    \
+            attr_done = true;                                                                               \
+        }                                                                                                   \
+        hipLaunchKernelGGL((gemm_pp_kernel<BN, NSLOT, E>), dim3(grid), dim3(512), smem, st, a);             \
+        break;                                                                                              \
+    }
+    switch (epi) {
+        ORV_GEMM_CASE(0)
+        ORV_GEMM_CASE(1)
+        ORV_GEMM_CASE(2)
+        default: orv_set_error("orv_gemm_bf16: bad epilogue %d", epi); return ORV_EINVAL;
+    }
+#undef ORV_GEMM_CASE
+    return orv_check_launch("orv_gemm_bf16");
 }
 
 template <int BM, int BN>
@@ -222,12 +486,19 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
     a.gate = g->gate; a.gate_b = g->gate_b; a.gate_g = g->gate_g;
     a.seq = g->grp.seq; a.n_text = g->grp.n_text; a.per_group = g->grp.per_group;
     a.c_rows = g->cmap.rows; a.c_bstride = g->cmap.bstride; a.c_off = g->cmap.off;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("ORV_GEMM_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     hipStream_t st = (hipStream_t)stream;
     const int bn = (g->N % 192 == 0) ? 192 : (g->N % 128 == 0 ? 128 : 64);
     a.tiles_n = g->N / bn;
     const int tiles256 = ((g->M + 255) / 256) * a.tiles_n;
     const bool big = tiles256 >= 224;  // ~one full wave of workgroups over the 256 CUs
     a.tiles_m = big ? (g->M + 255) / 256 : (g->M + 127) / 128;
+    static int algo = -1;   // ORV_GEMM_ALGO=0 forces the simple double-buffered kernel (A/B testing)
+    if (algo < 0) { const char* e = getenv("ORV_GEMM_ALGO"); algo = e ? atoi(e) : 1; }
+    if (big && algo == 1) {
+        if (bn == 192) return launch_pp<192, 5>(a, g->epilogue, st);
+        if (bn == 128) return launch_pp<128, 5>(a, g->epilogue, st);
+    }
     if (bn == 192) return big ? launch<256, 192>(a, g->epilogue, st) : launch<128, 192>(a, g->epilogue, st);
     if (bn == 128) return big ? launch<256, 128>(a, g->epilogue, st) : launch<128, 128>(a, g->epilogue, st);
     return big ? launch<256, 64>(a, g->epilogue, st) : launch<128, 64>(a, g->epilogue, st);

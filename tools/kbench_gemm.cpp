@@ -47,6 +47,7 @@ static void bench(int M,int N,int K,int epi,int iters){
 }
 int main(int argc,char**argv){
   if(orv_device_check(0)){ printf("%s\n",orv_last_error()); return 2; }
+  if(argc>=7 && !strcmp(argv[1],"bench")){ bench(atoi(argv[2]),atoi(argv[3]),atoi(argv[4]),atoi(argv[5]),atoi(argv[6])); return 0; }
   int bad=0;
   bad+=check(64,128,128,0,64,8,0); bad+=check(100,192,256,1,50,8,14); bad+=check(300,64,1920,0,300,0,0);
   bad+=check(700,384,512,2,350,30,64); bad+=check(3226,1920,1920,2,3226,226,600); bad+=check(3226,7680,1920,1,3226,226,600);
