@@ -101,11 +101,14 @@ int orv_modulation_tables(const void* temb, const void* action_emb, const void* 
 
 /* In-place per-head LayerNorm(64, eps) on the q and k thirds of a packed qkv buffer [B*S, 3*H*64] bf16, optional
  * RoPE on rows >= n_text (pairs (2i,2i+1); cos/sin fp32 [S-n_text, 64]), and transpose of the v third into
- * vT [B, H, 64, s_pad] (zero-filled for s >= S).  Replaces cogvideox_control.py:239-254 (+ diffusers
- * Attention.norm_q/norm_k, apply_rotary_emb). */
+ * vT [B, H, 64, s_pad] (zero-filled for s >= S; the key axis is stored with bits 2 and 3 of the key index exchanged,
+ * the order orv_attention_fwd's PV MFMA consumes).  q is multiplied by `q_premul` before its single bf16 rounding: pass
+ * softmax_scale * log2(e) and call orv_attention_fwd with scale = softmax_scale / q_premul to take its fused exp2 path
+ * (1.0f = leave q as is).  Replaces cogvideox_control.py:239-254 (+ diffusers Attention.norm_q/norm_k,
+ * apply_rotary_emb). */
 int orv_qkv_prep(void* qkv, void* vT, const void* gq, const void* bq, const void* gk, const void* bk,
                  const float* rope_cos, const float* rope_sin, int B, int S, int H, int n_text, int s_pad,
-                 float eps, void* stream);
+                 float eps, float q_premul, void* stream);
 
 /* -- GEMM ------------------------------------------------------------------------------------- */
 /* C = epilogue(A[M,K] . W[N,K]^T + bias[N]); bf16 operands, fp32 MFMA accumulation, bf16 output.

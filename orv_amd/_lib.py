@@ -43,7 +43,7 @@ SIGNATURES = {
     "orv_modulation_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                       c_int, c_void_p]),
     "orv_qkv_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                             c_int, c_int, c_int, c_int, c_float, c_void_p]),
+                             c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
     "orv_gemm_bf16": (c_int, [POINTER(Gemm), c_void_p]),
     "orv_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                   c_float, c_void_p]),

@@ -38,6 +38,7 @@ from .embeddings import sincos_3d
 from .schedulers import CogVideoXDDIMScheduler, CogVideoXDPMScheduler, retrieve_timesteps
 
 BF16 = torch.bfloat16
+LOG2E = 1.4426950408889634
 
 
 class FrozenConfig(dict):
@@ -557,8 +558,10 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             wqkv, bqkv = at.packed_qkv()
             ops.gemm(xn, wqkv, bqkv, qkv, M, 3 * D, D)
             nq, nk = at.norm_q, at.norm_k
-            ops.qkv_prep(qkv, vT, nq.weight, nq.bias, nk.weight, nk.bias, rope, B, S, heads, Nt, s_pad, at.eps)
-            ops.attention_fwd(qkv, vT, att, B, S, heads, s_pad, scale)
+            # softmax scale and log2(e) are folded into q (one rounding) so the attention kernel's exp2 needs no multiply
+            ops.qkv_prep(qkv, vT, nq.weight, nq.bias, nk.weight, nk.bias, rope, B, S, heads, Nt, s_pad, at.eps,
+                         q_premul=scale * LOG2E)
+            ops.attention_fwd(qkv, vT, att, B, S, heads, s_pad, 1.0 / LOG2E)
             ops.gemm(att, at.to_out[0].weight, at.to_out[0].bias, x, M, D, D, epilogue=2, R=x, ldr=D,
                      gate=m1[..., 2 * D:], gate_b=mb, gate_g=mg, grp=grp)
             ops.layernorm_modulate(x, xn, blk.norm2.norm.weight, blk.norm2.norm.bias, m2[..., D:2 * D], m2[..., :D],

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(bf16_t* __restrict__ qkv,
                                                        const bf16_t* __restrict__ gq, const bf16_t* __restrict__ bq,
                                                        const bf16_t* __restrict__ gk, const bf16_t* __restrict__ bk,
                                                        const float* __restrict__ rcos, const float* __restrict__ rsin,
-                                                       int S, int H, int n_text, int s_pad, float eps) {
+                                                       int S, int H, int n_text, int s_pad, float eps, float q_premul) {
     __shared__ bf16_t vt_s[64][66];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
@@ -156,6 +156,10 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(bf16_t* __restrict__ qkv,
                     v[e] = a * cp[e] - c2 * sp[e];
                     v[e + 1] = c2 * cp[e + 1] + a * sp[e + 1];
                 }
+            }
+            if (which == 0 && q_premul != 1.0f) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= q_premul;   // softmax scale (and log2 e) folded into q: one rounding
             }
             if (ok) {
                 uint4 o;
@@ -220,7 +224,7 @@ extern "C" int orv_layernorm_modulate(const void* x, int ldx, orv_rowmap_t xmap,
 
 extern "C" int orv_qkv_prep(void* qkv, void* vT, const void* gq, const void* bq, const void* gk, const void* bk,
                             const float* rope_cos, const float* rope_sin, int B, int S, int H, int n_text, int s_pad,
-                            float eps, void* stream) {
+                            float eps, float q_premul, void* stream) {
     ORV_REQUIRE(qkv && vT, "orv_qkv_prep: null operand");
     ORV_REQUIRE(B > 0 && S > 0 && H > 0, "orv_qkv_prep: empty problem");
     ORV_REQUIRE(s_pad % 64 == 0 && s_pad >= S && s_pad == ((S + 63) / 64) * 64,
@@ -229,7 +233,7 @@ extern "C" int orv_qkv_prep(void* qkv, void* vT, const void* gq, const void* bq,
     dim3 grid(s_pad / 64, H, B);
     hipLaunchKernelGGL(qkv_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, (bf16_t*)qkv, (bf16_t*)vT,
                        (const bf16_t*)gq, (const bf16_t*)bq, (const bf16_t*)gk, (const bf16_t*)bk, rope_cos, rope_sin, S,
-                       H, n_text, s_pad, eps);
+                       H, n_text, s_pad, eps, q_premul);
     return orv_check_launch("orv_qkv_prep");
 }
 

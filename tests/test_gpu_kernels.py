@@ -123,9 +123,14 @@ def _attention_reference(qkv, B, S, H, gq, bq, gk, bk, rope, nt):
     return o.transpose(1, 2).reshape(B * S, D), lse, qq, kk
 
 
+LOG2E = 1.4426950408889634
+
+
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("B,S,H,nt,use_rope", [(2, 200, 2, 8, False), (1, 3226, 3, 226, False), (2, 333, 2, 13, True),
                                                 (1, 64, 1, 0, False), (1, 257, 2, 1, True)])
-def test_qkv_prep_and_attention(B, S, H, nt, use_rope):
+def test_qkv_prep_and_attention(B, S, H, nt, use_rope, fused):
+    """fused: softmax scale * log2(e) folded into q by orv_qkv_prep (q_premul) -> the attention kernel's exp2 fast path."""
     from orv_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(S)
@@ -141,9 +146,10 @@ def test_qkv_prep_and_attention(B, S, H, nt, use_rope):
     dq = qkv.to(dev, BF).clone()
     vT = torch.full((B, H, 64, s_pad), float("nan"), dtype=BF, device=dev)
     ops.qkv_prep(dq, vT, gq.to(dev, BF), bq.to(dev, BF), gk.to(dev, BF), bk.to(dev, BF),
-                 None if rope is None else tuple(r.to(dev) for r in rope), B, S, H, nt, s_pad, 1e-6)
+                 None if rope is None else tuple(r.to(dev) for r in rope), B, S, H, nt, s_pad, 1e-6,
+                 q_premul=0.125 * LOG2E if fused else 1.0)
     got = dq.float().cpu().view(B, S, 3, H, 64)
-    close(got[:, :, 0].transpose(1, 2), q_ref)
+    close(got[:, :, 0].transpose(1, 2), q_ref * (0.125 * LOG2E if fused else 1.0))
     close(got[:, :, 1].transpose(1, 2), k_ref)
     assert torch.equal(got[:, :, 2], qkv.view(B, S, 3, H, 64)[:, :, 2])          # v third untouched
     # vT layout: pos = key with bits 2 and 3 swapped inside each 16-key group; zero padding (bit-exact copy)
@@ -154,12 +160,13 @@ def test_qkv_prep_and_attention(B, S, H, nt, use_rope):
     assert torch.equal(vT.float().cpu(), want)
     out = torch.full((B * S, D), float("nan"), dtype=BF, device=dev)
     lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
-    ops.attention_fwd(dq, vT, out, B, S, H, s_pad, 0.125, lse=lse)
+    ops.attention_fwd(dq, vT, out, B, S, H, s_pad, 1.0 / LOG2E if fused else 0.125, lse=lse)
     close(out, ref)
     close(lse, lse_ref, rtol=2e-2, afrac=5e-3)
 
 
-def test_attention_online_softmax_rescale_branch():
+@pytest.mark.parametrize("fused", [False, True])
+def test_attention_online_softmax_rescale_branch(fused):
     """A key far above the rest, late in the sequence, forces a large running-max jump (the rescale path)."""
     from orv_amd import ops
     dev = _dev()
@@ -175,9 +182,9 @@ def test_attention_online_softmax_rescale_branch():
     # feed q,k through the same LN as the reference
     ref, _, _, _ = _attention_reference(qkv, B, S, H, ident[0], ident[1], ident[0], ident[1], None, 0)
     ops.qkv_prep(dq, vT, ident[0].to(dev, BF), ident[1].to(dev, BF), ident[0].to(dev, BF), ident[1].to(dev, BF), None, B, S,
-                 H, 0, s_pad, 1e-6)
+                 H, 0, s_pad, 1e-6, q_premul=0.125 * LOG2E if fused else 1.0)
     out = torch.empty(B * S, 64, dtype=BF, device=dev)
-    ops.attention_fwd(dq, vT, out, B, S, H, s_pad, 0.125)
+    ops.attention_fwd(dq, vT, out, B, S, H, s_pad, 1.0 / LOG2E if fused else 0.125)
     close(out, ref)
 
 

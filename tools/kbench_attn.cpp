@@ -1,0 +1,17 @@
+// Standalone micro-benchmark of orv_qkv_prep + orv_attention_fwd at the CogVideoX-2B shape (no torch).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cstring>
+#include "../include/orv_mi355.h"
+int main(int argc,char**argv){ int B=argc>1?atoi(argv[1]):4, S=3226, H=30; int s_pad=(S+63)/64*64; size_t n=(size_t)B*S*3*H*64;
+  std::vector<uint16_t> h(n); for(size_t i=0;i<n;i++){ float f=((rand()&0xffff)/32768.f-1.f); uint32_t u; memcpy(&u,&f,4); h[i]=u>>16; }
+  uint16_t *qkv,*vT,*out; hipMalloc(&qkv,n*2); hipMalloc(&vT,(size_t)B*H*64*s_pad*2); hipMalloc(&out,(size_t)B*S*H*64*2); hipMemcpy(qkv,h.data(),n*2,hipMemcpyHostToDevice); hipMemset(vT,0,(size_t)B*H*64*s_pad*2);
+  float premul = getenv("FUSED") ? 0.125f*1.4426950408889634f : 1.0f; float sc = getenv("FUSED") ? 1.0f/1.4426950408889634f : 0.125f;
+  orv_qkv_prep(qkv,vT,nullptr,nullptr,nullptr,nullptr,nullptr,nullptr,B,S,H,226,s_pad,1e-6f,premul,nullptr);
+  hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for(int i=0;i<3;i++) orv_attention_fwd(qkv,3*H*64,vT,out,H*64,nullptr,B,S,H,s_pad,sc,nullptr);
+  hipEventRecord(e0); for(int i=0;i<20;i++) orv_attention_fwd(qkv,3*H*64,vT,out,H*64,nullptr,B,S,H,s_pad,sc,nullptr); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms,e0,e1); ms/=20;
+  printf("attention B=%d S=%d H=%d: %.4f ms  %.1f TFLOP/s (variant %s)\n",B,S,H,ms,4.0*B*H*(double)S*S*64/ms/1e9, getenv("ORV_ATTN_VARIANT")?getenv("ORV_ATTN_VARIANT"):"default");
+  return 0; }
