@@ -79,6 +79,12 @@ int orv_patchify(const void* src0, int c0, const void* src1, int c1, void* token
 /* Inverse scatter of cogvideox_control.py:926-936: x [B, N, p*p*(pt)*C] -> out [B,T,C,H,W].  Index-exact. */
 int orv_unpatchify(const void* x, void* out, int B, int T, int C, int H, int W, int p, int pt, void* stream);
 
+/* out[m, col_off + d] = a[amap(m), d] + b[m, d] (bf16, fp32 add, one rounding): builds the input of
+ * initial_combine_linear, `hidden_states.repeat(1, 1, num_control_keys) + cat(controls, -1)` (cogvideox_control.py:849-855),
+ * one control key per call, reading the video rows of the joint sequence in place. */
+int orv_add_rows(const void* a, int lda, orv_rowmap_t amap, const void* b, int ldb, void* out, int ldo, int col_off, int M,
+                 int D, void* stream);
+
 /* -- normalisation ---------------------------------------------------------------------------- */
 /* y = LN(x; gamma, beta, eps) * (1 + scale[b, g(s)]) + shift[b, g(s)]   (CogVideoXLayerNormZero.forward
  * cogvideox_control.py:117-145, AdaLayerNorm.forward :155-197, nn.LayerNorm norm_final :909-916).

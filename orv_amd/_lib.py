@@ -38,6 +38,7 @@ SIGNATURES = {
     "orv_patchify": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                              c_void_p]),
     "orv_unpatchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "orv_add_rows": (c_int, [c_void_p, c_int, RowMap, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "orv_layernorm_modulate": (c_int, [c_void_p, c_int, RowMap, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_long, c_long, Groups, c_int, c_int, c_float, c_void_p]),
     "orv_modulation_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -526,8 +526,31 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
                 actions_recon = self.action_recon(action_emb)
                 if pad_frames > 0:
                     actions_recon = actions_recon[:, pad_frames:]
-        if controls_or_guidances.get('depths', None) is not None and c.visual_guidance:
-            raise NotImplementedError("visual_guidance fuse (:828-858, BASELINE config 4) is not built yet")
+        # 3b. occupancy-derived visual guidance (:828-858): each control map goes through the SAME patch-embed (+ pos table),
+        #     initial_combine_linear(hidden.repeat(1,1,K) + cat(controls)) is added to the video rows.  The reference also
+        #     runs text_proj for every control map and throws the result away (:833,:842) - not reproduced.
+        ctrl_toks = []
+        if c.visual_guidance:
+            for key in ('depths', 'labels'):
+                cm = controls_or_guidances.get(key, None)
+                if cm is None:
+                    continue
+                tk = ops.patchify(cm.to(device=dev, dtype=BF16), None, p, pt)
+                a2c, w2c = self._linear_k64(tk.view(B * Nv, -1), pe.proj)
+                ctok = torch.empty(B * Nv, D, dtype=BF16, device=dev)
+                ops.gemm(a2c, w2c, pe.proj.bias, ctok, B * Nv, D, a2c.shape[1], epilogue=2 if pos is not None else 0,
+                         R=pos, r_mod=Nv, ldr=D)
+                ctrl_toks.append(ctok)
+        if ctrl_toks:
+            assert len(ctrl_toks) == self.num_control_keys, \
+                f'Mismatched number of controls: {len(ctrl_toks)=} but {self.num_control_keys=}.'
+            K2 = self.num_control_keys * D
+            comb = torch.empty(B * Nv, K2, dtype=BF16, device=dev)
+            vmap = ops.rowmap(Nv, S, Nt)
+            for jx, ctok in enumerate(ctrl_toks):
+                ops.add_rows(x, vmap, ctok, comb, jx * D, B * Nv, D, ldo=K2)
+            icl = self.initial_combine_linear
+            ops.gemm(comb, icl.weight, icl.bias, x, B * Nv, D, K2, epilogue=2, R=x, ldr=D, cmap=vmap)
 
         # 4. modulation tables for every norm, fp32 [B, G, 3D]: group 0 = text rows, 1.. = frames (:117-145)
         Ta = action_emb.shape[1] if action_emb is not None else 1
@@ -720,9 +743,15 @@ class CogVideoXImageToVideoPipelineTraj:
                 controls['actions'] = torch.cat(
                     [a, torch.zeros((a.size(0), add * self.vae_scale_factor_temporal, a.size(2)), dtype=a.dtype,
                                     device=a.device)], dim=1)
+        # occupancy controls given as un-sampled VAE moments [B, 2C, F, H, W] are sampled, scaled and doubled along the
+        # channel axis exactly as :1332-1364 (global RNG, like the reference's `.sample()` without a generator)
         for key in ('depths', 'labels'):
-            if controls.get(key, None) is not None:
-                raise NotImplementedError("visual guidance controls (BASELINE config 4) are not built yet")
+            cm = controls.get(key, None)
+            if cm is not None and cm.ndim == 5 and cm.size(1) == latent_channels * 2:
+                cm = cm.to(device=device, dtype=dtype)
+                eps = torch.randn((cm.shape[0], latent_channels) + tuple(cm.shape[2:]), device=device, dtype=dtype)
+                lat = ops.gaussian_sample(cm, eps.float(), self._scale())
+                controls[key] = torch.cat([lat, lat], dim=2)
         image = image.to(device=device, dtype=dtype) if torch.is_tensor(image) else image
         latents, image_latents = self.prepare_latents(image, batch_size * num_videos_per_prompt, latent_channels,
                                                       num_frames, num_views, height, width, dtype, device, generator,

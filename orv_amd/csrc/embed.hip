@@ -165,7 +165,35 @@ __global__ void gaussian_sample_kernel(const bf16_t* __restrict__ mom, const flo
     out[i] = f2bf((bf2f(mom[mi]) + expf(0.5f * lv) * eps[ei]) * scale);
 }
 
+// out[m, col_off + d] = a[amap(m), d] + b[m, d]  (16-byte vectors)
+__global__ void add_rows_kernel(const bf16_t* __restrict__ a, long lda, orv_rowmap_t amap, const bf16_t* __restrict__ b,
+                                long ldb, bf16_t* __restrict__ out, long ldo, int col_off, int M, int D) {
+    const int nchunk = D >> 3;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)M * nchunk) return;
+    const int m = (int)(i / nchunk), c = (int)(i % nchunk);
+    const long ar = amap.rows > 0 ? (long)(m / amap.rows) * amap.bstride + amap.off + m % amap.rows : m;
+    const uint4 ua = *(const uint4*)(a + ar * lda + c * 8);
+    const uint4 ub = *(const uint4*)(b + (long)m * ldb + c * 8);
+    const uint32_t wa[4] = {ua.x, ua.y, ua.z, ua.w}, wb[4] = {ub.x, ub.y, ub.z, ub.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        o[e] = pack2bf(bf2f(wa[e] & 0xffff) + bf2f(wb[e] & 0xffff), bf2f(wa[e] >> 16) + bf2f(wb[e] >> 16));
+    *(uint4*)(out + (long)m * ldo + col_off + c * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 }  // namespace
+
+extern "C" int orv_add_rows(const void* a, int lda, orv_rowmap_t amap, const void* b, int ldb, void* out, int ldo,
+                            int col_off, int M, int D, void* stream) {
+    ORV_REQUIRE(a && b && out && M > 0 && D > 0, "orv_add_rows: bad arguments");
+    ORV_REQUIRE(D % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldo % 8 == 0 && col_off % 8 == 0, "orv_add_rows: misaligned");
+    const long total = (long)M * (D / 8);
+    hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)a, (long)lda, amap, (const bf16_t*)b, (long)ldb, (bf16_t*)out, (long)ldo, col_off, M, D);
+    return orv_check_launch("orv_add_rows");
+}
 
 extern "C" int orv_timestep_embedding(const float* t, void* out_bf16, int batch, int dim, int flip_sin_to_cos,
                                       float freq_shift, void* stream) {

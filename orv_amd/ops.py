@@ -118,6 +118,13 @@ def unpatchify(x, B, T, C, H, W, p: int = 2, pt: Optional[int] = None):
     return out
 
 
+def add_rows(a, amap: Optional[RowMap], b, out, col_off, M, D, lda=None, ldb=None, ldo=None):
+    _need(a, BF16, "a"), _need(b, BF16, "b"), _need(out, BF16, "out")
+    check(lib().orv_add_rows(_p(a), lda or D, amap or RowMap(0, 0, 0), _p(b), ldb or D, _p(out), ldo or D, col_off, M, D,
+                             _stream()), "orv_add_rows")
+    return out
+
+
 def layernorm_modulate(x, y, gamma, beta, scale, shift, mod_b, mod_g, grp: Groups, batch, D, eps, ldx=None, ldy=None,
                        xmap: Optional[RowMap] = None):
     _need(x, BF16, "x"), _need(y, BF16, "y")

@@ -11,7 +11,7 @@ from conftest import load_golden  # noqa: E402
 from oracle import dit  # noqa: E402  (checker only)
 
 BF = torch.bfloat16
-FWD = ["fwd_actions", "fwd_actions_masked", "fwd_noactions", "fwd_nomod", "fwd_nomod_noactions", "fwd_rope", "fwd_pt2_ofs",
+FWD = ["fwd_actions", "fwd_actions_masked", "fwd_cond", "fwd_noactions", "fwd_nomod", "fwd_nomod_noactions", "fwd_rope", "fwd_pt2_ofs",
        "fwd_train_recon"]
 
 
@@ -37,6 +37,9 @@ def test_forward_matches_reference_golden(name):
     if "actions" in ins:
         ctrl["actions"] = ins["actions"].to(dev)
         m.action_embed.forced_mask = torch.tensor(extra["mask"])
+    for key in ("depths", "labels"):
+        if key in ins:
+            ctrl[key] = ins[key].to(dev, BF)
     rope = (ins["rope_cos"].to(dev), ins["rope_sin"].to(dev)) if "rope_cos" in ins else None
     ofs = None if extra["ofs"] is None else torch.full((1,), float(extra["ofs"]), device=dev)
     out, is_mask, recon = m(ins["hidden_states"].to(dev, BF), ins["encoder_hidden_states"].to(dev, BF), ctrl,
