@@ -1,0 +1,150 @@
+"""CPU: the host-side mirror of the reference surface - config, state-dict keys, checkpoint round trip, conversion of a
+vanilla CogVideoX checkpoint, scheduler tables/coefficients vs the oracle, RoPE/sincos tables, C-ABI symbol export."""
+import json
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from oracle import leaf
+
+from orv_amd import schedulers, utils
+from orv_amd.cogvideox_control import CogVideoXTransformer3DModelTraj, CogVideoXImageToVideoPipelineTraj
+from orv_amd.embeddings import sincos_3d
+
+CASES = ["fwd_actions", "fwd_cond", "fwd_nomod", "fwd_rope", "fwd_pt2_ofs", "fwd_multiview", "fwd_train_recon"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_state_dict_keys_equal_reference(name):
+    """Golden weights are the reference module's own state_dict(): key sets and shapes must match exactly."""
+    cfg, _, _, w, _ = load_golden(name)
+    m = CogVideoXTransformer3DModelTraj(**cfg)
+    sd = m.state_dict()
+    assert set(sd) == set(w)
+    assert all(sd[k].shape == w[k].shape for k in w)
+    for k, v in cfg.items():
+        assert getattr(m.config, k) == v
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from orv_amd import _lib
+    header = open(os.path.join(ROOT, "include", "orv_mi355.h")).read()
+    declared = set(re.findall(r"\b(orv_[a-z0-9_]+)\s*\(", header)) - {"orv_groups_t", "orv_rowmap_t", "orv_gemm_t"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    handle = _lib.lib()                      # loads without a GPU; getattr fails if a symbol is missing
+    assert handle.orv_version() == 1
+    for name in declared:
+        assert getattr(handle, name) is not None
+
+
+def test_save_load_roundtrip_and_error_convention(tmp_path):
+    cfg, _, _, w, _ = load_golden("fwd_actions")
+    m = CogVideoXTransformer3DModelTraj(**cfg)
+    m.load_state_dict(w)
+    m.save_pretrained(str(tmp_path / "transformer"), max_shard_size="1MB")        # forces sharding + index json
+    assert json.load(open(tmp_path / "transformer" / "config.json"))["_class_name"] == "CogVideoXTransformer3DModelTraj"
+    m2 = CogVideoXTransformer3DModelTraj.from_pretrained(str(tmp_path), subfolder="transformer", torch_dtype=torch.bfloat16)
+    assert all(torch.equal(m2.state_dict()[k].float(), w[k].to(torch.bfloat16).float()) for k in w)
+    # missing / unexpected keys -> RuntimeError, like cogvideox_control.py:955-967
+    from safetensors.torch import load_file, save_file
+    d = tmp_path / "broken"
+    os.makedirs(d)
+    sd = dict(w)
+    sd.pop("proj_out.bias")
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(d / "diffusion_pytorch_model.safetensors"))
+    json.dump({**cfg, "_class_name": "CogVideoXTransformer3DModelTraj"}, open(d / "config.json", "w"))
+    with pytest.raises(RuntimeError, match="not found in pretrained weights"):
+        CogVideoXTransformer3DModelTraj.from_pretrained(str(d))
+
+
+def test_vanilla_cogvideox_2b_conversion(tmp_path):
+    """THUDM*CogVideoX*-2b* folder (16 input channels, class CogVideoXTransformer3DModel) -> 32 channels, new half zero."""
+    base = dict(num_attention_heads=2, attention_head_dim=64, in_channels=16, out_channels=16, time_embed_dim=64,
+                text_embed_dim=96, num_layers=1, sample_width=12, sample_height=8, sample_frames=9, max_text_seq_length=8)
+    src = CogVideoXTransformer3DModelTraj(**base, modulate_encoder_hidden_states=True)
+    keep = {k: v for k, v in src.state_dict().items() if not k.startswith("action_embed")}
+    d = tmp_path / "THUDM" / "CogVideoX-2b" / "transformer"
+    os.makedirs(d)
+    from safetensors.torch import save_file
+    save_file({k: v.contiguous() for k, v in keep.items()}, str(d / "diffusion_pytorch_model.safetensors"))
+    json.dump({**base, "_class_name": "CogVideoXTransformer3DModel"}, open(d / "config.json", "w"))
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        m = CogVideoXTransformer3DModelTraj.from_pretrained("THUDM/CogVideoX-2b", subfolder="transformer", sample_height=8,
+                                                            sample_width=12, sample_frames=9,
+                                                            modulate_encoder_hidden_states=True,
+                                                            loaded_pretrained_model_name_or_path="THUDM/CogVideoX-2b")
+    finally:
+        os.chdir(cwd)
+    assert m.config.in_channels == 32 and m.config.from_t2v
+    wgt = m.patch_embed.proj.weight
+    assert torch.equal(wgt[:, :16], keep["patch_embed.proj.weight"]) and torch.all(wgt[:, 16:] == 0)
+    with pytest.raises(RuntimeError, match="modulate_encoder_hidden_states"):
+        CogVideoXTransformer3DModelTraj(**base, loaded_pretrained_model_name_or_path="THUDM/CogVideoX-2b")
+
+
+def test_pipeline_rejects_wrong_transformer_type():
+    with pytest.raises(ValueError, match="must be of type CogVideoXTransformer3DModelTraj"):
+        CogVideoXImageToVideoPipelineTraj(transformer=torch.nn.Linear(2, 2), scheduler=None)
+
+
+KW = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+          set_alpha_to_one=True, prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=3.0,
+          timestep_spacing="trailing")
+
+
+@pytest.mark.parametrize("n", [50, 3, 7])
+def test_scheduler_tables_and_coefficients_match_oracle(n):
+    ours, ref = schedulers.CogVideoXDPMScheduler(**KW), leaf.CogVideoXDPMScheduler(**KW)
+    assert torch.allclose(ours.alphas_cumprod, ref.alphas_cumprod, rtol=0, atol=1e-15)
+    ours.set_timesteps(n), ref.set_timesteps(n)
+    ts = ref.timesteps.tolist()
+    assert ours.timesteps.tolist() == ts
+    for i, t in enumerate(ts):
+        tb = ts[i - 1] if i else None
+        sa, sb, m1, m2, mn, m3, m4, prev = ours.step_coefficients(t, tb)
+        a_t = ref.alphas_cumprod[t]
+        a_p = ref.alphas_cumprod[prev] if prev >= 0 else ref.final_alpha_cumprod
+        r = ref.coefficients(a_t, a_p, ref.alphas_cumprod[tb] if tb is not None else None)
+        want = [float(r[0]), float(r[1]), float(r[2])]
+        for g, w_ in zip((m1, m2, mn), want):
+            assert abs(g - w_) <= 1e-9 * max(1.0, abs(w_))
+        if tb is not None and prev >= 0:
+            assert abs(m3 - float(r[3])) <= 1e-9 * max(1, abs(float(r[3]))) and abs(m4 - float(r[4])) <= 1e-9 * max(1, abs(float(r[4])))
+    d, dr = schedulers.CogVideoXDDIMScheduler(**KW), leaf.CogVideoXDDIMScheduler(**KW)
+    d.set_timesteps(n), dr.set_timesteps(n)
+    x, v = torch.randn(4, 3), torch.randn(4, 3)
+    for t in ts:
+        sa, sb, cx, cd = d.step_coefficients(t)
+        want = dr.step(v, t, x, return_dict=False)[0]
+        got = cx * x + cd * (sa * x - sb * v)
+        torch.testing.assert_close(got, want.float(), atol=1e-5, rtol=1e-5)
+    # training-side helpers
+    t3 = torch.tensor([0, 500, 999])
+    x0, nz = torch.randn(3, 2, 4), torch.randn(3, 2, 4)
+    torch.testing.assert_close(d.add_noise(x0, nz, t3), dr.add_noise(x0, nz, t3))
+    torch.testing.assert_close(d.get_velocity(x0, nz, t3), dr.get_velocity(x0, nz, t3))
+
+
+def test_positional_tables_match_oracle():
+    a = sincos_3d(1920, 30, 20, 5, 1.875, 1.0)
+    b = leaf.get_3d_sincos_pos_embed(1920, (30, 20), 5, 1.875, 1.0).flatten(0, 1).float()
+    assert torch.equal(a, b)
+    for (h, w, f, pt) in [(320, 480, 5, None), (256, 384, 8, 2), (480, 640, 5, None)]:
+        cos, sin = utils.prepare_rotary_positional_embeddings(h, w, f, patch_size_t=pt)
+        gh, gw = h // 16, w // 16
+        if pt is None:
+            crops = utils.get_resize_crop_region_for_grid((gh, gw), 45, 30)
+            rc, rs = leaf.get_3d_rotary_pos_embed(64, crops, (gh, gw), f)
+        else:
+            rc, rs = leaf.get_3d_rotary_pos_embed(64, None, (gh, gw), (f + pt - 1) // pt, grid_type="slice", max_size=(30, 45))
+        assert torch.equal(cos, rc) and torch.equal(sin, rs)
+    _, extra, _, _, _ = load_golden("misc_actions")      # crop helper pinned by the reference's own function
+    for key, want in extra["crops"].items():
+        h, w = map(int, key.split("x"))
+        got = utils.get_resize_crop_region_for_grid((h, w), 45, 30)
+        assert [list(got[0]), list(got[1])] == [list(want[0]), list(want[1])]

@@ -1,0 +1,50 @@
+"""CPU, world_size 2 over gloo: the N>1 path of the denoise job is replica sharding - each rank takes a strided slice of
+the clip list (evaluation_control_to_video.py:212-222), runs alone, and only the wall-clock max / result merge cross
+ranks.  No data-path collective exists in inference."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from orv_amd.sharding import merge_rank_results, shard_clips
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_clips, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard_clips(list(range(n_clips)), rank, world)
+    # stand-in for the per-clip denoise: a deterministic function of the clip id
+    results = {i: float(i) * 2.0 + 1.0 for i in mine}
+    wall = torch.tensor([1.0 + rank], dtype=torch.float64)
+    merged, wall_max = merge_rank_results(results, wall)
+    if rank == 0:
+        out.put((merged, wall_max))
+    dist.destroy_process_group()
+
+
+def test_two_rank_replica_sharding():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 7, q)) for r in range(2)]
+    [p.start() for p in procs]
+    merged, wall_max = q.get(timeout=120)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert merged == {i: float(i) * 2.0 + 1.0 for i in range(7)}        # every clip exactly once
+    assert wall_max == 2.0                                              # max over ranks, as bench.py reports
+
+
+def test_shard_is_a_partition():
+    for n, w in [(0, 2), (1, 2), (7, 2), (8, 8), (5, 8)]:
+        parts = [shard_clips(list(range(n)), r, w) for r in range(w)]
+        assert sorted(sum(parts, [])) == list(range(n))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
