@@ -123,6 +123,8 @@ int orv_qkv_prep(void* qkv, void* vT, const void* gq, const void* bq, const void
  * epilogue: 0 bias; 1 bias+GELU(tanh) (FeedForward net.0); 2 C = R[r_row] + gate[b,g(row)] * (acc + bias)
  * (gated residual :419-421,442-443; gate NULL => 1; R row r_row = r_mod ? m % r_mod : out_row, so a
  * [n,D] table broadcast over the batch - the sincos pos-embedding - uses r_mod = n).
+ * epilogue 3 (backward): C = acc * GELU'(R[out_row]) - the dgrad of FeedForward net.2 fused with the GELU adjoint
+ * (R = saved pre-activation).  Epilogue 2 with gate NULL and R == C accumulates gradients in place.
  * Output row remap: out_row = cmap(m) (scatter into the joint [B,S,D] sequence).  Constraints: K % 64 == 0, N % 64 == 0, 16-byte aligned rows. */
 typedef struct {
     const void* A; int lda;
@@ -136,6 +138,48 @@ typedef struct {
     orv_rowmap_t cmap;
 } orv_gemm_t;
 int orv_gemm_bf16(const orv_gemm_t* g, void* stream);
+
+/* -- backward (training) ------------------------------------------------------------------------------ */
+/* dst[c, r] = src[r, c] ([R, C] bf16 -> [C, ld_dst], columns [R, ld_dst) zero-filled).  Feeds the NT GEMM with the
+ * K-contiguous operands of dgrad (W^T) and wgrad (dY^T, X^T): dX = dY . W, dW = dY^T . X (torch autograd of nn.Linear). */
+int orv_transpose_bf16(const void* src, int ld_src, void* dst, int ld_dst, int R, int C, void* stream);
+/* out[c] += sum_r src[r, c] (fp32 atomics): bias gradients. */
+int orv_colsum(const void* src, int ld, float* out, int R, int C, void* stream);
+/* Adjoint of out = x + gate[b,g(row)] * y (cogvideox_control.py:419-421,442-443): dy = gate * dout (bf16),
+ * dgate[b,g,:] += sum_rows dout * y (fp32 atomics into a table laid out like `gate`). */
+int orv_gated_residual_bwd(const void* dout, const void* y, const float* gate, float* dgate, void* dy, long mod_b,
+                           long mod_g, orv_groups_t grp, int batch, int D, void* stream);
+/* Adjoint of orv_layernorm_modulate: dx[xmap(r)] = LN-path gradient (+ dres[xmap(r)] if given), and fp32-atomic sums
+ * dscale/dshift (tables like scale/shift), dgamma/dbeta [D] (any may be NULL when the forward had none). */
+int orv_layernorm_modulate_bwd(const void* dy, const void* x, orv_rowmap_t xmap, const void* dres, void* dx,
+                               const void* gamma, const void* beta, const float* scale, float* dscale, float* dshift,
+                               float* dgamma, float* dbeta, long mod_b, long mod_g, orv_groups_t grp, int batch, int D,
+                               float eps, void* stream);
+/* Small-row (R <= 4096) linear adjoint for the conditioning MLPs / AdaLN linears: dW[N,K] (+)= dy^T x (bf16),
+ * db[N] (+)= colsum(dy) (fp32), dx[R,K] += dy W (fp32 atomics).  dy fp32 [R, ldy].  Any of dW/dx may be NULL. */
+int orv_small_linear_bwd(const float* dy, int ldy, const void* x, int ldx, const void* W, void* dW, float* db, float* dx,
+                         int lddx, int R, int N, int K, int accumulate, void* stream);
+/* Fused AdamW step on bf16 params/grads with fp32 moments (torch.optim.AdamW semantics, base_train.yaml:143-153);
+ * `clip_coef` (device scalar or NULL) multiplies the gradient (global-norm clipping, train...sft.py:1095-1100). */
+int orv_adamw(void* p, const void* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+              float weight_decay, int step, const float* clip_coef, void* stream);
+/* out[0] += sum g^2 (gradient-norm reduction, orv/utils.py:166-174). */
+int orv_sumsq(const void* g, long n, float* out, void* stream);
+
+/* src[B*S, ld] columns [col0 + h*64, +64) -> dst[b,h,d,pos(s)] per head (pos = s with bits 2<->3 exchanged, zero for
+ * s >= S): the sequence-contiguous copies (q'^T, k^T, dO^T) the attention backward contracts over. */
+int orv_head_transpose(const void* src, int ld, int col0, void* dst, int B, int S, int H, int s_pad, void* stream);
+/* Adjoint of orv_attention_fwd on the fused path (q pre-multiplied by scale*log2 e in orv_qkv_prep): given out, dout and
+ * the saved lse, writes dqkv[B*S, ld_dqkv] = (dq | dk | dv) w.r.t. the normalised, un-premultiplied q, k and v.
+ * qT/kT/doT: orv_head_transpose of q', k, dout.  neg_lse2/neg_delta: fp32 scratch [B,H,s_pad]. */
+int orv_attention_bwd(const void* qkv, int ld_qkv, const void* qT, const void* kT, const void* out, const void* dout,
+                      int ld_out, const void* doT, const float* lse, float* neg_lse2, float* neg_delta, void* dqkv,
+                      int ld_dqkv, int B, int S, int H, int s_pad, float scale, void* stream);
+/* Adjoint of orv_qkv_prep for the q and k thirds, in place on dqkv: inverse RoPE, LayerNorm(64) backward (qkv_raw = the
+ * QKV GEMM output before orv_qkv_prep); dgq/dbq/dgk/dbk fp32 [64] accumulate the norm_q / norm_k parameter gradients. */
+int orv_qkv_prep_bwd(const void* qkv_raw, void* dqkv, const void* gq, const void* gk, const float* rope_cos,
+                     const float* rope_sin, float* dgq, float* dbq, float* dgk, float* dbk, int B, int S, int H, int n_text,
+                     float eps, void* stream);
 
 /* -- attention -------------------------------------------------------------------------------- */
 /* Non-causal, unmasked softmax(q k^T * scale) v over the joint text+video sequence, head_dim 64

@@ -48,6 +48,23 @@ SIGNATURES = {
     "orv_gemm_bf16": (c_int, [POINTER(Gemm), c_void_p]),
     "orv_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                   c_float, c_void_p]),
+    "orv_transpose_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "orv_colsum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "orv_gated_residual_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, Groups, c_int, c_int,
+                                       c_void_p]),
+    "orv_layernorm_modulate_bwd": (c_int, [c_void_p, c_void_p, RowMap, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, Groups, c_int, c_int,
+                                           c_float, c_void_p]),
+    "orv_small_linear_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                     c_int, c_int, c_int, c_void_p]),
+    "orv_adamw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float, c_float, c_int,
+                          c_void_p, c_void_p]),
+    "orv_sumsq": (c_int, [c_void_p, c_long, c_void_p, c_void_p]),
+    "orv_head_transpose": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "orv_attention_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "orv_qkv_prep_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "orv_sched_step": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                c_float, c_float, c_float, c_float, c_float, c_float, c_long, c_void_p]),
     "orv_gaussian_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),

@@ -1,0 +1,439 @@
+// Attention backward for gfx950 (adjoint of orv_attention_fwd; torch autograd of F.scaled_dot_product_attention at
+// orv/models/cogvideox_control.py:256-258 in the reference's training step).  Two passes, no atomics:
+//   pass A (one lane = one QUERY row, loops over key tiles)  ->  dQ
+//   pass B (one lane = one KEY row,   loops over query tiles) ->  dK, dV
+// Both recompute P = exp2(q'.k - lse2) from the saved log-sum-exp (q' = q * scale * log2 e as stored by orv_qkv_prep),
+// keep the row they own on the lane axis (swapped-operand MFMAs, as in the forward) so that -lse2 and -delta enter through
+// the accumulator init, and feed dS / P back into the next MFMA as its B operand straight from accumulator registers.
+// Operands whose contraction index is the sequence (K^T, Q^T, dO^T) come from per-head transposed copies
+// [B,H,64,s_pad] written by orv_head_transpose in the key order the accumulator layout produces (bits 2<->3 exchanged).
+#include "common.hpp"
+
+namespace {
+
+constexpr int TILE = 8192;  // 64 rows x 128 B
+
+__device__ __forceinline__ int seq_pos(int s) { return (s & ~12) | ((s & 4) << 1) | ((s & 8) >> 1); }
+
+// ---- [B*S, ld] columns [col0 + h*64, +64) -> dst[b, h, d, pos(s)], zero for s >= S ----
+__global__ __launch_bounds__(256) void head_transpose_kernel(const bf16_t* __restrict__ src, long ld, int col0,
+                                                             bf16_t* __restrict__ dst, int S, int H, int s_pad) {
+    __shared__ bf16_t t_s[64][66];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int sub = lane & 7;
+    for (int it = 0; it < 2; ++it) {
+        const int tl = wave * 16 + it * 8 + (lane >> 3);
+        const int s = s0 + tl;
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (s < S) u = *(const uint4*)(src + ((long)b * S + s) * ld + col0 + h * 64 + sub * 8);
+        uint32_t* d = (uint32_t*)&t_s[tl][sub * 8];
+        d[0] = u.x; d[1] = u.y; d[2] = u.z; d[3] = u.w;
+    }
+    __syncthreads();
+    const int d = tid >> 2, grp = tid & 3;
+    bf16_t o[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) o[seq_pos(k)] = t_s[grp * 16 + k][d];
+    bf16_t* out = dst + ((long)(b * H + h) * 64 + d) * s_pad + s0 + grp * 16;
+    uint4 a, c2;
+    a.x = o[0] | ((uint32_t)o[1] << 16); a.y = o[2] | ((uint32_t)o[3] << 16);
+    a.z = o[4] | ((uint32_t)o[5] << 16); a.w = o[6] | ((uint32_t)o[7] << 16);
+    c2.x = o[8] | ((uint32_t)o[9] << 16); c2.y = o[10] | ((uint32_t)o[11] << 16);
+    c2.z = o[12] | ((uint32_t)o[13] << 16); c2.w = o[14] | ((uint32_t)o[15] << 16);
+    *(uint4*)out = a;
+    *(uint4*)(out + 8) = c2;
+}
+
+// ---- neg_delta[b,h,s] = -sum_d dO*O ; neg_lse2[b,h,s] = -lse / ln 2 ; both [B,H,s_pad] fp32, 0 beyond S ----
+__global__ __launch_bounds__(256) void bwd_prep_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, long ld,
+                                                       const float* __restrict__ lse, float* __restrict__ neg_delta,
+                                                       float* __restrict__ neg_lse2, int S, int H, int s_pad, int B) {
+    // one 8-lane group per (row, head)
+    const long gid = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int sub = threadIdx.x & 7;
+    const long total = (long)B * s_pad * H;
+    if (gid >= total) return;
+    const int h = (int)(gid % H);
+    const long rs = gid / H;
+    const int s = (int)(rs % s_pad), b = (int)(rs / s_pad);
+    float acc = 0.f;
+    if (s < S) {
+        const uint4 uo = *(const uint4*)(o + ((long)b * S + s) * ld + h * 64 + sub * 8);
+        const uint4 ud = *(const uint4*)(dout + ((long)b * S + s) * ld + h * 64 + sub * 8);
+        const uint32_t wo[4] = {uo.x, uo.y, uo.z, uo.w}, wd[4] = {ud.x, ud.y, ud.z, ud.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc += bf2f(wo[e] & 0xffff) * bf2f(wd[e] & 0xffff) + bf2f(wo[e] >> 16) * bf2f(wd[e] >> 16);
+    }
+    acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+    if (sub == 0) {
+        const long oi = ((long)b * H + h) * s_pad + s;
+        neg_delta[oi] = -acc;
+        neg_lse2[oi] = s < S ? -lse[((long)b * H + h) * S + s] * 1.4426950408889634f : 0.f;
+    }
+}
+
+struct BwdArgs {
+    const bf16_t* qkv; long ld;      // q' | k | v (after orv_qkv_prep)
+    const bf16_t* qT; const bf16_t* kT; const bf16_t* doT;   // [B,H,64,s_pad]
+    const bf16_t* dout; long ld_do;  // [B*S, H*64]
+    const float* neg_lse2; const float* neg_delta;           // [B,H,s_pad]
+    bf16_t* dqkv; long ld_dqkv;      // [B*S, 3*H*64]: dq | dk | dv
+    int B, S, H, s_pad;
+    float scale;
+};
+
+// ===== pass A: dQ =====
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const BwdArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 3 * TILE];   // per stage: K | V | K^T
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 256 + wave * 32;
+    const int D = p.H * 64;
+    const long row0 = (long)b * p.S;
+    const int qr = min(q0 + l31, p.S - 1);
+    bf16x8 qf[4], dof[4];
+    {
+        const bf16_t* qp = p.qkv + (row0 + qr) * p.ld + h * 64 + hi * 8;
+        const bf16_t* dp = p.dout + (row0 + qr) * p.ld_do + h * 64 + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { qf[ks] = *(const bf16x8*)(qp + ks * 16); dof[ks] = *(const bf16x8*)(dp + ks * 16); }
+    }
+    const long vecq = ((long)b * p.H + h) * p.s_pad + qr;
+    f32x16 c_lse, c_del;
+    {
+        const float nl = p.neg_lse2[vecq], nd = p.neg_delta[vecq];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { c_lse[e] = nl; c_del[e] = nd; }
+    }
+    // staging: wave w moves rows 8w..8w+7 of each of the three tiles
+    const int srow = wave * 8 + (lane >> 3), slot = lane & 7;
+    const int schunk = slot ^ ((srow >> 1) & 7);
+    const bf16_t* kbase = p.qkv + D + h * 64 + schunk * 8;
+    const bf16_t* vbase = p.qkv + 2 * D + h * 64 + schunk * 8;
+    const bf16_t* ktsrc = p.kT + ((long)(b * p.H + h) * 64 + srow) * p.s_pad + schunk * 8;
+    auto stage_load = [&](int s, int kv0) {
+        const int krow = min(kv0 + srow, p.S - 1);
+        glds16(kbase + (row0 + krow) * p.ld, smem + s * 3 * TILE + wave * 1024);
+        glds16(vbase + (row0 + krow) * p.ld, smem + s * 3 * TILE + TILE + wave * 1024);
+        glds16(ktsrc + kv0, smem + s * 3 * TILE + 2 * TILE + wave * 1024);
+    };
+    f32x16 dq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dq[i][e] = 0.f;
+    const int row_off = l31 * 128;
+    const int nt = (p.S + 63) / 64;
+    stage_load(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) stage_load((t + 1) & 1, (t + 1) * 64);
+        const char* sK = smem + (t & 1) * 3 * TILE;
+        const char* sV = sK + TILE;
+        const char* sKT = sK + 2 * TILE;
+        f32x16 sT[2], dP[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const bf16x8 k0 = *(const bf16x8*)(sK + kb * 4096 + row_off + (((0 * 2 + hi) ^ sw) * 16));
+            const bf16x8 v0 = *(const bf16x8*)(sV + kb * 4096 + row_off + (((0 * 2 + hi) ^ sw) * 16));
+            sT[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0], c_lse, 0, 0, 0);
+            dP[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, dof[0], c_del, 0, 0, 0);
+#pragma unroll
+            for (int ks = 1; ks < 4; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(sK + kb * 4096 + row_off + (((ks * 2 + hi) ^ sw) * 16));
+                const bf16x8 vf = *(const bf16x8*)(sV + kb * 4096 + row_off + (((ks * 2 + hi) ^ sw) * 16));
+                sT[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sT[kb], 0, 0, 0);
+                dP[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dP[kb], 0, 0, 0);
+            }
+        }
+        const bool tail = (t == nt - 1) && (p.S & 63) != 0;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pv = __builtin_amdgcn_exp2f(sT[kb][r]);
+                if (tail && t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.S) pv = 0.f;
+                sT[kb][r] = pv * dP[kb][r];      // dS^T = P (dP - delta)
+            }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            union { bf16x8 v; uint32_t u[4]; } ds;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ds.u[i] = pack2bf(sT[kk >> 1][(kk & 1) * 8 + 2 * i], sT[kk >> 1][(kk & 1) * 8 + 2 * i + 1]);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const bf16x8 ktf = *(const bf16x8*)(sKT + db * 4096 + row_off + (((kk * 2 + hi) ^ sw) * 16));
+                dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, ds.v, dq[db], 0, 0, 0);
+            }
+        }
+    }
+    const int q = q0 + l31;
+    if (q < p.S) {
+        bf16_t* op = p.dqkv + (row0 + q) * p.ld_dqkv + h * 64 + hi * 4;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                uint2 o;
+                o.x = pack2bf(dq[db][qd * 4 + 0] * p.scale, dq[db][qd * 4 + 1] * p.scale);
+                o.y = pack2bf(dq[db][qd * 4 + 2] * p.scale, dq[db][qd * 4 + 3] * p.scale);
+                *(uint2*)(op + db * 32 + qd * 8) = o;
+            }
+    }
+}
+
+// ===== pass B: dK, dV =====
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const BwdArgs p) {
+    // per stage: Q' | dO | Q'^T | dO^T (8 KiB each) | neg_lse2[64] | neg_delta[64] (fp32)
+    constexpr int STG = 4 * TILE + 512;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STG];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int k0 = blockIdx.x * 256 + wave * 32;
+    const int D = p.H * 64;
+    const long row0 = (long)b * p.S;
+    const int kr = min(k0 + l31, p.S - 1);
+    bf16x8 kf[4], vf[4];   // B operands: this lane's key row of K and V
+    {
+        const bf16_t* kp = p.qkv + (row0 + kr) * p.ld + D + h * 64 + hi * 8;
+        const bf16_t* vp = p.qkv + (row0 + kr) * p.ld + 2 * D + h * 64 + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { kf[ks] = *(const bf16x8*)(kp + ks * 16); vf[ks] = *(const bf16x8*)(vp + ks * 16); }
+    }
+    const int srow = wave * 8 + (lane >> 3), slot = lane & 7;
+    const int schunk = slot ^ ((srow >> 1) & 7);
+    const bf16_t* qbase = p.qkv + h * 64 + schunk * 8;
+    const bf16_t* dobase = p.dout + h * 64 + schunk * 8;
+    const long hb = (long)(b * p.H + h);
+    const bf16_t* qtsrc = p.qT + (hb * 64 + srow) * p.s_pad + schunk * 8;
+    const bf16_t* dotsrc = p.doT + (hb * 64 + srow) * p.s_pad + schunk * 8;
+    auto stage_load = [&](int s, int q0) {
+        char* base = smem + s * STG;
+        const int qrow = min(q0 + srow, p.S - 1);
+        glds16(qbase + (row0 + qrow) * p.ld, base + wave * 1024);
+        glds16(dobase + (row0 + qrow) * p.ld_do, base + TILE + wave * 1024);
+        glds16(qtsrc + q0, base + 2 * TILE + wave * 1024);
+        glds16(dotsrc + q0, base + 3 * TILE + wave * 1024);
+        if (wave == 0 && lane < 32) {     // 64 + 64 floats = 32 lanes x 16 B
+            const float* src = (lane < 16 ? p.neg_lse2 : p.neg_delta) + hb * p.s_pad + q0 + (lane & 15) * 4;
+            *(float4*)(base + 4 * TILE + lane * 16) = *(const float4*)src;
+        }
+    };
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dk[i][e] = 0.f; dv[i][e] = 0.f; }
+    const int row_off = l31 * 128;
+    const int nt = (p.S + 63) / 64;
+    const bool key_valid = (k0 + l31) < p.S;
+    stage_load(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) stage_load((t + 1) & 1, (t + 1) * 64);
+        const char* sQ = smem + (t & 1) * STG;
+        const char* sDO = sQ + TILE;
+        const char* sQT = sQ + 2 * TILE;
+        const char* sDOT = sQ + 3 * TILE;
+        const float* sL = (const float*)(sQ + 4 * TILE);
+        const float* sDl = sL + 64;
+        f32x16 sS[2], dP[2];   // [q block][reg]: rows = q, cols = this lane's key
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16 cl, cd;     // accumulator init: -lse2[q(r)] / -delta[q(r)], q(r) = qb*32 + (r&3) + 8*(r>>2) + 4*hi
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 a = *(const float4*)(sL + qb * 32 + g * 8 + hi * 4);
+                const float4 d = *(const float4*)(sDl + qb * 32 + g * 8 + hi * 4);
+                cl[g * 4] = a.x; cl[g * 4 + 1] = a.y; cl[g * 4 + 2] = a.z; cl[g * 4 + 3] = a.w;
+                cd[g * 4] = d.x; cd[g * 4 + 1] = d.y; cd[g * 4 + 2] = d.z; cd[g * 4 + 3] = d.w;
+            }
+            const bf16x8 q0f = *(const bf16x8*)(sQ + qb * 4096 + row_off + (((0 * 2 + hi) ^ sw) * 16));
+            const bf16x8 d0f = *(const bf16x8*)(sDO + qb * 4096 + row_off + (((0 * 2 + hi) ^ sw) * 16));
+            sS[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0f, kf[0], cl, 0, 0, 0);
+            dP[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0f, vf[0], cd, 0, 0, 0);
+#pragma unroll
+            for (int ks = 1; ks < 4; ++ks) {
+                const bf16x8 qf_ = *(const bf16x8*)(sQ + qb * 4096 + row_off + (((ks * 2 + hi) ^ sw) * 16));
+                const bf16x8 df_ = *(const bf16x8*)(sDO + qb * 4096 + row_off + (((ks * 2 + hi) ^ sw) * 16));
+                sS[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf_, kf[ks], sS[qb], 0, 0, 0);
+                dP[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df_, vf[ks], dP[qb], 0, 0, 0);
+            }
+        }
+        const bool tail = (t == nt - 1) && (p.S & 63) != 0;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pv = __builtin_amdgcn_exp2f(sS[qb][r]);
+                if (!key_valid || (tail && t * 64 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.S)) pv = 0.f;
+                sS[qb][r] = pv;                 // P
+                dP[qb][r] = pv * dP[qb][r];     // dS
+            }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            union { bf16x8 v; uint32_t u[4]; } pf, ds;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pf.u[i] = pack2bf(sS[kk >> 1][(kk & 1) * 8 + 2 * i], sS[kk >> 1][(kk & 1) * 8 + 2 * i + 1]);
+                ds.u[i] = pack2bf(dP[kk >> 1][(kk & 1) * 8 + 2 * i], dP[kk >> 1][(kk & 1) * 8 + 2 * i + 1]);
+            }
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const bf16x8 dot = *(const bf16x8*)(sDOT + db * 4096 + row_off + (((kk * 2 + hi) ^ sw) * 16));
+                const bf16x8 qt = *(const bf16x8*)(sQT + db * 4096 + row_off + (((kk * 2 + hi) ^ sw) * 16));
+                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pf.v, dv[db], 0, 0, 0);
+                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, ds.v, dk[db], 0, 0, 0);
+            }
+        }
+    }
+    const int key = k0 + l31;
+    if (key < p.S) {
+        // dk = scale * dS_raw^T q = dS_raw^T q' / log2(e)
+        const float ksc = 0.6931471805599453f;
+        bf16_t* okp = p.dqkv + (row0 + key) * p.ld_dqkv + D + h * 64 + hi * 4;
+        bf16_t* ovp = p.dqkv + (row0 + key) * p.ld_dqkv + 2 * D + h * 64 + hi * 4;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                uint2 o;
+                o.x = pack2bf(dk[db][qd * 4 + 0] * ksc, dk[db][qd * 4 + 1] * ksc);
+                o.y = pack2bf(dk[db][qd * 4 + 2] * ksc, dk[db][qd * 4 + 3] * ksc);
+                *(uint2*)(okp + db * 32 + qd * 8) = o;
+                o.x = pack2bf(dv[db][qd * 4 + 0], dv[db][qd * 4 + 1]);
+                o.y = pack2bf(dv[db][qd * 4 + 2], dv[db][qd * 4 + 3]);
+                *(uint2*)(ovp + db * 32 + qd * 8) = o;
+            }
+    }
+}
+
+// ---- adjoint of orv_qkv_prep on the q and k thirds, in place on dqkv (dq, dk arrive as gradients of the normalised,
+//      rotated, un-premultiplied q / k): inverse RoPE rotation, LayerNorm(64) backward; norm_q / norm_k weight gradients.
+__global__ __launch_bounds__(256) void qkv_prep_bwd_kernel(const bf16_t* __restrict__ qkv_raw, bf16_t* __restrict__ dqkv,
+                                                           const bf16_t* __restrict__ gq, const bf16_t* __restrict__ gk,
+                                                           const float* __restrict__ rcos, const float* __restrict__ rsin,
+                                                           float* __restrict__ dgq, float* __restrict__ dbq,
+                                                           float* __restrict__ dgk, float* __restrict__ dbk, int S, int H,
+                                                           int n_text, float eps) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const long ld = 3L * H * 64;
+    const int sub = lane & 7;
+    for (int which = 0; which < 2; ++which) {
+        const bf16_t* g = which ? gk : gq;
+        float gam[8], ag[8], ab[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gam[e] = g ? bf2f(g[sub * 8 + e]) : 1.f; ag[e] = ab[e] = 0.f; }
+        for (int it = 0; it < 2; ++it) {
+            const int s = s0 + wave * 16 + it * 8 + (lane >> 3);
+            const bool ok = s < S;
+            const long off = ((long)b * S + (ok ? s : S - 1)) * ld + which * H * 64 + h * 64 + sub * 8;
+            const uint4 ux = *(const uint4*)(qkv_raw + off);
+            const uint4 ud = *(const uint4*)(dqkv + off);
+            const uint32_t wx[4] = {ux.x, ux.y, ux.z, ux.w}, wd[4] = {ud.x, ud.y, ud.z, ud.w};
+            float x[8], dz[8], sum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x[2 * e] = bf2f(wx[e] & 0xffff); x[2 * e + 1] = bf2f(wx[e] >> 16);
+                dz[2 * e] = ok ? bf2f(wd[e] & 0xffff) : 0.f; dz[2 * e + 1] = ok ? bf2f(wd[e] >> 16) : 0.f;
+                sum += x[2 * e] + x[2 * e + 1];
+            }
+            if (rcos && s >= n_text && ok) {   // inverse rotation (adjoint of pairs (2i,2i+1): x cos + rot(x) sin)
+                const float* cp = rcos + (long)(s - n_text) * 64 + sub * 8;
+                const float* sp = rsin + (long)(s - n_text) * 64 + sub * 8;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const float a = dz[e], c2 = dz[e + 1];
+                    dz[e] = a * cp[e] + c2 * sp[e + 1];
+                    dz[e + 1] = c2 * cp[e + 1] - a * sp[e];
+                }
+            }
+            sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+            const float mean = sum * (1.f / 64.f);
+            float sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { x[e] -= mean; sq += x[e] * x[e]; }
+            sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+            const float rstd = rsqrtf(sq * (1.f / 64.f) + eps);
+            float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                x[e] *= rstd;                     // xh
+                ag[e] += dz[e] * x[e];
+                ab[e] += dz[e];
+                dz[e] *= gam[e];                  // dxh
+                m1 += dz[e];
+                m2 += dz[e] * x[e];
+            }
+            m1 += __shfl_xor(m1, 1, 64); m1 += __shfl_xor(m1, 2, 64); m1 += __shfl_xor(m1, 4, 64);
+            m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64); m2 += __shfl_xor(m2, 4, 64);
+            m1 *= (1.f / 64.f); m2 *= (1.f / 64.f);
+            if (ok) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rstd * (dz[e] - m1 - x[e] * m2);
+                *(uint4*)(dqkv + off) = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+            }
+        }
+        // reduce the weight gradients over the 8 rows of the wave (lanes with equal `sub`), then one atomic per column
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = ag[e], c2 = ab[e];
+            a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            c2 += __shfl_xor(c2, 8, 64); c2 += __shfl_xor(c2, 16, 64); c2 += __shfl_xor(c2, 32, 64);
+            if (lane < 8) {
+                if (which ? dgk != nullptr : dgq != nullptr) atomicAdd((which ? dgk : dgq) + sub * 8 + e, a);
+                if (which ? dbk != nullptr : dbq != nullptr) atomicAdd((which ? dbk : dbq) + sub * 8 + e, c2);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int orv_head_transpose(const void* src, int ld, int col0, void* dst, int B, int S, int H, int s_pad, void* stream) {
+    ORV_REQUIRE(src && dst && B > 0 && S > 0 && H > 0, "orv_head_transpose: bad arguments");
+    ORV_REQUIRE(s_pad == ((S + 63) / 64) * 64 && ld % 8 == 0 && col0 % 8 == 0, "orv_head_transpose: bad s_pad/ld");
+    hipLaunchKernelGGL(head_transpose_kernel, dim3(s_pad / 64, H, B), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, (long)ld, col0, (bf16_t*)dst, S, H, s_pad);
+    return orv_check_launch("orv_head_transpose");
+}
+
+extern "C" int orv_attention_bwd(const void* qkv, int ld_qkv, const void* qT, const void* kT, const void* out,
+                                 const void* dout, int ld_out, const void* doT, const float* lse, float* neg_lse2,
+                                 float* neg_delta, void* dqkv, int ld_dqkv, int B, int S, int H, int s_pad, float scale,
+                                 void* stream) {
+    ORV_REQUIRE(qkv && qT && kT && out && dout && doT && lse && neg_lse2 && neg_delta && dqkv, "orv_attention_bwd: null operand");
+    ORV_REQUIRE(s_pad == ((S + 63) / 64) * 64, "orv_attention_bwd: s_pad must be S rounded up to 64");
+    hipStream_t st = (hipStream_t)stream;
+    const long groups = (long)B * s_pad * H;
+    hipLaunchKernelGGL(bwd_prep_kernel, dim3((unsigned)((groups * 8 + 255) / 256)), dim3(256), 0, st, (const bf16_t*)out,
+                       (const bf16_t*)dout, (long)ld_out, lse, neg_delta, neg_lse2, S, H, s_pad, B);
+    BwdArgs a;
+    a.qkv = (const bf16_t*)qkv; a.ld = ld_qkv; a.qT = (const bf16_t*)qT; a.kT = (const bf16_t*)kT; a.doT = (const bf16_t*)doT;
+    a.dout = (const bf16_t*)dout; a.ld_do = ld_out; a.neg_lse2 = neg_lse2; a.neg_delta = neg_delta;
+    a.dqkv = (bf16_t*)dqkv; a.ld_dqkv = ld_dqkv; a.B = B; a.S = S; a.H = H; a.s_pad = s_pad; a.scale = scale;
+    dim3 grid((S + 255) / 256, H, B);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(512), 0, st, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(512), 0, st, a);
+    return orv_check_launch("orv_attention_bwd");
+}
+
+extern "C" int orv_qkv_prep_bwd(const void* qkv_raw, void* dqkv, const void* gq, const void* gk, const float* rope_cos,
+                                const float* rope_sin, float* dgq, float* dbq, float* dgk, float* dbk, int B, int S, int H,
+                                int n_text, float eps, void* stream) {
+    ORV_REQUIRE(qkv_raw && dqkv && B > 0 && S > 0 && H > 0, "orv_qkv_prep_bwd: bad arguments");
+    ORV_REQUIRE((rope_cos == nullptr) == (rope_sin == nullptr), "orv_qkv_prep_bwd: cos and sin go together");
+    hipLaunchKernelGGL(qkv_prep_bwd_kernel, dim3((S + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)qkv_raw, (bf16_t*)dqkv, (const bf16_t*)gq, (const bf16_t*)gk, rope_cos, rope_sin, dgq,
+                       dbq, dgk, dbk, S, H, n_text, eps);
+    return orv_check_launch("orv_qkv_prep_bwd");
+}

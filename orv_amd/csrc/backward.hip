@@ -1,0 +1,420 @@
+// Backward (training) kernels that are HBM-bound: transposes feeding the dgrad/wgrad GEMMs, LayerNorm-modulate backward,
+// gated-residual backward, bias/column sums, small-row weight/data gradients of the conditioning MLPs, fused AdamW.
+// Gradients of the reference flow through torch autograd over the same ops (train_cogvideox_control_to_video_sft.py:1093);
+// here every op of the forward path (cogvideox_control.py:394-445, :60-150) has its hand-written adjoint.
+#include "common.hpp"
+
+namespace {
+
+// ---- dst[c, r] = src[r, c] for a [R, C] bf16 matrix (row stride lds), dst row stride ldd >= R; columns r in [R, ldd) of dst
+//      are zero-filled (K padding for the wgrad GEMM).  64x64 tiles through LDS, 16-byte global accesses both ways.
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ src, long lds_, bf16_t* __restrict__ dst,
+                                                        long ldd, int R, int C) {
+    __shared__ bf16_t tile[64][72];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    // load 64 rows x 64 cols: thread -> (row = tid/8 + 32*it, 8-col chunk = tid%8)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int r = (tid >> 3) + 32 * it, ch = tid & 7;
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (r0 + r < R && c0 + ch * 8 < C) u = *(const uint4*)(src + (long)(r0 + r) * lds_ + c0 + ch * 8);
+        *(uint4*)&tile[r][ch * 8] = u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = (tid >> 3) + 32 * it, ch = tid & 7;   // output row c (source column), 8 source rows per chunk
+        if (c0 + c >= C) continue;
+        bf16_t o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = tile[ch * 8 + e][c];
+        uint4 u;
+        u.x = o[0] | ((uint32_t)o[1] << 16); u.y = o[2] | ((uint32_t)o[3] << 16);
+        u.z = o[4] | ((uint32_t)o[5] << 16); u.w = o[6] | ((uint32_t)o[7] << 16);
+        if (r0 + ch * 8 < ldd) *(uint4*)(dst + (long)(c0 + c) * ldd + r0 + ch * 8) = u;   // rows >= R were loaded as zeros
+    }
+}
+
+// ---- out[c] (+)= sum_r src[r, c]  (bias gradients).  One block = 64 columns x a slab of rows; fp32 atomics across slabs.
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ src, long ld, float* __restrict__ out, int R,
+                                                     int C, int rows_per_block) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    const int rb = blockIdx.y * rows_per_block, re = min(R, rb + rows_per_block);
+    float s = 0.f;
+    if (c < C)
+        for (int r = rb + w; r < re; r += 4) s += bf2f(src[(long)r * ld + c]);
+    red[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < C) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ---- gated residual backward (cogvideox_control.py:419-421,442-443):  out = x + gate[b,g] * y
+//      dy = gate * dout (bf16);  dgate[b,g,:] += sum_{rows of group} dout * y.  One wave walks RPW consecutive rows and keeps
+//      the gate-gradient partial sums in registers until the group changes (rows of a group are contiguous).
+template <int CH>
+__global__ __launch_bounds__(256) void gated_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ y,
+                                                        const float* __restrict__ gate, float* __restrict__ dgate,
+                                                        bf16_t* __restrict__ dy, long mod_b, long mod_g, int seq, int n_text,
+                                                        int per_group, int rows, int D, int rpw) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nchunk = D >> 3;
+    const int r0 = wid * rpw, r1 = min(rows, r0 + rpw);
+    if (r0 >= rows) return;
+    float acc[CH][8];
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+    long cur_off = -1;
+    for (int row = r0; row < r1; ++row) {
+        const int b = row / seq, s = row % seq;
+        const long off = b * mod_b + orv_group_of(s, n_text, per_group) * mod_g;
+        if (off != cur_off) {
+            if (cur_off >= 0) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const int c = lane + 64 * i;
+                    if (c < nchunk)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { atomicAdd(dgate + cur_off + c * 8 + e, acc[i][e]); acc[i][e] = 0.f; }
+                }
+            }
+            cur_off = off;
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = lane + 64 * i;
+            if (c >= nchunk) continue;
+            const uint4 ud = *(const uint4*)(dout + (long)row * D + c * 8);
+            const uint4 uy = *(const uint4*)(y + (long)row * D + c * 8);
+            const float4 g0 = *(const float4*)(gate + off + c * 8), g1 = *(const float4*)(gate + off + c * 8 + 4);
+            const uint32_t wd[4] = {ud.x, ud.y, ud.z, ud.w}, wy[4] = {uy.x, uy.y, uy.z, uy.w};
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d0 = bf2f(wd[e] & 0xffff), d1 = bf2f(wd[e] >> 16);
+                acc[i][2 * e] += d0 * bf2f(wy[e] & 0xffff);
+                acc[i][2 * e + 1] += d1 * bf2f(wy[e] >> 16);
+                o[e] = pack2bf(d0 * gg[2 * e], d1 * gg[2 * e + 1]);
+            }
+            *(uint4*)(dy + (long)row * D + c * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(dgate + cur_off + c * 8 + e, acc[i][e]);
+    }
+}
+
+// ---- LayerNorm-modulate backward.  Forward: xh = (x - mu) rstd ; z = xh*gamma + beta ; y = z*(1+sc) + sh.
+//      Given dy: dsh += dy ; dsc += dy*z ; dz = dy*(1+sc) ; dbeta += dz ; dgamma += dz*xh ;
+//      dxh = dz*gamma ; dx = rstd*(dxh - mean(dxh) - xh*mean(dxh*xh)) ; dx_out = dx (+ dres).
+//      One wave walks RPW consecutive rows; per-column sums stay in registers (dsc/dsh until the group changes).
+template <int CH>
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                         const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
+                                                         const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
+                                                         const float* __restrict__ scale, float* __restrict__ dscale,
+                                                         float* __restrict__ dshift, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, long mod_b, long mod_g, int seq,
+                                                         int n_text, int per_group, int rows, int D, float eps, int rpw,
+                                                         orv_rowmap_t xmap) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nchunk = D >> 3;
+    const int r0 = wid * rpw, r1 = min(rows, r0 + rpw);
+    if (r0 >= rows) return;
+    float gam[CH][8], bet[CH][8], a_sc[CH][8], a_sh[CH][8], a_g[CH][8], a_b[CH][8];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = lane + 64 * i;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            gam[i][e] = (gamma && c < nchunk) ? bf2f(gamma[c * 8 + e]) : 1.f;
+            bet[i][e] = (beta && c < nchunk) ? bf2f(beta[c * 8 + e]) : 0.f;
+            a_sc[i][e] = a_sh[i][e] = a_g[i][e] = a_b[i][e] = 0.f;
+        }
+    }
+    long cur_off = -1;
+    for (int row = r0; row < r1; ++row) {
+        long off = 0;
+        if (scale) {
+            const int b = row / seq, s = row % seq;
+            off = b * mod_b + orv_group_of(s, n_text, per_group) * mod_g;
+            if (off != cur_off) {
+                if (cur_off >= 0) {
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) {
+                        const int c = lane + 64 * i;
+                        if (c < nchunk)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                atomicAdd(dscale + cur_off + c * 8 + e, a_sc[i][e]);
+                                atomicAdd(dshift + cur_off + c * 8 + e, a_sh[i][e]);
+                                a_sc[i][e] = a_sh[i][e] = 0.f;
+                            }
+                    }
+                }
+                cur_off = off;
+            }
+        }
+        const long xrow = xmap.rows > 0 ? (long)(row / xmap.rows) * xmap.bstride + xmap.off + row % xmap.rows : row;
+        float xv[CH][8], dv[CH][8];
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                const uint4 ux = *(const uint4*)(x + xrow * D + c * 8);
+                const uint4 ud = *(const uint4*)(dy + (long)row * D + c * 8);
+                const uint32_t wx[4] = {ux.x, ux.y, ux.z, ux.w}, wd[4] = {ud.x, ud.y, ud.z, ud.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xv[i][2 * e] = bf2f(wx[e] & 0xffff); xv[i][2 * e + 1] = bf2f(wx[e] >> 16);
+                    dv[i][2 * e] = bf2f(wd[e] & 0xffff); dv[i][2 * e + 1] = bf2f(wd[e] >> 16);
+                    s1 += xv[i][2 * e] + xv[i][2 * e + 1];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[i][e] = dv[i][e] = 0.f;
+            }
+        }
+        const float mean = wave_sum(s1) / (float)D;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (lane + 64 * i < nchunk)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = xv[i][e] - mean; sq += d * d; }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = lane + 64 * i;
+            if (c >= nchunk) continue;
+            float sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (scale) {
+                const float4 s0 = *(const float4*)(scale + off + c * 8), s4 = *(const float4*)(scale + off + c * 8 + 4);
+                sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s4.x; sc[5] = s4.y; sc[6] = s4.z; sc[7] = s4.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = (xv[i][e] - mean) * rstd;
+                const float z = xh * gam[i][e] + bet[i][e];
+                const float d = dv[i][e];
+                a_sh[i][e] += d;
+                a_sc[i][e] += d * z;
+                const float dz = d * (1.f + sc[e]);
+                a_b[i][e] += dz;
+                a_g[i][e] += dz * xh;
+                const float dxh = dz * gam[i][e];
+                xv[i][e] = xh;       // keep xh
+                dv[i][e] = dxh;      // keep dxh
+                m1 += dxh;
+                m2 += dxh * xh;
+            }
+        }
+        m1 = wave_sum(m1) / (float)D;
+        m2 = wave_sum(m2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = lane + 64 * i;
+            if (c >= nchunk) continue;
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rstd * (dv[i][e] - m1 - xv[i][e] * m2);
+            if (dres) {
+                const uint4 ur = *(const uint4*)(dres + xrow * D + c * 8);
+                const uint32_t wr[4] = {ur.x, ur.y, ur.z, ur.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[2 * e] += bf2f(wr[e] & 0xffff); o[2 * e + 1] += bf2f(wr[e] >> 16); }
+            }
+            *(uint4*)(dx + xrow * D + c * 8) = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = lane + 64 * i;
+        if (c >= nchunk) continue;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (scale) { atomicAdd(dscale + cur_off + c * 8 + e, a_sc[i][e]); atomicAdd(dshift + cur_off + c * 8 + e, a_sh[i][e]); }
+            if (dgamma) atomicAdd(dgamma + c * 8 + e, a_g[i][e]);
+            if (dbeta) atomicAdd(dbeta + c * 8 + e, a_b[i][e]);
+        }
+    }
+}
+
+// ---- small-row linear backward (rows <= 64; the conditioning MLPs and AdaLN linears):
+//      dW[n, k] (+)= sum_r dy[r, n] * x[r, k]      (fp32 dy, bf16 x -> bf16 dW accumulate)
+__global__ void small_wgrad_kernel(const float* __restrict__ dy, long ldy, const bf16_t* __restrict__ x, long ldx_,
+                                   bf16_t* __restrict__ dW, float* __restrict__ db, int R, int N, int K, int accumulate) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * K) return;
+    const int n = (int)(i / K), k = (int)(i % K);
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += dy[(long)r * ldy + n] * bf2f(x[(long)r * ldx_ + k]);
+    if (accumulate) s += bf2f(dW[i]);
+    dW[i] = f2bf(s);
+    if (db && k == 0) {
+        float t = 0.f;
+        for (int r = 0; r < R; ++r) t += dy[(long)r * ldy + n];
+        if (accumulate) t += db[n];
+        db[n] = t;
+    }
+}
+//      dx[r, k] += sum_n dy[r, n] * W[n, k]   (fp32 atomics; block = 256 columns n-slab x all rows)
+__global__ __launch_bounds__(256) void small_dgrad_kernel(const float* __restrict__ dy, long ldy, const bf16_t* __restrict__ W,
+                                                          float* __restrict__ dx, long lddx, int R, int N, int K, int nslab) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int n0 = blockIdx.y * nslab, n1 = min(N, n0 + nslab);
+    if (k >= K) return;
+    for (int r0 = 0; r0 < R; r0 += 8) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int n = n0; n < n1; ++n) {
+            const float w = bf2f(W[(long)n * K + k]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (r0 + j < R) acc[j] = fmaf(dy[(long)(r0 + j) * ldy + n], w, acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (r0 + j < R) atomicAdd(dx + (long)(r0 + j) * lddx + k, acc[j]);
+    }
+}
+
+// ---- fused AdamW on bf16 parameters / bf16 gradients with fp32 moments (torch.optim.AdamW semantics, decoupled decay):
+//      g *= clip ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p = p (1 - lr wd) - lr (m / bc1) / (sqrt(v / bc2) + eps)
+__global__ void adamw_kernel(bf16_t* __restrict__ p, const bf16_t* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
+                             const float* __restrict__ clip) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float c = clip ? *clip : 1.f;
+    const float gr = bf2f(g[i]) * c;
+    const float mm = b1 * m[i] + (1.f - b1) * gr;
+    const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
+    m[i] = mm; v[i] = vv;
+    float pv = bf2f(p[i]);
+    pv = pv * (1.f - lr * wd) - lr * (mm / bc1) / (sqrtf(vv / bc2) + eps);
+    p[i] = f2bf(pv);
+}
+
+// ---- out[0] += sum g^2 (global gradient norm)
+__global__ __launch_bounds__(256) void sumsq_kernel(const bf16_t* __restrict__ g, long n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (long)gridDim.x * 256 * 8) {
+        if (i + 8 <= n) {
+            const uint4 u = *(const uint4*)(g + i);
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float a = bf2f(w[e] & 0xffff), b = bf2f(w[e] >> 16); s += a * a + b * b; }
+        } else {
+            for (long j = i; j < n; ++j) { const float a = bf2f(g[j]); s += a * a; }
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+}  // namespace
+
+extern "C" int orv_transpose_bf16(const void* src, int ld_src, void* dst, int ld_dst, int R, int C, void* stream) {
+    ORV_REQUIRE(src && dst && R > 0 && C > 0, "orv_transpose_bf16: bad arguments");
+    ORV_REQUIRE(ld_src % 8 == 0 && ld_dst % 8 == 0 && ld_dst >= R && C % 8 == 0, "orv_transpose_bf16: misaligned");
+    dim3 grid((ld_dst + 63) / 64, (C + 63) / 64);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (long)ld_src,
+                       (bf16_t*)dst, (long)ld_dst, R, C);
+    return orv_check_launch("orv_transpose_bf16");
+}
+
+extern "C" int orv_colsum(const void* src, int ld, float* out, int R, int C, void* stream) {
+    ORV_REQUIRE(src && out && R > 0 && C > 0, "orv_colsum: bad arguments");
+    const int rpb = 512;
+    dim3 grid((C + 63) / 64, (R + rpb - 1) / rpb);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (long)ld, out, R, C, rpb);
+    return orv_check_launch("orv_colsum");
+}
+
+extern "C" int orv_gated_residual_bwd(const void* dout, const void* y, const float* gate, float* dgate, void* dy,
+                                      long mod_b, long mod_g, orv_groups_t grp, int batch, int D, void* stream) {
+    ORV_REQUIRE(dout && y && gate && dgate && dy, "orv_gated_residual_bwd: null operand");
+    ORV_REQUIRE(D % 8 == 0 && D <= 4096, "orv_gated_residual_bwd: D=%d unsupported", D);
+    const int rows = batch * grp.seq, rpw = 8;
+    const int waves = (rows + rpw - 1) / rpw;
+    dim3 grid((waves + 3) / 4);
+    const int ch = (D / 8 + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+#define ORV_CASE(C)                                                                                                    \
+    hipLaunchKernelGGL(gated_bwd_kernel<C>, grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)y, gate, dgate, \
+                       (bf16_t*)dy, mod_b, mod_g, grp.seq, grp.n_text, grp.per_group, rows, D, rpw)
+    if (ch <= 1) ORV_CASE(1); else if (ch <= 2) ORV_CASE(2); else if (ch <= 4) ORV_CASE(4); else if (ch <= 6) ORV_CASE(6); else ORV_CASE(8);
+#undef ORV_CASE
+    return orv_check_launch("orv_gated_residual_bwd");
+}
+
+extern "C" int orv_layernorm_modulate_bwd(const void* dy, const void* x, orv_rowmap_t xmap, const void* dres, void* dx,
+                                          const void* gamma, const void* beta, const float* scale, float* dscale,
+                                          float* dshift, float* dgamma, float* dbeta, long mod_b, long mod_g,
+                                          orv_groups_t grp, int batch, int D, float eps, void* stream) {
+    ORV_REQUIRE(dy && x && dx, "orv_layernorm_modulate_bwd: null operand");
+    ORV_REQUIRE(D % 8 == 0 && D <= 4096, "orv_layernorm_modulate_bwd: D=%d unsupported", D);
+    ORV_REQUIRE(!scale || (dscale && dshift), "orv_layernorm_modulate_bwd: dscale/dshift required with scale");
+    const int rows = batch * grp.seq, rpw = 8;
+    const int waves = (rows + rpw - 1) / rpw;
+    dim3 grid((waves + 3) / 4);
+    const int ch = (D / 8 + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+#define ORV_CASE(C)                                                                                                     \
+    hipLaunchKernelGGL(ln_mod_bwd_kernel<C>, grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x,               \
+                       (const bf16_t*)dres, (bf16_t*)dx, (const bf16_t*)gamma, (const bf16_t*)beta, scale, dscale, dshift, \
+                       dgamma, dbeta, mod_b, mod_g, grp.seq, grp.n_text, grp.per_group, rows, D, eps, rpw, xmap)
+    if (ch <= 1) ORV_CASE(1); else if (ch <= 2) ORV_CASE(2); else if (ch <= 4) ORV_CASE(4); else ORV_CASE(6);
+#undef ORV_CASE
+    return orv_check_launch("orv_layernorm_modulate_bwd");
+}
+
+extern "C" int orv_small_linear_bwd(const float* dy, int ldy, const void* x, int ldx, const void* W, void* dW, float* db,
+                                    float* dx, int lddx, int R, int N, int K, int accumulate, void* stream) {
+    ORV_REQUIRE(dy && R > 0 && R <= 4096 && N > 0 && K > 0, "orv_small_linear_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (dW) {
+        ORV_REQUIRE(x, "orv_small_linear_bwd: x required for dW");
+        const long total = (long)N * K;
+        hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, (long)ldy,
+                           (const bf16_t*)x, (long)ldx, (bf16_t*)dW, db, R, N, K, accumulate);
+    }
+    if (dx) {
+        ORV_REQUIRE(W, "orv_small_linear_bwd: W required for dx");
+        const int nslab = 256;
+        dim3 grid((K + 255) / 256, (N + nslab - 1) / nslab);
+        hipLaunchKernelGGL(small_dgrad_kernel, grid, dim3(256), 0, st, dy, (long)ldy, (const bf16_t*)W, dx, (long)lddx, R, N, K, nslab);
+    }
+    return orv_check_launch("orv_small_linear_bwd");
+}
+
+extern "C" int orv_adamw(void* p, const void* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, int step, const float* clip_coef, void* stream) {
+    ORV_REQUIRE(p && g && m && v && n > 0 && step > 0, "orv_adamw: bad arguments");
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)p,
+                       (const bf16_t*)g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, clip_coef);
+    return orv_check_launch("orv_adamw");
+}
+
+extern "C" int orv_sumsq(const void* g, long n, float* out, void* stream) {
+    ORV_REQUIRE(g && out && n > 0, "orv_sumsq: bad arguments");
+    const int blocks = (int)min((long)2048, (n + 2047) / 2048);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, n, out);
+    return orv_check_launch("orv_sumsq");
+}

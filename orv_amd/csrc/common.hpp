@@ -48,6 +48,14 @@ __device__ __forceinline__ float gelu_tanh(float x) {
     const float e = __builtin_amdgcn_exp2f(u2);
     return x - x * __builtin_amdgcn_rcpf(1.0f + e);
 }
+// d/dx of gelu_tanh
+__device__ __forceinline__ float gelu_tanh_grad(float x) {
+    const float a = 0.7978845608028654f, b = 0.044715f;
+    const float x2 = x * x;
+    const float e = __builtin_amdgcn_exp2f((2.0f * a * 1.4426950408889634f) * (x + b * x * x2));
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);        // tanh(a (x + b x^3))
+    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * a * (1.0f + 3.0f * b * x2);
+}
 __device__ __forceinline__ float silu(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }

@@ -62,7 +62,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[N
         bf16_t* crow = p.C + orow * p.ldc;
         const bf16_t* rrow = nullptr;
         const float* grow = nullptr;
-        if (EPI == 2) {
+        if (EPI == 2 || EPI == 3) {
             const long rr = p.r_mod > 0 ? m % p.r_mod : orow;
             rrow = p.R + rr * p.ldr;
             if (p.gate) {
@@ -93,6 +93,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[N
                     if (grow) { const float4 gg = *(const float4*)(grow + n); g[0] = gg.x; g[1] = gg.y; g[2] = gg.z; g[3] = gg.w; }
                     v[0] = bf2f(rr.x & 0xffff) + g[0] * v[0]; v[1] = bf2f(rr.x >> 16) + g[1] * v[1];
                     v[2] = bf2f(rr.y & 0xffff) + g[2] * v[2]; v[3] = bf2f(rr.y >> 16) + g[3] * v[3];
+                }
+                if (EPI == 3) {   // backward through GELU(tanh): C = acc * gelu'(U), U = saved pre-activation
+                    const uint2 uu = *(const uint2*)(rrow + n);
+                    v[0] *= gelu_tanh_grad(bf2f(uu.x & 0xffff)); v[1] *= gelu_tanh_grad(bf2f(uu.x >> 16));
+                    v[2] *= gelu_tanh_grad(bf2f(uu.y & 0xffff)); v[3] *= gelu_tanh_grad(bf2f(uu.y >> 16));
                 }
                 uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
                 *(uint2*)(crow + n) = o;
@@ -435,6 +440,7 @@ int launch_pp(const GemmArgs& a, int epi, hipStream_t st) {
         ORV_GEMM_CASE(0)
         ORV_GEMM_CASE(1)
         ORV_GEMM_CASE(2)
+        ORV_GEMM_CASE(3)
         default: orv_set_error("orv_gemm_bf16: bad epilogue %d", epi); return ORV_EINVAL;
     }
 #undef ORV_GEMM_CASE
@@ -460,6 +466,7 @@ int launch(const GemmArgs& a, int epi, hipStream_t st) {
         ORV_GEMM_CASE(0)
         ORV_GEMM_CASE(1)
         ORV_GEMM_CASE(2)
+        ORV_GEMM_CASE(3)
         default: orv_set_error("orv_gemm_bf16: bad epilogue %d", epi); return ORV_EINVAL;
     }
 #undef ORV_GEMM_CASE
@@ -476,7 +483,7 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
     ORV_REQUIRE(g->K % 64 == 0, "orv_gemm_bf16: K=%d must be a multiple of 64", g->K);
     ORV_REQUIRE(g->N % 64 == 0, "orv_gemm_bf16: N=%d must be a multiple of 64", g->N);
     ORV_REQUIRE(g->lda % 8 == 0 && g->ldw % 8 == 0 && g->ldc % 4 == 0, "orv_gemm_bf16: misaligned leading dimension");
-    ORV_REQUIRE(g->epilogue != 2 || g->R, "orv_gemm_bf16: epilogue 2 needs R");
+    ORV_REQUIRE((g->epilogue != 2 && g->epilogue != 3) || g->R, "orv_gemm_bf16: epilogue 2/3 needs R");
     ORV_REQUIRE(g->epilogue != 2 || !g->gate || g->grp.seq > 0, "orv_gemm_bf16: gate needs grp.seq");
     GemmArgs a;
     a.A = (const bf16_t*)g->A; a.lda = g->lda; a.W = (const bf16_t*)g->W; a.ldw = g->ldw;

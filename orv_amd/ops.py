@@ -210,3 +210,70 @@ def gaussian_sample(moments, eps, scale):
     check(lib().orv_gaussian_sample(_p(moments), _p(eps), _p(out), B, C2 // 2, F, H * W, float(scale), _stream()),
           "orv_gaussian_sample")
     return out
+
+
+# ---- backward (training) ----------------------------------------------------------------------------------------------
+def transpose(src, R, C, ld_dst=None, out=None, ld_src=None):
+    """[R, C] bf16 -> [C, ld_dst] (ld_dst = R rounded up to 64, zero padded): K-contiguous operand for dgrad/wgrad."""
+    _need(src, BF16, "src")
+    ld_dst = ld_dst or (R + 63) // 64 * 64
+    if out is None:
+        out = torch.empty(C, ld_dst, dtype=BF16, device=src.device)
+    check(lib().orv_transpose_bf16(_p(src), ld_src or C, _p(out), ld_dst, R, C, _stream()), "orv_transpose_bf16")
+    return out
+
+
+def colsum(src, out, R, C, ld=None):
+    _need(src, BF16, "src"), _need(out, torch.float32, "out")
+    check(lib().orv_colsum(_p(src), ld or C, _p(out), R, C, _stream()), "orv_colsum")
+    return out
+
+
+def gated_residual_bwd(dout, y, gate, dgate, dy, mod_b, mod_g, grp, batch, D):
+    check(lib().orv_gated_residual_bwd(_p(dout), _p(y), _p(gate), _p(dgate), _p(dy), mod_b, mod_g, grp, batch, D, _stream()),
+          "orv_gated_residual_bwd")
+    return dy
+
+
+def layernorm_modulate_bwd(dy, x, dres, dx, gamma, beta, scale, dscale, dshift, dgamma, dbeta, mod_b, mod_g, grp, batch, D,
+                           eps, xmap: Optional[RowMap] = None):
+    check(lib().orv_layernorm_modulate_bwd(_p(dy), _p(x), xmap or RowMap(0, 0, 0), _p(dres), _p(dx), _p(gamma), _p(beta),
+                                           _p(scale), _p(dscale), _p(dshift), _p(dgamma), _p(dbeta), mod_b, mod_g, grp, batch,
+                                           D, float(eps), _stream()), "orv_layernorm_modulate_bwd")
+    return dx
+
+
+def small_linear_bwd(dy, x, W, dW, db, dx, R, N, K, accumulate=True, ldy=None, ldx=None, lddx=None):
+    _need(dy, torch.float32, "dy")
+    check(lib().orv_small_linear_bwd(_p(dy), ldy or N, _p(x), ldx or K, _p(W), _p(dW), _p(db), _p(dx), lddx or K, R, N, K,
+                                     int(accumulate), _stream()), "orv_small_linear_bwd")
+
+
+def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, clip_coef=None):
+    check(lib().orv_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                          float(weight_decay), int(step), _p(clip_coef), _stream()), "orv_adamw")
+
+
+def sumsq(g, out):
+    check(lib().orv_sumsq(_p(g), g.numel(), _p(out), _stream()), "orv_sumsq")
+
+
+def head_transpose(src, col0, dst, B, S, H, s_pad, ld=None):
+    check(lib().orv_head_transpose(_p(src), ld or src.shape[-1], col0, _p(dst), B, S, H, s_pad, _stream()),
+          "orv_head_transpose")
+    return dst
+
+
+def attention_bwd(qkv, qT, kT, out, dout, doT, lse, neg_lse2, neg_delta, dqkv, B, S, H, s_pad, scale):
+    check(lib().orv_attention_bwd(_p(qkv), 3 * H * 64, _p(qT), _p(kT), _p(out), _p(dout), H * 64, _p(doT), _p(lse),
+                                  _p(neg_lse2), _p(neg_delta), _p(dqkv), 3 * H * 64, B, S, H, s_pad, float(scale), _stream()),
+          "orv_attention_bwd")
+    return dqkv
+
+
+def qkv_prep_bwd(qkv_raw, dqkv, gq, gk, rope, dgq, dbq, dgk, dbk, B, S, H, n_text, eps):
+    cos = sin = None
+    if rope is not None:
+        cos, sin = rope
+    check(lib().orv_qkv_prep_bwd(_p(qkv_raw), _p(dqkv), _p(gq), _p(gk), _p(cos), _p(sin), _p(dgq), _p(dbq), _p(dgk), _p(dbk),
+                                 B, S, H, n_text, float(eps), _stream()), "orv_qkv_prep_bwd")
