@@ -136,6 +136,7 @@ typedef struct {
     const void* R; int ldr; int r_mod;
     const float* gate; long gate_b, gate_g; orv_groups_t grp;
     orv_rowmap_t cmap;
+    void* Y; int ldy;   /* optional: also store acc + bias (before GELU / gate) at the same rows - saved for backward */
 } orv_gemm_t;
 int orv_gemm_bf16(const orv_gemm_t* g, void* stream);
 

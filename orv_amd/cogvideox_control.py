@@ -456,7 +456,6 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             x2d, W = torch.nn.functional.pad(x2d, (0, pad)), torch.nn.functional.pad(W, (0, pad))
         return x2d.contiguous(), W.contiguous()
 
-    @torch.no_grad()
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor,
                 controls_or_guidances: Dict[str, torch.Tensor], timestep: Union[int, float, torch.LongTensor],
                 timestep_cond: Optional[torch.Tensor] = None, ofs: Optional[Union[int, float, torch.LongTensor]] = None,
@@ -470,8 +469,22 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             raise RuntimeError(f"orv_amd kernels are bf16: call model.to(torch.bfloat16) (got {self.dtype})")
         if c.multiview or num_views > 1:
             raise NotImplementedError("multiview (MVBlock, :273-348) is a SURVEY §8(f) 'next' row, not built yet")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            pass  # inference kernels only in this round; gradients are not recorded (see DESIGN.md "next")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training step (train_cogvideox_control_to_video_sft.py:1051-1093): forward that saves activations, with the
+            # hand-written backward attached to autograd as one node
+            from .training import forward_with_grad
+            out, mask, recon = forward_with_grad(self, hidden_states, encoder_hidden_states, controls_or_guidances, timestep,
+                                                 ofs, image_rotary_emb)
+            if not return_dict:
+                return (out, mask, recon)
+            return Transformer3DModelTrajOutput(sample=out, is_action_mask=mask, actions_recon=recon)
+        with torch.no_grad():
+            return self._forward_inference(hidden_states, encoder_hidden_states, controls_or_guidances, timestep, ofs,
+                                           image_rotary_emb, return_dict)
+
+    def _forward_inference(self, hidden_states, encoder_hidden_states, controls_or_guidances, timestep, ofs,
+                           image_rotary_emb, return_dict):
+        c = self.config
         dev = hidden_states.device
         B, T, C, Hh, Ww = hidden_states.shape
         p, pt = c.patch_size, c.patch_size_t

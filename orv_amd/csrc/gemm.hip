@@ -41,6 +41,7 @@ struct GemmArgs {
     const float* gate; long gate_b, gate_g;
     int seq, n_text, per_group;
     int c_rows, c_bstride, c_off;
+    bf16_t* Y; long ldy;   // optional second output: the pre-epilogue value acc + bias (saved for backward)
     int tiles_m, tiles_n;
     int dbg;  // ORV_GEMM_DBG: 1 = skip main-loop loads, 2 = skip MFMAs (ablation only)
 };
@@ -60,6 +61,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[N
         long orow = m;
         if (p.c_rows > 0) orow = (long)(m / p.c_rows) * p.c_bstride + p.c_off + m % p.c_rows;
         bf16_t* crow = p.C + orow * p.ldc;
+        bf16_t* yrow = p.Y ? p.Y + orow * p.ldy : nullptr;
         const bf16_t* rrow = nullptr;
         const float* grow = nullptr;
         if (EPI == 2 || EPI == 3) {
@@ -82,6 +84,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[N
                     const uint2 bb = *(const uint2*)(p.bias + n);
                     v[0] += bf2f(bb.x & 0xffff); v[1] += bf2f(bb.x >> 16);
                     v[2] += bf2f(bb.y & 0xffff); v[3] += bf2f(bb.y >> 16);
+                }
+                if (yrow) {   // training: keep acc + bias (GELU pre-activation / un-gated branch output)
+                    uint2 yo; yo.x = pack2bf(v[0], v[1]); yo.y = pack2bf(v[2], v[3]);
+                    *(uint2*)(yrow + n) = yo;
                 }
                 if (EPI == 1) {
 #pragma unroll
@@ -493,6 +499,7 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
     a.gate = g->gate; a.gate_b = g->gate_b; a.gate_g = g->gate_g;
     a.seq = g->grp.seq; a.n_text = g->grp.n_text; a.per_group = g->grp.per_group;
     a.c_rows = g->cmap.rows; a.c_bstride = g->cmap.bstride; a.c_off = g->cmap.off;
+    a.Y = (bf16_t*)g->Y; a.ldy = g->ldy;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("ORV_GEMM_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     hipStream_t st = (hipStream_t)stream;
     const int bn = (g->N % 192 == 0) ? 192 : (g->N % 128 == 0 ? 128 : 64);

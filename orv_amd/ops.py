@@ -155,7 +155,7 @@ def qkv_prep(qkv, vT, gq, bq, gk, bk, rope: Optional[Tuple[torch.Tensor, torch.T
 
 
 def gemm(A, W, bias, C, M, N, K, epilogue=0, R=None, r_mod=0, gate=None, gate_b=0, gate_g=0, grp: Optional[Groups] = None,
-         cmap: Optional[RowMap] = None, lda=None, ldw=None, ldc=None, ldr=None):
+         cmap: Optional[RowMap] = None, lda=None, ldw=None, ldc=None, ldr=None, Y=None, ldy=None):
     _need(A, BF16, "A"), _need(W, BF16, "W"), _need(C, BF16, "C")
     g = Gemm()
     g.A, g.lda, g.W, g.ldw, g.bias = _p(A), lda or K, _p(W), ldw or K, _p(bias)
@@ -164,6 +164,7 @@ def gemm(A, W, bias, C, M, N, K, epilogue=0, R=None, r_mod=0, gate=None, gate_b=
     g.gate, g.gate_b, g.gate_g = _p(gate), gate_b, gate_g
     g.grp = grp or Groups(0, 0, 0)
     g.cmap = cmap or RowMap(0, 0, 0)
+    g.Y, g.ldy = _p(Y), ldy or N
     with _timed(("gemm", M, N, K, epilogue)):
         check(lib().orv_gemm_bf16(g, _stream()), "orv_gemm_bf16")
     return C
