@@ -115,6 +115,67 @@ def cpu_baseline(cfg, layers, threads):
             "s_per_step": per_step}
 
 
+def train_mode(args, model, latents, image_latents, prompt, actions, sched, dev, rank, world):
+    """BASELINE configs[2]: CogVideoX-2B SFT step (train_cogvideox_control_to_video_sft.py:1005-1104), B clips per GPU, bf16
+    params/grads, data parallel: forward+backward through the HIP kernels, ONE bucketed RCCL all-reduce of the gradients,
+    global-norm clip + fused AdamW.  value = trained clips per second (all GPUs)."""
+    import torch.distributed as dist
+    from orv_amd.optim import FusedAdamW
+    from orv_amd.sharding import allreduce_gradients
+    B = args.batch
+    model.train()
+    opt = FusedAdamW(model.parameters(), lr=1e-5, betas=(0.9, 0.95), weight_decay=1e-3, max_grad_norm=1.0)
+    ac = sched.alphas_cumprod.to(dev, torch.float32)
+    g = torch.Generator(device=dev).manual_seed(42 + rank)
+    x0 = latents
+
+    def step():
+        noise = torch.randn(x0.shape, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+        ts = torch.randint(0, 1000, (B,), generator=g, device=dev)
+        noisy = sched.add_noise(x0, noise, ts)
+        out = model(torch.cat([noisy, image_latents], dim=2), prompt, {"actions": actions}, ts, return_dict=False)[0]
+        pred = sched.get_velocity(out, noisy, ts)
+        wgt = (1 / (1 - ac[ts]).clamp_min(1e-4))[:, None, None, None, None]
+        loss = torch.mean((wgt * (pred.float() - x0.float()) ** 2).reshape(B, -1), dim=1).mean()
+        loss.backward()
+        allreduce_gradients(model.parameters())
+        opt.step()
+        opt.zero_grad()
+        return loss
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        w = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        wall = float(w.item())
+    if rank == 0:
+        fl = 3.0 * flops_per_sample({**CFG_2B, "num_layers": args.layers}, 3226)
+        value = world * B * args.steps / wall
+        print(json.dumps({
+            "metric": "train-clips/sec", "value": round(value, 3), "unit": "clips/s (SFT step: fwd+bwd+allreduce+AdamW)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "achieved_tflops_attn_ffn": round(value * fl / 1e12, 1), "final_loss": float(loss),
+            "config": {"workload": "configs[2]: CogVideoX-2B SFT step, 320x480x17f latents, bf16 params+grads, DP",
+                       "batch_per_gpu": B, "num_layers": args.layers, "parallelism": f"dp{world} (one RCCL all-reduce/step)",
+                       "valid": args.layers == 30}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +183,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4, help="clips per GPU per step (reference eval batch = 4, demo = 1)")
     ap.add_argument("--layers", type=int, default=30, help="debug only; anything but 30 marks the line INVALID")
+    ap.add_argument("--mode", choices=["denoise", "train"], default="denoise",
+                    help="denoise (headline, BASELINE configs[1]) or train (configs[2]: one SFT step = fwd+bwd+all-reduce+AdamW)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-layers", type=int, default=6)
     args = ap.parse_args()
@@ -158,6 +221,9 @@ def main():
         v = model(hidden_states=model_in, encoder_hidden_states=prompt, timestep=tvec,
                   controls_or_guidances=controls, return_dict=False)[0]
         return sched.step(v, t, lat, return_dict=False)[0]
+
+    if args.mode == "train":
+        return train_mode(args, model, latents, image_latents, prompt, actions, sched, dev, rank, world)
 
     def barrier():
         torch.cuda.synchronize()

@@ -179,8 +179,8 @@ int orv_attention_bwd(const void* qkv, int ld_qkv, const void* qT, const void* k
 /* Adjoint of orv_qkv_prep for the q and k thirds, in place on dqkv: inverse RoPE, LayerNorm(64) backward (qkv_raw = the
  * QKV GEMM output before orv_qkv_prep); dgq/dbq/dgk/dbk fp32 [64] accumulate the norm_q / norm_k parameter gradients. */
 int orv_qkv_prep_bwd(const void* qkv_raw, void* dqkv, const void* gq, const void* gk, const float* rope_cos,
-                     const float* rope_sin, float* dgq, float* dbq, float* dgk, float* dbk, int B, int S, int H, int n_text,
-                     float eps, void* stream);
+                     const float* rope_sin, float* dgq, float* dbq, float* dgk, float* dbk, float* scratch, int B, int S,
+                     int H, int n_text, float eps, void* stream);   /* scratch: fp32 [ceil(S/64)*H*B*256] */
 
 /* -- attention -------------------------------------------------------------------------------- */
 /* Non-causal, unmasked softmax(q k^T * scale) v over the joint text+video sequence, head_dim 64

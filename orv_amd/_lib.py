@@ -64,7 +64,7 @@ SIGNATURES = {
     "orv_attention_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "orv_qkv_prep_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                 c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+                                 c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "orv_sched_step": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                c_float, c_float, c_float, c_float, c_float, c_float, c_long, c_void_p]),
     "orv_gaussian_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),

@@ -320,9 +320,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const BwdArgs p) {
 __global__ __launch_bounds__(256) void qkv_prep_bwd_kernel(const bf16_t* __restrict__ qkv_raw, bf16_t* __restrict__ dqkv,
                                                            const bf16_t* __restrict__ gq, const bf16_t* __restrict__ gk,
                                                            const float* __restrict__ rcos, const float* __restrict__ rsin,
-                                                           float* __restrict__ dgq, float* __restrict__ dbq,
-                                                           float* __restrict__ dgk, float* __restrict__ dbk, int S, int H,
+                                                           float* __restrict__ partial, int S, int H,
                                                            int n_text, float eps) {
+    // partial[block][which][0: dgamma | 1: dbeta][64]: per-block sums, reduced by reduce_partials_kernel (no atomics on
+    // the 256 shared addresses - with 6000 blocks they serialised into milliseconds)
+    __shared__ float red[4][2][2][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
     const long ld = 3L * H * 64;
@@ -390,11 +392,30 @@ __global__ __launch_bounds__(256) void qkv_prep_bwd_kernel(const bf16_t* __restr
             a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
             c2 += __shfl_xor(c2, 8, 64); c2 += __shfl_xor(c2, 16, 64); c2 += __shfl_xor(c2, 32, 64);
             if (lane < 8) {
-                if (which ? dgk != nullptr : dgq != nullptr) atomicAdd((which ? dgk : dgq) + sub * 8 + e, a);
-                if (which ? dbk != nullptr : dbq != nullptr) atomicAdd((which ? dbk : dbq) + sub * 8 + e, c2);
+                red[wave][which][0][sub * 8 + e] = a;
+                red[wave][which][1][sub * 8 + e] = c2;
             }
         }
     }
+    __syncthreads();
+    {
+        const int w2 = tid >> 7, gb = (tid >> 6) & 1, col = tid & 63;     // 256 threads = 2 x 2 x 64 outputs
+        const float v = red[0][w2][gb][col] + red[1][w2][gb][col] + red[2][w2][gb][col] + red[3][w2][gb][col];
+        const long blk = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partial[blk * 256 + tid] = v;
+    }
+}
+
+// out[j] += sum_rows partial[row][j], j < 256: one block per 64-row slab, fp32 atomics only across slabs
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, long nrows,
+                                                              float* __restrict__ o0, float* __restrict__ o1,
+                                                              float* __restrict__ o2, float* __restrict__ o3) {
+    const int tid = threadIdx.x;
+    const long r0 = (long)blockIdx.x * 64, r1 = min(nrows, r0 + 64);
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) s += partial[r * 256 + tid];
+    float* dst = (tid < 64) ? o0 : (tid < 128) ? o1 : (tid < 192) ? o2 : o3;     // dgq | dbq | dgk | dbk
+    if (dst) atomicAdd(dst + (tid & 63), s);
 }
 
 }  // namespace
@@ -428,12 +449,15 @@ extern "C" int orv_attention_bwd(const void* qkv, int ld_qkv, const void* qT, co
 }
 
 extern "C" int orv_qkv_prep_bwd(const void* qkv_raw, void* dqkv, const void* gq, const void* gk, const float* rope_cos,
-                                const float* rope_sin, float* dgq, float* dbq, float* dgk, float* dbk, int B, int S, int H,
-                                int n_text, float eps, void* stream) {
-    ORV_REQUIRE(qkv_raw && dqkv && B > 0 && S > 0 && H > 0, "orv_qkv_prep_bwd: bad arguments");
+                                const float* rope_sin, float* dgq, float* dbq, float* dgk, float* dbk, float* scratch,
+                                int B, int S, int H, int n_text, float eps, void* stream) {
+    ORV_REQUIRE(qkv_raw && dqkv && scratch && B > 0 && S > 0 && H > 0, "orv_qkv_prep_bwd: bad arguments");
     ORV_REQUIRE((rope_cos == nullptr) == (rope_sin == nullptr), "orv_qkv_prep_bwd: cos and sin go together");
     hipLaunchKernelGGL(qkv_prep_bwd_kernel, dim3((S + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)qkv_raw, (bf16_t*)dqkv, (const bf16_t*)gq, (const bf16_t*)gk, rope_cos, rope_sin, dgq,
-                       dbq, dgk, dbk, S, H, n_text, eps);
+                       (const bf16_t*)qkv_raw, (bf16_t*)dqkv, (const bf16_t*)gq, (const bf16_t*)gk, rope_cos, rope_sin, scratch,
+                       S, H, n_text, eps);
+    const long nblk = (long)((S + 63) / 64) * H * B;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nblk + 63) / 64)), dim3(256), 0, (hipStream_t)stream, scratch, nblk,
+                       dgq, dbq, dgk, dbk);
     return orv_check_launch("orv_qkv_prep_bwd");
 }

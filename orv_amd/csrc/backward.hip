@@ -129,8 +129,7 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16_t* __restric
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nchunk = D >> 3;
-    const int r0 = wid * rpw, r1 = min(rows, r0 + rpw);
-    if (r0 >= rows) return;
+    const int r0 = min(wid * rpw, rows), r1 = min(rows, r0 + rpw);     // waves past the end run zero rows (they still join the barrier)
     float gam[CH][8], bet[CH][8], a_sc[CH][8], a_sh[CH][8], a_g[CH][8], a_b[CH][8];
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
@@ -244,10 +243,36 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16_t* __restric
         const int c = lane + 64 * i;
         if (c >= nchunk) continue;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            if (scale) { atomicAdd(dscale + cur_off + c * 8 + e, a_sc[i][e]); atomicAdd(dshift + cur_off + c * 8 + e, a_sh[i][e]); }
-            if (dgamma) atomicAdd(dgamma + c * 8 + e, a_g[i][e]);
-            if (dbeta) atomicAdd(dbeta + c * 8 + e, a_b[i][e]);
+        for (int e = 0; e < 8; ++e)
+            if (scale && cur_off >= 0) { atomicAdd(dscale + cur_off + c * 8 + e, a_sc[i][e]); atomicAdd(dshift + cur_off + c * 8 + e, a_sh[i][e]); }
+    }
+    // dgamma / dbeta: every wave of the grid adds into the same D addresses -> reduce the 4 waves of the block in LDS first
+    // (callers guarantee whole blocks are live: rows are padded out by the r0 >= rows early-exit only in the last block)
+    if (dgamma || dbeta) {
+        __shared__ float red_g[3][4096], red_b[3][4096];
+        const int w = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk && w > 0)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { red_g[w - 1][c * 8 + e] = a_g[i][e]; red_b[w - 1][c * 8 + e] = a_b[i][e]; }
+        }
+        __syncthreads();
+        if (w == 0) {
+            const int live = min(4, (rows - (int)blockIdx.x * 4 * rpw + rpw - 1) / rpw);    // waves of this block that had rows
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int c = lane + 64 * i;
+                if (c >= nchunk) continue;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float g = a_g[i][e], bsum = a_b[i][e];
+                    for (int k = 1; k < live; ++k) { g += red_g[k - 1][c * 8 + e]; bsum += red_b[k - 1][c * 8 + e]; }
+                    if (dgamma) atomicAdd(dgamma + c * 8 + e, g);
+                    if (dbeta) atomicAdd(dbeta + c * 8 + e, bsum);
+                }
+            }
         }
     }
 }
@@ -273,20 +298,29 @@ __global__ void small_wgrad_kernel(const float* __restrict__ dy, long ldy, const
 //      dx[r, k] += sum_n dy[r, n] * W[n, k]   (fp32 atomics; block = 256 columns n-slab x all rows)
 __global__ __launch_bounds__(256) void small_dgrad_kernel(const float* __restrict__ dy, long ldy, const bf16_t* __restrict__ W,
                                                           float* __restrict__ dx, long lddx, int R, int N, int K, int nslab) {
+    // block: 256 columns k x one n-slab; dy slab staged in LDS (rows x nslab), W streamed once, 32 rows per pass in registers
+    extern __shared__ float dys[];   // [min(R,32)][nslab]
     const int k = blockIdx.x * 256 + threadIdx.x;
-    const int n0 = blockIdx.y * nslab, n1 = min(N, n0 + nslab);
-    if (k >= K) return;
-    for (int r0 = 0; r0 < R; r0 += 8) {
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int n = n0; n < n1; ++n) {
-            const float w = bf2f(W[(long)n * K + k]);
+    const int n0 = blockIdx.y * nslab, n1 = min(N, n0 + nslab), nn = n1 - n0;
+    for (int r0 = 0; r0 < R; r0 += 32) {
+        const int rr = min(32, R - r0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < rr * nn; i += 256) dys[(i / nn) * nslab + i % nn] = dy[(long)(r0 + i / nn) * ldy + n0 + i % nn];
+        __syncthreads();
+        if (k < K) {
+            float acc[32];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (r0 + j < R) acc[j] = fmaf(dy[(long)(r0 + j) * ldy + n], w, acc[j]);
+            for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+            for (int n = 0; n < nn; ++n) {
+                const float w = bf2f(W[(long)(n0 + n) * K + k]);
+#pragma unroll
+                for (int j = 0; j < 32; ++j)
+                    if (j < rr) acc[j] = fmaf(dys[j * nslab + n], w, acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 32; ++j)
+                if (j < rr) atomicAdd(dx + (long)(r0 + j) * lddx + k, acc[j]);
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (r0 + j < R) atomicAdd(dx + (long)(r0 + j) * lddx + k, acc[j]);
     }
 }
 
@@ -370,7 +404,7 @@ extern "C" int orv_layernorm_modulate_bwd(const void* dy, const void* x, orv_row
     ORV_REQUIRE(dy && x && dx, "orv_layernorm_modulate_bwd: null operand");
     ORV_REQUIRE(D % 8 == 0 && D <= 4096, "orv_layernorm_modulate_bwd: D=%d unsupported", D);
     ORV_REQUIRE(!scale || (dscale && dshift), "orv_layernorm_modulate_bwd: dscale/dshift required with scale");
-    const int rows = batch * grp.seq, rpw = 8;
+    const int rows = batch * grp.seq, rpw = rows >= 8192 ? 12 : 4;
     const int waves = (rows + rpw - 1) / rpw;
     dim3 grid((waves + 3) / 4);
     const int ch = (D / 8 + 63) / 64;
@@ -396,9 +430,10 @@ extern "C" int orv_small_linear_bwd(const float* dy, int ldy, const void* x, int
     }
     if (dx) {
         ORV_REQUIRE(W, "orv_small_linear_bwd: W required for dx");
-        const int nslab = 256;
+        const int nslab = 64;
         dim3 grid((K + 255) / 256, (N + nslab - 1) / nslab);
-        hipLaunchKernelGGL(small_dgrad_kernel, grid, dim3(256), 0, st, dy, (long)ldy, (const bf16_t*)W, dx, (long)lddx, R, N, K, nslab);
+        hipLaunchKernelGGL(small_dgrad_kernel, grid, dim3(256), 32 * nslab * sizeof(float), st, dy, (long)ldy, (const bf16_t*)W, dx,
+                           (long)lddx, R, N, K, nslab);
     }
     return orv_check_launch("orv_small_linear_bwd");
 }

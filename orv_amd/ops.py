@@ -276,5 +276,7 @@ def qkv_prep_bwd(qkv_raw, dqkv, gq, gk, rope, dgq, dbq, dgk, dbk, B, S, H, n_tex
     cos = sin = None
     if rope is not None:
         cos, sin = rope
+    nblk = ((S + 63) // 64) * H * B
+    scratch = torch.empty(nblk * 256, dtype=torch.float32, device=dqkv.device)
     check(lib().orv_qkv_prep_bwd(_p(qkv_raw), _p(dqkv), _p(gq), _p(gk), _p(cos), _p(sin), _p(dgq), _p(dbq), _p(dgk), _p(dbk),
-                                 B, S, H, n_text, float(eps), _stream()), "orv_qkv_prep_bwd")
+                                 _p(scratch), B, S, H, n_text, float(eps), _stream()), "orv_qkv_prep_bwd")
