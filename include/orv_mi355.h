@@ -85,6 +85,15 @@ int orv_unpatchify(const void* x, void* out, int B, int T, int C, int H, int W, 
 int orv_add_rows(const void* a, int lda, orv_rowmap_t amap, const void* b, int ldb, void* out, int ldo, int col_off, int M,
                  int D, void* stream);
 
+/* Multiview cross-view attention (MVBlock.forward cogvideox_control.py:313-348) re-groups tokens
+ * '(b v) (f s) d -> (b f) (v s) d' (einops rearrange :328,:346; text '(b v) n d -> (b f) (v n) d' :329-331):
+ * orv_gather_rows:        dst[r, :] = src[idx[r], :]                      (idx = host-built permutation, int32 on device)
+ * orv_scatter_gated_rows: x[idx[r], :] += gate[idx[r] / seq, :] * y[r, :]  for video target rows only - the rearrange back
+ *                         fused with the gated residual `hidden + gate_msa * attn` (:347). */
+int orv_gather_rows(const void* src, int ld_src, const int* idx, void* dst, int ld_dst, int R, int D, void* stream);
+int orv_scatter_gated_rows(const void* y, int ldy, const int* idx, const float* gate, long gate_b, void* x, int ldx, int R,
+                           int D, int seq, int n_text, void* stream);
+
 /* -- normalisation ---------------------------------------------------------------------------- */
 /* y = LN(x; gamma, beta, eps) * (1 + scale[b, g(s)]) + shift[b, g(s)]   (CogVideoXLayerNormZero.forward
  * cogvideox_control.py:117-145, AdaLayerNorm.forward :155-197, nn.LayerNorm norm_final :909-916).

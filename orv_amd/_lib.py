@@ -38,6 +38,9 @@ SIGNATURES = {
     "orv_patchify": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                              c_void_p]),
     "orv_unpatchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "orv_gather_rows": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "orv_scatter_gated_rows": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                       c_void_p]),
     "orv_add_rows": (c_int, [c_void_p, c_int, RowMap, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "orv_layernorm_modulate": (c_int, [c_void_p, c_int, RowMap, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_long, c_long, Groups, c_int, c_int, c_float, c_void_p]),

@@ -148,7 +148,8 @@ class CogVideoXBlock(_NoForward):
 
 
 class MVBlock(_NoForward):
-    """:273-348 (multiview cross-view attention).  Parameters only: the MV path is a SURVEY §8(f) "next" row."""
+    """:273-348 (multiview cross-view attention).  Parameter container; the arithmetic is
+    ``CogVideoXTransformer3DModelTraj._mv_block`` (gather -> QKV GEMM -> attention -> out/proj GEMMs -> gated scatter)."""
 
     def __init__(self, dim, num_attention_heads, attention_head_dim, time_embed_dim, attention_bias=False, qk_norm=True,
                  norm_elementwise_affine=True, norm_eps=1e-5, attention_out_bias=True,
@@ -436,6 +437,19 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
                                   vis2=e(B * Nv, D), s_pad=s_pad)}
         return self._ws[key]
 
+    def _view_pos_table(self, pos, n_view, T, P, dev):
+        key = ("posv", n_view, T, P, str(dev))
+        if key not in self._ws:
+            D = self.inner_dim
+            pv = self.pos_embedding_v.to(device=dev, dtype=torch.float32).reshape(self.config.max_n_view, -1, D)[:n_view]
+            if pv.shape[1] != P:
+                raise ValueError(f"pos_embedding_v is built for {pv.shape[1]} spatial tokens, got {P} (:679-688)")
+            base = pos.float().reshape(1, T, P, D) if pos is not None else 0.0
+            # the reference rounds to bf16 after each of the two adds; one table keeps a single rounding in the epilogue
+            tab = (base + pv.to(BF16).float()[:, None]).reshape(n_view * T * P, D)
+            self._ws[key] = tab.to(BF16).contiguous()
+        return self._ws[key]
+
     def _pointer_tables(self, dev):
         """Device arrays of weight/bias pointers of every AdaLN linear (norm1, norm2 of each block; norm_out), built once."""
         lins = [n.linear for blk in self.transformer_blocks for n in (blk.norm1, blk.norm2)]
@@ -467,8 +481,10 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             raise RuntimeError("orv_amd runs on MI355X only: move the model and its inputs to the GPU (no CPU fallback)")
         if self.dtype != BF16:
             raise RuntimeError(f"orv_amd kernels are bf16: call model.to(torch.bfloat16) (got {self.dtype})")
-        if c.multiview or num_views > 1:
-            raise NotImplementedError("multiview (MVBlock, :273-348) is a SURVEY §8(f) 'next' row, not built yet")
+        if num_views > 1 and not c.multiview:
+            raise ValueError("num_views > 1 needs a multiview=True model (pos_embedding_v / mv_blocks, :592-606)")
+        if c.multiview and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("the hand-written backward covers the single-view SFT step; run multiview under no_grad")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # training step (train_cogvideox_control_to_video_sft.py:1051-1093): forward that saves activations, with the
             # hand-written backward attached to autograd as one node
@@ -480,12 +496,66 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             return Transformer3DModelTrajOutput(sample=out, is_action_mask=mask, actions_recon=recon)
         with torch.no_grad():
             return self._forward_inference(hidden_states, encoder_hidden_states, controls_or_guidances, timestep, ofs,
-                                           image_rotary_emb, return_dict)
+                                           image_rotary_emb, return_dict, num_views, image_rotary_emb_view)
+
+    # ---- multiview (:273-348, :797-800) ----
+    def _mv_state(self, b, v, f, Nt, P, S, dev):
+        """Workspace + the token permutation '(b v) (f s) -> (b f) (v s)' (text '(b v) n -> (b f) (v n)') as a row index
+        into the joint [(b v), S, D] buffer, built once per shape."""
+        key = ("mv", b, v, f, Nt, P, str(dev))
+        if key not in self._ws:
+            D, H = self.inner_dim, self.config.num_attention_heads
+            Sm = v * (Nt + P)
+            bi = torch.arange(b, device=dev).view(b, 1, 1, 1)
+            fi = torch.arange(f, device=dev).view(1, f, 1, 1)
+            vi = torch.arange(v, device=dev).view(1, 1, v, 1)
+            txt = ((bi * v + vi) * S + torch.arange(Nt, device=dev).view(1, 1, 1, Nt)).expand(b, f, v, Nt)
+            vid = (bi * v + vi) * S + Nt + fi * P + torch.arange(P, device=dev).view(1, 1, 1, P)
+            idx = torch.cat([txt.reshape(b, f, v * Nt), vid.reshape(b, f, v * P)], dim=2).to(torch.int32).contiguous()
+            s_pad = (Sm + 63) // 64 * 64
+            R = b * f * Sm
+            e = lambda *shape: torch.empty(*shape, dtype=BF16, device=dev)
+            self._ws[key] = dict(idx=idx.view(-1), xm=e(R, D), qkv=e(R, 3 * D), att=e(R, D), s_pad=s_pad, Sm=Sm, R=R,
+                                 vT=torch.zeros(b * f, H, 64, s_pad, dtype=BF16, device=dev))
+        return self._ws[key]
+
+    def _mv_pointer_tables(self, dev):
+        lins = [blk.norm1.linear for blk in self.mv_blocks]
+        key = (str(dev),) + tuple(l.weight.data_ptr() for l in lins)
+        if getattr(self, "_mv_ptr_tables", None) is None or self._mv_ptr_tables[0] != key:
+            arr = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=dev)
+            self._mv_ptr_tables = (key, arr([l.weight for l in lins]), arr([l.bias for l in lins]))
+        return self._mv_ptr_tables[1:]
+
+    def _mv_block(self, blk, mv, m, x, xn, grp0, Bv, S, Nt, n_view, n_frame, rope_view=None):
+        """MVBlock.forward (:313-348): AdaLN (no action term) -> tokens of all views of one frame attend jointly ->
+        to_out, proj_out -> rearranged back and added with gate_msa.  m: this block's fp32 table [Bv, 2, 3D]."""
+        c = self.config
+        D, heads = self.inner_dim, c.num_attention_heads
+        at = blk.attn1
+        ops.layernorm_modulate(x, xn, blk.norm1.norm.weight, blk.norm1.norm.bias, m[..., D:2 * D], m[..., :D],
+                               2 * 3 * D, 3 * D, grp0, Bv, D, c.norm_eps)
+        R, Sm, s_pad = mv["R"], mv["Sm"], mv["s_pad"]
+        ops.gather_rows(xn, mv["idx"], mv["xm"], R, D)
+        wqkv, bqkv = at.packed_qkv()
+        ops.gemm(mv["xm"], wqkv, bqkv, mv["qkv"], R, 3 * D, D)
+        scale = 1.0 / math.sqrt(c.attention_head_dim)
+        ops.qkv_prep(mv["qkv"], mv["vT"], at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, rope_view,
+                     R // Sm, Sm, heads, n_view * Nt, s_pad, at.eps, q_premul=scale * LOG2E)
+        ops.attention_fwd(mv["qkv"], mv["vT"], mv["att"], R // Sm, Sm, heads, s_pad, 1.0 / LOG2E)
+        ops.gemm(mv["att"], at.to_out[0].weight, at.to_out[0].bias, mv["xm"], R, D, D)
+        ops.gemm(mv["xm"], blk.proj_out.weight, blk.proj_out.bias, mv["att"], R, D, D)
+        # '(b f) (v s) d -> (b v) (f s) d' + gated residual on the video rows only (the text output of attn1 is dropped)
+        ops.scatter_gated_rows(mv["att"], mv["idx"], m[:, 1, 2 * D:], 2 * 3 * D, x, R, D, S, Nt)
 
     def _forward_inference(self, hidden_states, encoder_hidden_states, controls_or_guidances, timestep, ofs,
-                           image_rotary_emb, return_dict):
+                           image_rotary_emb, return_dict, num_views=1, image_rotary_emb_view=None):
         c = self.config
         dev = hidden_states.device
+        if num_views > 1:                                                            # :756-758
+            bb, vf = hidden_states.shape[:2]
+            hidden_states = hidden_states.reshape(bb * num_views, vf // num_views, *hidden_states.shape[2:])
+            encoder_hidden_states = encoder_hidden_states.repeat_interleave(num_views, dim=0)
         B, T, C, Hh, Ww = hidden_states.shape
         p, pt = c.patch_size, c.patch_size_t
         D, heads, E = self.inner_dim, c.num_attention_heads, c.time_embed_dim
@@ -500,8 +570,8 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
 
         # 1. time (+ofs) embedding  (:762-775)
         tvec = torch.as_tensor(timestep, device=dev).reshape(-1).to(torch.float32)
-        if tvec.numel() == 1 and B > 1:
-            tvec = tvec.expand(B)
+        if tvec.numel() == 1 and B // num_views > 1:
+            tvec = tvec.expand(B // num_views)
         te = self.time_embedding
         t_emb = ops.timestep_embedding(tvec.contiguous(), D, c.flip_sin_to_cos, c.freq_shift)
         temb = ops.skinny_linear(ops.skinny_linear(t_emb, te.linear_1.weight, te.linear_1.bias, act_out="silu"),
@@ -513,13 +583,20 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             o_emb = ops.skinny_linear(ops.skinny_linear(o_emb, oe.linear_1.weight, oe.linear_1.bias, act_out="silu"),
                                       oe.linear_2.weight, oe.linear_2.bias)
             temb = temb + o_emb          # [B,E] + [1,E]; tiny glue add in the model dtype as at :775
+        if num_views > 1:                # multiviews share the same noise level (:777-779)
+            temb = temb.repeat_interleave(num_views, dim=0).contiguous()
 
         # 2. patch embedding straight into the joint [B,S,D] buffer (:788-794)
         pe = self.patch_embed
         tokens = ops.patchify(hidden_states.to(BF16), None, p, pt)
         a2, w2 = self._linear_k64(tokens.view(B * Nv, -1), pe.proj)
         pos = pe.video_pos_table(T, Hh, Ww, dev)
-        ops.gemm(a2, w2, pe.proj.bias, x, B * Nv, D, a2.shape[1], epilogue=2 if pos is not None else 0, R=pos, r_mod=Nv,
+        pos_mod = Nv
+        if num_views > 1:
+            # :797-800 adds pos_embedding_v[view, spatial] to every frame: folded into the patch-embed epilogue as one table
+            # of n_view*Nv rows (row = view*Nv + frame*P + s), built once per shape.
+            pos, pos_mod = self._view_pos_table(pos, num_views, T, P, dev), num_views * Nv
+        ops.gemm(a2, w2, pe.proj.bias, x, B * Nv, D, a2.shape[1], epilogue=2 if pos is not None else 0, R=pos, r_mod=pos_mod,
                  ldr=D, cmap=ops.rowmap(Nv, S, Nt))
         if mod_text:
             a2, w2 = self._linear_k64(encoder_hidden_states.to(BF16).reshape(B * Nt, -1), pe.text_proj)
@@ -535,6 +612,8 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             if pad_frames:
                 actions = torch.cat([actions.new_zeros((actions.shape[0], pad_frames, actions.shape[2])), actions], dim=1)
             action_emb, is_action_mask = self.action_embed(actions)
+            if num_views > 1:            # multiviews share the same actions (:815-816)
+                action_emb = action_emb.repeat_interleave(num_views, dim=0)
             if self.training and c.recon_action and self.action_recon is not None:
                 actions_recon = self.action_recon(action_emb)
                 if pad_frames > 0:
@@ -548,11 +627,14 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
                 cm = controls_or_guidances.get(key, None)
                 if cm is None:
                     continue
+                if num_views > 1:
+                    cm = cm.reshape(cm.shape[0] * num_views, cm.shape[1] // num_views, *cm.shape[2:])
                 tk = ops.patchify(cm.to(device=dev, dtype=BF16), None, p, pt)
                 a2c, w2c = self._linear_k64(tk.view(B * Nv, -1), pe.proj)
                 ctok = torch.empty(B * Nv, D, dtype=BF16, device=dev)
-                ops.gemm(a2c, w2c, pe.proj.bias, ctok, B * Nv, D, a2c.shape[1], epilogue=2 if pos is not None else 0,
-                         R=pos, r_mod=Nv, ldr=D)
+                cpos = pe.video_pos_table(T, Hh, Ww, dev)      # controls get the frame table only (:828-858)
+                ops.gemm(a2c, w2c, pe.proj.bias, ctok, B * Nv, D, a2c.shape[1], epilogue=2 if cpos is not None else 0,
+                         R=cpos, r_mod=Nv, ldr=D)
                 ctrl_toks.append(ctok)
         if ctrl_toks:
             assert len(ctrl_toks) == self.num_control_keys, \
@@ -581,12 +663,24 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         rope = None
         if image_rotary_emb is not None:
             rope = tuple(r.to(device=dev, dtype=torch.float32).contiguous() for r in image_rotary_emb)
+        mv = mv_mod = rope_view = None
+        if c.multiview:
+            if Nv % T:
+                raise ValueError(f"{Nv} video tokens cannot be split over {T} frames for the multiview blocks")
+            mv = self._mv_state(B // num_views, num_views, T, Nt, Nv // T, S, dev)
+            wmv, bmv = self._mv_pointer_tables(dev)
+            mv_mod = ops.modulation_tables(temb, None, wmv, bmv, L, B, 1, E, 3 * D, mod_text)       # [L, B, 2, 3D]
+            grp0 = ops.groups(S, Nt, 0)
+            if image_rotary_emb_view is not None:
+                rope_view = tuple(r.to(device=dev, dtype=torch.float32).contiguous() for r in image_rotary_emb_view)
 
         # 5. transformer blocks (:861-907 -> :394-445)
         M = B * S
         mb, mg = G * 3 * D, 3 * D
         scale = 1.0 / math.sqrt(c.attention_head_dim)
         for i, blk in enumerate(self.transformer_blocks):
+            if mv is not None:
+                self._mv_block(self.mv_blocks[i], mv, mv_mod[i], x, xn, grp0, B, S, Nt, num_views, T, rope_view)
             m1, m2 = mod[2 * i], mod[2 * i + 1]
             at = blk.attn1
             ops.layernorm_modulate(x, xn, blk.norm1.norm.weight, blk.norm1.norm.bias, m1[..., D:2 * D], m1[..., :D],
@@ -627,6 +721,8 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         if wo.shape[0] != fo:
             out_tok = out_tok[:, :fo].contiguous()
         output = ops.unpatchify(out_tok, B, T, fo // (p * p * (pt or 1)), Hh, Ww, p, pt)
+        if num_views > 1:                                                            # :941
+            output = output.reshape(B // num_views, num_views * T, *output.shape[2:])
 
         if not return_dict:
             return (output, is_action_mask, actions_recon)

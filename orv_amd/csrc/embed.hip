@@ -183,7 +183,55 @@ __global__ void add_rows_kernel(const bf16_t* __restrict__ a, long lda, orv_rowm
     *(uint4*)(out + (long)m * ldo + col_off + c * 8) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// dst[r, :] = src[idx[r], :]
+__global__ void gather_rows_kernel(const bf16_t* __restrict__ src, long lds_, const int* __restrict__ idx,
+                                   bf16_t* __restrict__ dst, long ldd, int R, int D) {
+    const int nchunk = D >> 3;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)R * nchunk) return;
+    const int r = (int)(i / nchunk), c = (int)(i % nchunk);
+    *(uint4*)(dst + (long)r * ldd + c * 8) = *(const uint4*)(src + (long)idx[r] * lds_ + c * 8);
+}
+// x[idx[r], :] += gate[(idx[r] / seq) * gate_b + :] * y[r, :]   for rows whose target is a video row ((idx[r] % seq) >= n_text)
+__global__ void scatter_gated_rows_kernel(const bf16_t* __restrict__ y, long ldy, const int* __restrict__ idx,
+                                          const float* __restrict__ gate, long gate_b, bf16_t* __restrict__ x, long ldx_,
+                                          int R, int D, int seq, int n_text) {
+    const int nchunk = D >> 3;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)R * nchunk) return;
+    const int r = (int)(i / nchunk), c = (int)(i % nchunk);
+    const int t = idx[r];
+    if (t % seq < n_text) return;
+    const float* g = gate + (long)(t / seq) * gate_b + c * 8;
+    const uint4 uy = *(const uint4*)(y + (long)r * ldy + c * 8);
+    bf16_t* xp = x + (long)t * ldx_ + c * 8;
+    const uint4 ux = *(const uint4*)xp;
+    const uint32_t wy[4] = {uy.x, uy.y, uy.z, uy.w}, wx[4] = {ux.x, ux.y, ux.z, ux.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        o[e] = pack2bf(bf2f(wx[e] & 0xffff) + g[2 * e] * bf2f(wy[e] & 0xffff), bf2f(wx[e] >> 16) + g[2 * e + 1] * bf2f(wy[e] >> 16));
+    *(uint4*)xp = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 }  // namespace
+
+extern "C" int orv_gather_rows(const void* src, int ld_src, const int* idx, void* dst, int ld_dst, int R, int D, void* stream) {
+    ORV_REQUIRE(src && idx && dst && R > 0 && D > 0 && D % 8 == 0, "orv_gather_rows: bad arguments");
+    const long total = (long)R * (D / 8);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, (long)ld_src, idx, (bf16_t*)dst, (long)ld_dst, R, D);
+    return orv_check_launch("orv_gather_rows");
+}
+
+extern "C" int orv_scatter_gated_rows(const void* y, int ldy, const int* idx, const float* gate, long gate_b, void* x, int ldx,
+                                      int R, int D, int seq, int n_text, void* stream) {
+    ORV_REQUIRE(y && idx && gate && x && R > 0 && D > 0 && D % 8 == 0 && seq > 0, "orv_scatter_gated_rows: bad arguments");
+    const long total = (long)R * (D / 8);
+    hipLaunchKernelGGL(scatter_gated_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)y, (long)ldy, idx, gate, gate_b, (bf16_t*)x, (long)ldx, R, D, seq, n_text);
+    return orv_check_launch("orv_scatter_gated_rows");
+}
 
 extern "C" int orv_add_rows(const void* a, int lda, orv_rowmap_t amap, const void* b, int ldb, void* out, int ldo,
                             int col_off, int M, int D, void* stream) {

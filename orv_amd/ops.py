@@ -118,6 +118,17 @@ def unpatchify(x, B, T, C, H, W, p: int = 2, pt: Optional[int] = None):
     return out
 
 
+def gather_rows(src, idx, dst, R, D, ld_src=None, ld_dst=None):
+    check(lib().orv_gather_rows(_p(src), ld_src or D, _p(idx), _p(dst), ld_dst or D, R, D, _stream()), "orv_gather_rows")
+    return dst
+
+
+def scatter_gated_rows(y, idx, gate, gate_b, x, R, D, seq, n_text, ldy=None, ldx=None):
+    check(lib().orv_scatter_gated_rows(_p(y), ldy or D, _p(idx), _p(gate), gate_b, _p(x), ldx or D, R, D, seq, n_text,
+                                       _stream()), "orv_scatter_gated_rows")
+    return x
+
+
 def add_rows(a, amap: Optional[RowMap], b, out, col_off, M, D, lda=None, ldb=None, ldo=None):
     _need(a, BF16, "a"), _need(b, BF16, "b"), _need(out, BF16, "out")
     check(lib().orv_add_rows(_p(a), lda or D, amap or RowMap(0, 0, 0), _p(b), ldb or D, _p(out), ldo or D, col_off, M, D,

@@ -297,3 +297,29 @@ def test_modulation_tables(B, T, E, width, text, with_act):
             close(out[i, :, 0], ref_t, rtol=1e-2, afrac=5e-3)
         else:
             assert torch.all(out[i, :, 0] == 0)
+
+
+def test_gather_and_gated_scatter_rows():
+    """MVBlock token regrouping (cogvideox_control.py:328-331,:346-347): exact permutation, one-rounding gated add."""
+    from orv_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    Bv, S, Nt, D = 4, 20, 4, 128
+    x = torch.randn(Bv * S, D, generator=g).to(dev, torch.bfloat16)
+    R = 50
+    idx = torch.randperm(Bv * S, generator=g)[:R].to(torch.int32).to(dev)
+    dst = torch.empty(R, D, dtype=torch.bfloat16, device=dev)
+    ops.gather_rows(x, idx, dst, R, D)
+    assert torch.equal(dst, x[idx.long()])
+    y = torch.randn(R, D, generator=g).to(dev, torch.bfloat16)
+    gate = torch.randn(Bv, 3 * D, generator=g).to(dev)
+    x2 = x.clone()
+    ops.scatter_gated_rows(y, idx, gate[:, 2 * D:], 3 * D, x2, R, D, S, Nt)
+    ref = x.clone().float()
+    il = idx.long()
+    vid = (il % S) >= Nt
+    ref[il[vid]] += gate[il[vid] // S, 2 * D:] * y[vid].float()
+    # fp32 fma vs mul+add may flip a rare bf16 rounding tie: allow one bf16 ulp on <0.1% of the elements
+    d = (x2.float() - ref.to(torch.bfloat16).float()).abs()
+    assert (d > 0).float().mean().item() < 1e-3 and d.max().item() <= 2 ** -5
+    assert torch.equal(x2[il[~vid]], x[il[~vid]])

@@ -12,7 +12,7 @@ from oracle import dit  # noqa: E402  (checker only)
 
 BF = torch.bfloat16
 FWD = ["fwd_actions", "fwd_actions_masked", "fwd_cond", "fwd_noactions", "fwd_nomod", "fwd_nomod_noactions", "fwd_rope", "fwd_pt2_ofs",
-       "fwd_train_recon"]
+       "fwd_train_recon", "fwd_multiview"]
 
 
 def rel_l2(got, ref):
@@ -42,8 +42,10 @@ def test_forward_matches_reference_golden(name):
             ctrl[key] = ins[key].to(dev, BF)
     rope = (ins["rope_cos"].to(dev), ins["rope_sin"].to(dev)) if "rope_cos" in ins else None
     ofs = None if extra["ofs"] is None else torch.full((1,), float(extra["ofs"]), device=dev)
-    out, is_mask, recon = m(ins["hidden_states"].to(dev, BF), ins["encoder_hidden_states"].to(dev, BF), ctrl,
-                            ins["timestep"].to(dev), ofs=ofs, image_rotary_emb=rope, return_dict=False)
+    with torch.no_grad():     # grad-enabled calls take the training path, covered by test_gpu_training.py
+        out, is_mask, recon = m(ins["hidden_states"].to(dev, BF), ins["encoder_hidden_states"].to(dev, BF), ctrl,
+                                ins["timestep"].to(dev), ofs=ofs, image_rotary_emb=rope, return_dict=False,
+                                num_views=extra["num_views"])
     assert out.shape == outs["sample"].shape and out.dtype == BF
     assert rel_l2(out, outs["sample"]) <= 2e-2
     if "is_action_mask" in outs:
