@@ -483,14 +483,12 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             raise RuntimeError(f"orv_amd kernels are bf16: call model.to(torch.bfloat16) (got {self.dtype})")
         if num_views > 1 and not c.multiview:
             raise ValueError("num_views > 1 needs a multiview=True model (pos_embedding_v / mv_blocks, :592-606)")
-        if c.multiview and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("the hand-written backward covers the single-view SFT step; run multiview under no_grad")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # training step (train_cogvideox_control_to_video_sft.py:1051-1093): forward that saves activations, with the
             # hand-written backward attached to autograd as one node
             from .training import forward_with_grad
             out, mask, recon = forward_with_grad(self, hidden_states, encoder_hidden_states, controls_or_guidances, timestep,
-                                                 ofs, image_rotary_emb)
+                                                 ofs, image_rotary_emb, num_views, image_rotary_emb_view)
             if not return_dict:
                 return (out, mask, recon)
             return Transformer3DModelTrajOutput(sample=out, is_action_mask=mask, actions_recon=recon)

@@ -106,6 +106,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[N
                     v[2] *= gelu_tanh_grad(bf2f(uu.y & 0xffff)); v[3] *= gelu_tanh_grad(bf2f(uu.y >> 16));
                 }
                 uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+#ifdef ORV_GEMM_ABLATE_NOSTORE
+                if (p.dbg == 12345)
+#endif
                 *(uint2*)(crow + n) = o;
             }
         }

@@ -75,13 +75,95 @@ def _dgrad(dY2d, W, dX, M, N, K, epilogue=0, R=None):
     return dX
 
 
-def forward_train(model, hidden_states, encoder_hidden_states, controls, timestep, ofs=None, image_rotary_emb=None):
+class _AttnBufs:
+    """Per-(batch, sequence) scratch of the attention forward/backward (not saved activations)."""
+
+    def __init__(self, B_, S_, heads, dev):
+        self.s_pad = (S_ + 63) // 64 * 64
+        z = lambda: torch.zeros(B_, heads, 64, self.s_pad, dtype=BF16, device=dev)
+        self.work = torch.empty(B_ * S_, 3 * heads * 64, dtype=BF16, device=dev)
+        self.vT, self.qT, self.kT, self.doT = z(), z(), z(), z()
+        self.nl = torch.empty(B_, heads, self.s_pad, dtype=torch.float32, device=dev)
+        self.nd = torch.empty(B_, heads, self.s_pad, dtype=torch.float32, device=dev)
+
+
+def _attn_forward(at, xn, ly, bufs, B_, S_, n_text, heads, rope, scale):
+    """QKV GEMM -> qk LayerNorm / RoPE / V^T -> flash attention; keeps qkv_raw, att, lse on ``ly``."""
+    D = heads * 64
+    M_ = B_ * S_
+    dev = xn.device
+    wqkv, bqkv = at.packed_qkv()
+    ly.qkv_raw = torch.empty(M_, 3 * D, dtype=BF16, device=dev)
+    ops.gemm(xn, wqkv, bqkv, ly.qkv_raw, M_, 3 * D, D)
+    bufs.work.copy_(ly.qkv_raw)
+    ops.qkv_prep(bufs.work, bufs.vT, at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, rope, B_, S_, heads,
+                 n_text, bufs.s_pad, at.eps, q_premul=scale * LOG2E)
+    ly.att = torch.empty(M_, D, dtype=BF16, device=dev)
+    ly.lse = torch.empty(B_, heads, S_, dtype=torch.float32, device=dev)
+    ops.attention_fwd(bufs.work, bufs.vT, ly.att, B_, S_, heads, bufs.s_pad, 1.0 / LOG2E, lse=ly.lse)
+
+
+def _attn_backward(at, ly, xn, datt, bufs, B_, S_, n_text, heads, rope, scale, grads, f32_to_param_grad):
+    """Adjoint of ``_attn_forward``: datt [M, D] -> gradient w.r.t. xn [M, D]; parameter gradients into ``grads``."""
+    D = heads * 64
+    M_ = B_ * S_
+    dev = xn.device
+    z32 = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+    bufs.work.copy_(ly.qkv_raw)
+    ops.qkv_prep(bufs.work, bufs.vT, at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, rope, B_, S_, heads,
+                 n_text, bufs.s_pad, at.eps, q_premul=scale * LOG2E)
+    ops.head_transpose(bufs.work, 0, bufs.qT, B_, S_, heads, bufs.s_pad, ld=3 * D)
+    ops.head_transpose(bufs.work, D, bufs.kT, B_, S_, heads, bufs.s_pad, ld=3 * D)
+    ops.head_transpose(datt, 0, bufs.doT, B_, S_, heads, bufs.s_pad, ld=D)
+    dqkv = torch.empty(M_, 3 * D, dtype=BF16, device=dev)
+    ops.attention_bwd(bufs.work, bufs.qT, bufs.kT, ly.att, datt, bufs.doT, ly.lse, bufs.nl, bufs.nd, dqkv, B_, S_, heads,
+                      bufs.s_pad, scale)
+    dgq, dbq, dgk, dbk = z32(64), z32(64), z32(64), z32(64)
+    ops.qkv_prep_bwd(ly.qkv_raw, dqkv, at.norm_q.weight, at.norm_k.weight, rope, dgq, dbq, dgk, dbk, B_, S_, heads, n_text,
+                     at.eps)
+    f32_to_param_grad(at.norm_q.weight, dgq), f32_to_param_grad(at.norm_q.bias, dbq)
+    f32_to_param_grad(at.norm_k.weight, dgk), f32_to_param_grad(at.norm_k.bias, dbk)
+    wqkv, _ = at.packed_qkv()
+    lins = (at.to_q, at.to_k, at.to_v)
+    if any(l.weight.requires_grad for l in lins):
+        dwqkv = torch.zeros(3 * D, D, dtype=BF16, device=dev)
+        _wgrad(dqkv, xn, dwqkv, M_, 3 * D, D)
+        for j, lin in enumerate(lins):
+            if lin.weight.requires_grad:
+                _acc_grad(grads, lin.weight).add_(dwqkv[j * D:(j + 1) * D])
+    if lins[0].bias is not None and any(l.bias.requires_grad for l in lins):
+        bs = z32(3 * D)
+        ops.colsum(dqkv, bs, M_, 3 * D)
+        for j, lin in enumerate(lins):
+            f32_to_param_grad(lin.bias, bs[j * D:(j + 1) * D])
+    dxn = torch.empty(M_, D, dtype=BF16, device=dev)
+    _dgrad(dqkv, wqkv, dxn, M_, 3 * D, D)
+    return dxn
+
+
+def _mv_index(b, v, f, Nt, P, S, dev):
+    """Row index of the '(b v) (f s) -> (b f) (v s)' regrouping (text '(b v) n -> (b f) (v n)'), as in
+    ``CogVideoXTransformer3DModelTraj._mv_state``."""
+    bi = torch.arange(b, device=dev).view(b, 1, 1, 1)
+    fi = torch.arange(f, device=dev).view(1, f, 1, 1)
+    vi = torch.arange(v, device=dev).view(1, 1, v, 1)
+    txt = ((bi * v + vi) * S + torch.arange(Nt, device=dev).view(1, 1, 1, Nt)).expand(b, f, v, Nt)
+    vid = (bi * v + vi) * S + Nt + fi * P + torch.arange(P, device=dev).view(1, 1, 1, P)
+    return torch.cat([txt.reshape(b, f, v * Nt), vid.reshape(b, f, v * P)], dim=2).to(torch.int32).contiguous().view(-1)
+
+
+def forward_train(model, hidden_states, encoder_hidden_states, controls, timestep, ofs=None, image_rotary_emb=None,
+                  num_views=1, image_rotary_emb_view=None):
     """Same arithmetic as ``CogVideoXTransformer3DModelTraj.forward`` (inference kernels), keeping what backward needs."""
     c = model.config
     dev = hidden_states.device
-    if c.multiview or c.visual_guidance:
-        raise NotImplementedError("training path covers the single-view trajectory model (BASELINE config 3) for now")
+    nv_ = num_views
+    if nv_ > 1:                                                                      # :756-758
+        bb, vf = hidden_states.shape[:2]
+        hidden_states = hidden_states.reshape(bb * nv_, vf // nv_, *hidden_states.shape[2:])
+        encoder_hidden_states = encoder_hidden_states.repeat_interleave(nv_, dim=0)
     B, T, C, Hh, Ww = hidden_states.shape
+    b0 = B // nv_
     p, pt = c.patch_size, c.patch_size_t
     D, heads, E = model.inner_dim, c.num_attention_heads, c.time_embed_dim
     mod_text = bool(c.modulate_encoder_hidden_states)
@@ -91,22 +173,30 @@ def forward_train(model, hidden_states, encoder_hidden_states, controls, timeste
     Nv = Tq * P
     S = Nt + Nv
     M = B * S
-    s_pad = (S + 63) // 64 * 64
     sv = _Saved()
-    sv.dims = dict(B=B, T=T, Hh=Hh, Ww=Ww, D=D, heads=heads, E=E, Nt=Nt, Nv=Nv, S=S, M=M, s_pad=s_pad, P=P, mod_text=mod_text)
+    sv.dims = dict(B=B, T=T, Hh=Hh, Ww=Ww, D=D, heads=heads, E=E, Nt=Nt, Nv=Nv, S=S, M=M, P=P, mod_text=mod_text, nv=nv_,
+                   b0=b0)
     e = lambda *shape, dt=BF16: torch.empty(*shape, dtype=dt, device=dev)
 
     # conditioning branch (tiny): matmuls in HIP, activations' adjoints later via torch on [B, T, E] tensors
     tvec = torch.as_tensor(timestep, device=dev).reshape(-1).to(torch.float32)
-    if tvec.numel() == 1 and B > 1:
-        tvec = tvec.expand(B)
+    if tvec.numel() == 1 and b0 > 1:
+        tvec = tvec.expand(b0)
     te = model.time_embedding
     sv.t_emb = ops.timestep_embedding(tvec.contiguous(), D, c.flip_sin_to_cos, c.freq_shift)
     sv.te_u1 = ops.skinny_linear(sv.t_emb, te.linear_1.weight, te.linear_1.bias)                 # pre-SiLU
     sv.te_h1 = torch.nn.functional.silu(sv.te_u1.float()).to(BF16)
     temb = ops.skinny_linear(sv.te_h1, te.linear_2.weight, te.linear_2.bias)
-    if model.ofs_embedding is not None:
-        raise NotImplementedError("ofs embedding (CogVideoX1.5) training adjoint not built yet")
+    sv.has_ofs = model.ofs_embedding is not None
+    if sv.has_ofs:                                                                   # :771-775
+        oe = model.ofs_embedding
+        ovec = torch.as_tensor(ofs, device=dev).reshape(-1).to(torch.float32)
+        sv.o_emb = ops.timestep_embedding(ovec.contiguous(), c.ofs_embed_dim, c.flip_sin_to_cos, c.freq_shift)
+        sv.oe_u1 = ops.skinny_linear(sv.o_emb, oe.linear_1.weight, oe.linear_1.bias)
+        sv.oe_h1 = torch.nn.functional.silu(sv.oe_u1.float()).to(BF16)
+        temb = temb + ops.skinny_linear(sv.oe_h1, oe.linear_2.weight, oe.linear_2.bias)
+    if nv_ > 1:
+        temb = temb.repeat_interleave(nv_, dim=0).contiguous()
     sv.temb = temb
 
     pe = model.patch_embed
@@ -114,16 +204,22 @@ def forward_train(model, hidden_states, encoder_hidden_states, controls, timeste
     x = e(M, D)
     a2, w2 = _pad_k(sv.tokens.view(B * Nv, -1), pe.proj.weight.reshape(D, -1))
     pos = pe.video_pos_table(T, Hh, Ww, dev)
-    ops.gemm(a2, w2, pe.proj.bias, x, B * Nv, D, a2.shape[1], epilogue=2 if pos is not None else 0, R=pos, r_mod=Nv, ldr=D,
-             cmap=ops.rowmap(Nv, S, Nt))
+    cpos = pos
+    pos_mod = Nv
+    if nv_ > 1:
+        pos, pos_mod = model._view_pos_table(pos, nv_, T, P, dev), nv_ * Nv
+    vmap = ops.rowmap(Nv, S, Nt)
+    ops.gemm(a2, w2, pe.proj.bias, x, B * Nv, D, a2.shape[1], epilogue=2 if pos is not None else 0, R=pos, r_mod=pos_mod, ldr=D,
+             cmap=vmap)
     if mod_text:
         sv.text2d = encoder_hidden_states.to(BF16).reshape(B * Nt, -1).contiguous()
         a2, w2 = _pad_k(sv.text2d, pe.text_proj.weight)
         ops.gemm(a2, w2, pe.text_proj.bias, x, B * Nt, D, a2.shape[1], cmap=ops.rowmap(Nt, S, 0))
 
-    action_emb = is_mask = None
+    action_emb = is_mask = actions_recon = None
     actions = controls.get('actions', None)
     sv.has_actions = actions is not None
+    sv.has_recon = False
     if actions is not None:
         actions = actions.to(device=dev)
         res = (actions.size(1) + 1) % 4
@@ -132,21 +228,63 @@ def forward_train(model, hidden_states, encoder_hidden_states, controls, timeste
             actions = torch.cat([actions.new_zeros((actions.shape[0], padf, actions.shape[2])), actions], dim=1)
         ae = model.action_embed
         xa = torch.cat([torch.zeros_like(actions[:, :1]), actions], dim=1)
-        xa = xa.reshape(B, (actions.shape[1] + 1) // ae.compress_ratio, -1)
+        xa = xa.reshape(b0, (actions.shape[1] + 1) // ae.compress_ratio, -1)
         if ae.patch_size_t > 1:
-            xa = xa.reshape(B, xa.shape[1] // ae.patch_size_t, -1)
+            xa = xa.reshape(b0, xa.shape[1] // ae.patch_size_t, -1)
         Ta = xa.shape[1]
-        sv.ae_in = xa.reshape(B * Ta, -1).to(BF16).contiguous()
+        sv.ae_in = xa.reshape(b0 * Ta, -1).to(BF16).contiguous()
         sv.ae_u = ops.skinny_linear(sv.ae_in, ae.mlp[0].weight, ae.mlp[0].bias)
         sv.ae_h = torch.nn.functional.gelu(sv.ae_u.float(), approximate="tanh").to(BF16)
-        emb = ops.skinny_linear(sv.ae_h, ae.mlp[3].weight, ae.mlp[3].bias).view(B, Ta, E)
-        is_mask = ae.forced_mask.to(dev, torch.bool) if ae.forced_mask is not None else torch.rand(B, device=dev) < 0.1
+        emb = ops.skinny_linear(sv.ae_h, ae.mlp[3].weight, ae.mlp[3].bias).view(b0, Ta, E)
+        is_mask = ae.forced_mask.to(dev, torch.bool) if ae.forced_mask is not None else torch.rand(b0, device=dev) < 0.1
         if ae.mask:
             emb = torch.where(is_mask[:, None, None], ae.mask_embed.weight[None].to(emb.dtype), emb)
         sv.is_mask = is_mask
+        if nv_ > 1:                                                                  # :815-816
+            emb = emb.repeat_interleave(nv_, dim=0)
         action_emb = emb.contiguous()
+        if model.training and c.recon_action and model.action_recon is not None:    # :822-825, components.py:92-104
+            ar = model.action_recon
+            sv.has_recon, sv.ar_pad = True, padf
+            sv.ar_in = action_emb.reshape(B * Ta, E)
+            sv.ar_u = ops.skinny_linear(sv.ar_in, ar.mlp[0].weight, ar.mlp[0].bias)
+            sv.ar_h = torch.nn.functional.gelu(sv.ar_u.float(), approximate="tanh").to(BF16)
+            y = ops.skinny_linear(sv.ar_h, ar.mlp[2].weight, ar.mlp[2].bias).view(B, Ta, -1)
+            if ar.compress_ratio > 1:
+                y = y.reshape(B, int(Ta * ar.compress_ratio), y.shape[-1] // ar.compress_ratio)
+            actions_recon = y[:, 1 + padf:].contiguous()
     sv.action_emb = action_emb
+
+    # occupancy-derived visual guidance (:828-858)
+    sv.ctrl_tokens = []
+    if c.visual_guidance:
+        ctoks = []
+        for key in ('depths', 'labels'):
+            cm = controls.get(key, None)
+            if cm is None:
+                continue
+            if nv_ > 1:
+                cm = cm.reshape(cm.shape[0] * nv_, cm.shape[1] // nv_, *cm.shape[2:])
+            tk = ops.patchify(cm.to(device=dev, dtype=BF16), None, p, pt)
+            a2c, w2c = _pad_k(tk.view(B * Nv, -1), pe.proj.weight.reshape(D, -1))
+            ctok = e(B * Nv, D)
+            ops.gemm(a2c, w2c, pe.proj.bias, ctok, B * Nv, D, a2c.shape[1], epilogue=2 if cpos is not None else 0, R=cpos,
+                     r_mod=Nv, ldr=D)
+            ctoks.append(ctok)
+            sv.ctrl_tokens.append(tk.view(B * Nv, -1))
+        if ctoks:
+            assert len(ctoks) == model.num_control_keys, \
+                f'Mismatched number of controls: {len(ctoks)=} but {model.num_control_keys=}.'
+            K2 = model.num_control_keys * D
+            sv.comb = e(B * Nv, K2)
+            for jx, ctok in enumerate(ctoks):
+                ops.add_rows(x, vmap, ctok, sv.comb, jx * D, B * Nv, D, ldo=K2)
+            icl = model.initial_combine_linear
+            ops.gemm(sv.comb, icl.weight, icl.bias, x, B * Nv, D, K2, epilogue=2, R=x, ldr=D, cmap=vmap)
+
     Ta = action_emb.shape[1] if action_emb is not None else 1
+    if Nv % Ta:
+        raise ValueError(f"{Nv} video tokens cannot be split over {Ta} action frames")
     per_group = Nv // Ta if action_emb is not None else 0
     G = 1 + Ta
     sv.dims.update(Ta=Ta, G=G, per_group=per_group)
@@ -160,13 +298,49 @@ def forward_train(model, hidden_states, encoder_hidden_states, controls, timeste
     if image_rotary_emb is not None:
         rope = tuple(r.to(device=dev, dtype=torch.float32).contiguous() for r in image_rotary_emb)
     sv.rope = rope
+    sv.rope_view = None
+    if image_rotary_emb_view is not None:
+        sv.rope_view = tuple(r.to(device=dev, dtype=torch.float32).contiguous() for r in image_rotary_emb_view)
 
     mb, mg = G * 3 * D, 3 * D
     scale = 1.0 / math.sqrt(c.attention_head_dim)
-    work = e(M, 3 * D)
-    vT = torch.zeros(B, heads, 64, s_pad, dtype=BF16, device=dev)
+    bufs = _AttnBufs(B, S, heads, dev)
+    sv.mv = None
+    if c.multiview:                                                                  # :273-348
+        if Nv % T:
+            raise ValueError(f"{Nv} video tokens cannot be split over {T} frames for the multiview blocks")
+        Pm = Nv // T
+        mv = _Saved()
+        mv.idx = _mv_index(b0, nv_, T, Nt, Pm, S, dev)
+        mv.Sm, mv.Bm = nv_ * (Nt + Pm), b0 * T
+        mv.R = mv.Bm * mv.Sm
+        mv.n_text = nv_ * Nt
+        wmv, bmv = model._mv_pointer_tables(dev)
+        mv.mod = ops.modulation_tables(temb, None, wmv, bmv, L, B, 1, E, 3 * D, mod_text)        # [L, B, 2, 3D]
+        mv.grp0 = ops.groups(S, Nt, 0)
+        mv.bufs = _AttnBufs(mv.Bm, mv.Sm, heads, dev)
+        # gate of (b f)-batch row groups {text, view 0, view 1, ...}: text rows of the attention output are dropped (zero gate)
+        mv.grp = ops.groups(mv.Sm, mv.n_text, Pm)
+        mv.layers = []
+        sv.mv = mv
     sv.layers = []
     for i, blk in enumerate(model.transformer_blocks):
+        if sv.mv is not None:
+            mblk, mly, m = model.mv_blocks[i], _Saved(), mv.mod[i]
+            mly.x_in = x
+            xn = e(M, D)
+            ops.layernorm_modulate(x, xn, mblk.norm1.norm.weight, mblk.norm1.norm.bias, m[..., D:2 * D], m[..., :D],
+                                   2 * 3 * D, 3 * D, mv.grp0, B, D, c.norm_eps)
+            mly.xm = e(mv.R, D)
+            ops.gather_rows(xn, mv.idx, mly.xm, mv.R, D)
+            _attn_forward(mblk.attn1, mly.xm, mly, mv.bufs, mv.Bm, mv.Sm, mv.n_text, heads, sv.rope_view, scale)
+            mly.ao, mly.y = e(mv.R, D), e(mv.R, D)
+            wo = mblk.attn1.to_out[0]
+            ops.gemm(mly.att, wo.weight, wo.bias, mly.ao, mv.R, D, D)
+            ops.gemm(mly.ao, mblk.proj_out.weight, mblk.proj_out.bias, mly.y, mv.R, D, D)
+            x = x.clone()
+            ops.scatter_gated_rows(mly.y, mv.idx, m[:, 1, 2 * D:], 2 * 3 * D, x, mv.R, D, S, Nt)
+            mv.layers.append(mly)
         m1, m2 = mod[2 * i], mod[2 * i + 1]
         at = blk.attn1
         ly = _Saved()
@@ -174,15 +348,7 @@ def forward_train(model, hidden_states, encoder_hidden_states, controls, timeste
         ly.xn1 = e(M, D)
         ops.layernorm_modulate(x, ly.xn1, blk.norm1.norm.weight, blk.norm1.norm.bias, m1[..., D:2 * D], m1[..., :D], mb, mg,
                                grp, B, D, c.norm_eps)
-        wqkv, bqkv = at.packed_qkv()
-        ly.qkv_raw = e(M, 3 * D)
-        ops.gemm(ly.xn1, wqkv, bqkv, ly.qkv_raw, M, 3 * D, D)
-        work.copy_(ly.qkv_raw)
-        ops.qkv_prep(work, vT, at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, rope, B, S, heads, Nt,
-                     s_pad, at.eps, q_premul=scale * LOG2E)
-        ly.att = e(M, D)
-        ly.lse = e(B, heads, S, dt=torch.float32)
-        ops.attention_fwd(work, vT, ly.att, B, S, heads, s_pad, 1.0 / LOG2E, lse=ly.lse)
+        _attn_forward(at, ly.xn1, ly, bufs, B, S, Nt, heads, rope, scale)
         ly.x1, ly.y1 = e(M, D), e(M, D)
         ops.gemm(ly.att, at.to_out[0].weight, at.to_out[0].bias, ly.x1, M, D, D, epilogue=2, R=x, ldr=D, gate=m1[..., 2 * D:],
                  gate_b=mb, gate_g=mg, grp=grp, Y=ly.y1, ldy=D)
@@ -207,23 +373,35 @@ def forward_train(model, hidden_states, encoder_hidden_states, controls, timeste
     ops.layernorm_modulate(sv.vis, sv.vis2, no.norm.weight, no.norm.bias, modf[..., D:], modf[..., :D], G * 2 * D, 2 * D, gv, B,
                            D, c.norm_eps)
     fo = model.proj_out.weight.shape[0]
-    if fo % 64:
-        raise NotImplementedError("proj_out width must be a multiple of 64 on the training path")
-    out_tok = e(B * Nv, fo)
-    ops.gemm(sv.vis2, model.proj_out.weight, model.proj_out.bias, out_tok, B * Nv, fo, D)
+    sv.fo_pad = (fo + 63) // 64 * 64
+    wo_, bo_ = model.proj_out.weight, model.proj_out.bias
+    if sv.fo_pad != fo:                       # CogVideoX1.5 (p_t = 2): 128 -> fits; tiny test configs: zero-padded columns
+        wo_ = torch.nn.functional.pad(wo_, (0, 0, 0, sv.fo_pad - fo)).contiguous()
+        bo_ = torch.nn.functional.pad(bo_, (0, sv.fo_pad - fo)).contiguous() if bo_ is not None else None
+    out_tok = e(B * Nv, sv.fo_pad)
+    ops.gemm(sv.vis2, wo_, bo_, out_tok, B * Nv, sv.fo_pad, D)
+    if sv.fo_pad != fo:
+        out_tok = out_tok[:, :fo].contiguous()
     c_out = fo // (p * p * (pt or 1))
     output = ops.unpatchify(out_tok, B, T, c_out, Hh, Ww, p, pt)
-    actions_recon = None
+    if nv_ > 1:                                                                      # :941
+        output = output.reshape(b0, nv_ * T, *output.shape[2:])
     return output, is_mask, actions_recon, sv
 
 
-def backward(model, sv, dout) -> Dict[int, torch.Tensor]:
-    """Gradients of every trainable parameter (bf16, keyed by id(param)) given dL/d(sample)."""
+def _gelu_tanh_grad(u):
+    a_, b_ = 0.7978845608028654, 0.044715
+    th = torch.tanh(a_ * (u + b_ * u ** 3))
+    return 0.5 * (1 + th) + 0.5 * u * (1 - th * th) * a_ * (1 + 3 * b_ * u * u)
+
+
+def backward(model, sv, dout, drecon=None) -> Dict[int, torch.Tensor]:
+    """Gradients of every trainable parameter (bf16, keyed by id(param)) given dL/d(sample) (and dL/d(actions_recon))."""
     c = model.config
     d = sv.dims
     B, T, Hh, Ww, D, heads, E = d["B"], d["T"], d["Hh"], d["Ww"], d["D"], d["heads"], d["E"]
-    Nt, Nv, S, M, s_pad, G, Ta, per_group = d["Nt"], d["Nv"], d["S"], d["M"], d["s_pad"], d["G"], d["Ta"], d["per_group"]
-    mod_text = d["mod_text"]
+    Nt, Nv, S, M, G, Ta, per_group = d["Nt"], d["Nv"], d["S"], d["M"], d["G"], d["Ta"], d["per_group"]
+    mod_text, nv_, b0 = d["mod_text"], d["nv"], d["b0"]
     dev = dout.device
     p, pt = c.patch_size, c.patch_size_t
     grads: Dict[int, torch.Tensor] = {}
@@ -238,18 +416,40 @@ def backward(model, sv, dout) -> Dict[int, torch.Tensor]:
     scale = 1.0 / math.sqrt(c.attention_head_dim)
 
     def f32_to_param_grad(param, g32):
+        if param is None or not param.requires_grad:
+            return
         acc = _acc_grad(grads, param)
         acc.add_(g32.to(BF16).view_as(acc))
 
+    def wgrad_p(param, dY2d, X2d, M_, N_, K_):
+        if param.requires_grad:                 # frozen weights (e.g. everything but mv_blocks, :641-656) cost no GEMM
+            _wgrad(dY2d, X2d, _acc_grad(grads, param), M_, N_, K_)
+
+    def bias_p(param, dY2d, M_, N_):
+        if param is not None and param.requires_grad:
+            bs = z32(N_)
+            ops.colsum(dY2d, bs, M_, N_)
+            f32_to_param_grad(param, bs)
+
     # ---- head: unpatchify^T = patchify ; proj_out ; norm_out ; norm_final ----
+    if nv_ > 1:
+        dout = dout.reshape(B, T, *dout.shape[2:])
     fo = model.proj_out.weight.shape[0]
     d_tok = ops.patchify(dout.to(BF16).contiguous(), None, p, pt).view(B * Nv, fo)
-    _wgrad(d_tok, sv.vis2, _acc_grad(grads, model.proj_out.weight), B * Nv, fo, D)
-    bsum = z32(fo)
-    ops.colsum(d_tok, bsum, B * Nv, fo)
-    f32_to_param_grad(model.proj_out.bias, bsum)
+    wo_ = model.proj_out.weight
+    if sv.fo_pad != fo:
+        d_tok = torch.nn.functional.pad(d_tok, (0, sv.fo_pad - fo)).contiguous()
+        wo_ = torch.nn.functional.pad(wo_.detach(), (0, 0, 0, sv.fo_pad - fo)).contiguous()
+    if model.proj_out.weight.requires_grad:
+        gwo = torch.zeros(sv.fo_pad, D, dtype=BF16, device=dev)
+        _wgrad(d_tok, sv.vis2, gwo, B * Nv, sv.fo_pad, D)
+        _acc_grad(grads, model.proj_out.weight).add_(gwo[:fo])
+    if model.proj_out.bias is not None and model.proj_out.bias.requires_grad:
+        bsum = z32(sv.fo_pad)
+        ops.colsum(d_tok, bsum, B * Nv, sv.fo_pad)
+        f32_to_param_grad(model.proj_out.bias, bsum[:fo])
     dvis2 = e(B * Nv, D)
-    _dgrad(d_tok, model.proj_out.weight, dvis2, B * Nv, fo, D)
+    _dgrad(d_tok, wo_, dvis2, B * Nv, sv.fo_pad, D)
     no = model.norm_out
     dvis = e(B * Nv, D)
     dg, db_ = z32(D), z32(D)
@@ -263,10 +463,11 @@ def backward(model, sv, dout) -> Dict[int, torch.Tensor]:
     f32_to_param_grad(model.norm_final.weight, dg), f32_to_param_grad(model.norm_final.bias, db_)
 
     # ---- blocks, last to first ----
-    work = e(M, 3 * D)
-    vT = torch.zeros(B, heads, 64, s_pad, dtype=BF16, device=dev)
-    qT, kT, doT = (torch.zeros(B, heads, 64, s_pad, dtype=BF16, device=dev) for _ in range(3))
-    nl, nd = e(B, heads, s_pad, dt=torch.float32), e(B, heads, s_pad, dt=torch.float32)
+    bufs = _AttnBufs(B, S, heads, dev)
+    mv = sv.mv
+    if mv is not None:
+        dmv = z32(L, B, 2, 3 * D)
+        ones_gate = torch.ones(B, D, dtype=torch.float32, device=dev)
     for i in reversed(range(L)):
         blk, ly = model.transformer_blocks[i], sv.layers[i]
         at = blk.attn1
@@ -277,12 +478,12 @@ def backward(model, sv, dout) -> Dict[int, torch.Tensor]:
         # FFN branch: x2 = x1 + g2 * y2
         dy2 = e(M, D)
         ops.gated_residual_bwd(dx, ly.y2, m2[..., 2 * D:], dm2[..., 2 * D:], dy2, mb, mg, grp, B, D)
-        _wgrad(dy2, ly.h, _acc_grad(grads, f2.weight), M, D, FF)
-        bs = z32(D); ops.colsum(dy2, bs, M, D); f32_to_param_grad(f2.bias, bs)
+        wgrad_p(f2.weight, dy2, ly.h, M, D, FF)
+        bias_p(f2.bias, dy2, M, D)
         du = e(M, FF)
         _dgrad(dy2, f2.weight, du, M, D, FF, epilogue=3, R=ly.u)          # GELU adjoint fused
-        _wgrad(du, ly.xn2, _acc_grad(grads, f0.weight), M, FF, D)
-        bs = z32(FF); ops.colsum(du, bs, M, FF); f32_to_param_grad(f0.bias, bs)
+        wgrad_p(f0.weight, du, ly.xn2, M, FF, D)
+        bias_p(f0.bias, du, M, FF)
         dxn2 = e(M, D)
         _dgrad(du, f0.weight, dxn2, M, FF, D)
         dx1 = e(M, D)
@@ -294,55 +495,93 @@ def backward(model, sv, dout) -> Dict[int, torch.Tensor]:
         dy1 = e(M, D)
         ops.gated_residual_bwd(dx1, ly.y1, m1[..., 2 * D:], dm1[..., 2 * D:], dy1, mb, mg, grp, B, D)
         wo = at.to_out[0]
-        _wgrad(dy1, ly.att, _acc_grad(grads, wo.weight), M, D, D)
-        bs = z32(D); ops.colsum(dy1, bs, M, D); f32_to_param_grad(wo.bias, bs)
+        wgrad_p(wo.weight, dy1, ly.att, M, D, D)
+        bias_p(wo.bias, dy1, M, D)
         datt = e(M, D)
         _dgrad(dy1, wo.weight, datt, M, D, D)
-        work.copy_(ly.qkv_raw)
-        ops.qkv_prep(work, vT, at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, sv.rope, B, S, heads, Nt,
-                     s_pad, at.eps, q_premul=scale * LOG2E)
-        ops.head_transpose(work, 0, qT, B, S, heads, s_pad, ld=3 * D)
-        ops.head_transpose(work, D, kT, B, S, heads, s_pad, ld=3 * D)
-        ops.head_transpose(datt, 0, doT, B, S, heads, s_pad, ld=D)
-        dqkv = e(M, 3 * D)
-        ops.attention_bwd(work, qT, kT, ly.att, datt, doT, ly.lse, nl, nd, dqkv, B, S, heads, s_pad, scale)
-        dgq, dbq, dgk, dbk = z32(64), z32(64), z32(64), z32(64)
-        ops.qkv_prep_bwd(ly.qkv_raw, dqkv, at.norm_q.weight, at.norm_k.weight, sv.rope, dgq, dbq, dgk, dbk, B, S, heads, Nt,
-                         at.eps)
-        f32_to_param_grad(at.norm_q.weight, dgq), f32_to_param_grad(at.norm_q.bias, dbq)
-        f32_to_param_grad(at.norm_k.weight, dgk), f32_to_param_grad(at.norm_k.bias, dbk)
-        wqkv, _ = at.packed_qkv()
-        dwqkv = torch.zeros(3 * D, D, dtype=BF16, device=dev)
-        _wgrad(dqkv, ly.xn1, dwqkv, M, 3 * D, D)
-        for j, lin in enumerate((at.to_q, at.to_k, at.to_v)):
-            _acc_grad(grads, lin.weight).add_(dwqkv[j * D:(j + 1) * D])
-        bs = z32(3 * D); ops.colsum(dqkv, bs, M, 3 * D)
-        for j, lin in enumerate((at.to_q, at.to_k, at.to_v)):
-            if lin.bias is not None:
-                f32_to_param_grad(lin.bias, bs[j * D:(j + 1) * D])
-        dxn1 = e(M, D)
-        _dgrad(dqkv, wqkv, dxn1, M, 3 * D, D)
+        dxn1 = _attn_backward(at, ly, ly.xn1, datt, bufs, B, S, Nt, heads, sv.rope, scale, grads, f32_to_param_grad)
         dx0 = e(M, D)
         dg, db_ = z32(D), z32(D)
         ops.layernorm_modulate_bwd(dxn1, ly.x0, dx1, dx0, blk.norm1.norm.weight, blk.norm1.norm.bias, m1[..., D:2 * D],
                                    dm1[..., D:2 * D], dm1[..., :D], dg, db_, mb, mg, grp, B, D, c.norm_eps)
         f32_to_param_grad(blk.norm1.norm.weight, dg), f32_to_param_grad(blk.norm1.norm.bias, db_)
         dx = dx0
+        if mv is not None:
+            # MVBlock adjoint: x_out[idx[r]] = x_in[idx[r]] + gate[view] * y[r] on the video rows (text output dropped)
+            mblk, mly, m = model.mv_blocks[i], mv.layers[i], mv.mod[i]
+            Pm = Nv // T
+            dxm = e(mv.R, D)
+            ops.gather_rows(dx, mv.idx, dxm, mv.R, D)
+            # gate / its gradient laid out per (b f)-batch: group 0 = text (zero), 1 + v = view v
+            gate_mv = z32(b0, T, 1 + nv_, D)
+            gate_mv[:, :, 1:] = m[:, 1, 2 * D:].reshape(b0, 1, nv_, D)
+            dgate_mv = z32(b0 * T, 1 + nv_, D)
+            dy = e(mv.R, D)
+            ops.gated_residual_bwd(dxm, mly.y, gate_mv.view(b0 * T, 1 + nv_, D), dgate_mv, dy, (1 + nv_) * D, D, mv.grp, mv.Bm,
+                                   D)
+            dmv[i][:, 1, 2 * D:] += dgate_mv.view(b0, T, 1 + nv_, D)[:, :, 1:].sum(1).reshape(B, D)
+            wgrad_p(mblk.proj_out.weight, dy, mly.ao, mv.R, D, D)
+            bias_p(mblk.proj_out.bias, dy, mv.R, D)
+            dao = e(mv.R, D)
+            _dgrad(dy, mblk.proj_out.weight, dao, mv.R, D, D)
+            wo = mblk.attn1.to_out[0]
+            wgrad_p(wo.weight, dao, mly.att, mv.R, D, D)
+            bias_p(wo.bias, dao, mv.R, D)
+            datt = e(mv.R, D)
+            _dgrad(dao, wo.weight, datt, mv.R, D, D)
+            dxm_n = _attn_backward(mblk.attn1, mly, mly.xm, datt, mv.bufs, mv.Bm, mv.Sm, mv.n_text, heads, sv.rope_view, scale,
+                                   grads, f32_to_param_grad)
+            # gather^T: video rows are a bijection (scatter), text rows were replicated over the f frames (sum)
+            dxn = torch.zeros(M, D, dtype=BF16, device=dev)
+            ops.scatter_gated_rows(dxm_n, mv.idx, ones_gate, D, dxn, mv.R, D, S, Nt)
+            if Nt:
+                dtxt = dxm_n.view(b0, T, mv.Sm, D)[:, :, :mv.n_text].float().sum(1)            # [b, v*Nt, D]
+                dxn.view(B, S, D)[:, :Nt] = dtxt.view(B, Nt, D).to(BF16)
+            dx_in = e(M, D)
+            dg, db_ = z32(D), z32(D)
+            ops.layernorm_modulate_bwd(dxn, mly.x_in, dx, dx_in, mblk.norm1.norm.weight, mblk.norm1.norm.bias, m[..., D:2 * D],
+                                       dmv[i][..., D:2 * D], dmv[i][..., :D], dg, db_, 2 * 3 * D, 3 * D, mv.grp0, B, D,
+                                       c.norm_eps)
+            f32_to_param_grad(mblk.norm1.norm.weight, dg), f32_to_param_grad(mblk.norm1.norm.bias, db_)
+            dx = dx_in
 
-    # ---- patch embed (weights only; the latents need no gradient) ----
+    # ---- visual-guidance fuse (:846-858): x_vis += icl([x_vis + c0 | x_vis + c1]) ----
     pe = model.patch_embed
     dxj = dx.view(B, S, D)
     dvis_rows = dxj[:, Nt:].reshape(B * Nv, D).contiguous()
     wp = pe.proj.weight.reshape(D, -1)
-    gp = torch.zeros(D, sv.tokens.shape[-1], dtype=BF16, device=dev)
-    _wgrad(dvis_rows, sv.tokens.view(B * Nv, -1), gp, B * Nv, D, sv.tokens.shape[-1])
-    _acc_grad(grads, pe.proj.weight).add_(gp.view_as(pe.proj.weight))
-    bs = z32(D); ops.colsum(dvis_rows, bs, B * Nv, D); f32_to_param_grad(pe.proj.bias, bs)
+    Kp = sv.tokens.shape[-1]
+    gp = None
+    if pe.proj.weight.requires_grad:
+        gp = torch.zeros(D, Kp, dtype=BF16, device=dev)
+    dpb = z32(D)
+    if sv.ctrl_tokens:
+        icl = model.initial_combine_linear
+        K2 = icl.weight.shape[1]
+        wgrad_p(icl.weight, dvis_rows, sv.comb, B * Nv, D, K2)
+        bias_p(icl.bias, dvis_rows, B * Nv, D)
+        dcomb = e(B * Nv, K2)
+        _dgrad(dvis_rows, icl.weight, dcomb, B * Nv, D, K2)
+        acc32 = dvis_rows.float()
+        for jx, tk in enumerate(sv.ctrl_tokens):
+            dct = dcomb[:, jx * D:(jx + 1) * D].contiguous()
+            acc32 += dct.float()
+            if gp is not None:
+                _wgrad(dct, tk, gp, B * Nv, D, Kp)
+            ops.colsum(dct, dpb, B * Nv, D)
+        dvis_rows = acc32.to(BF16)
+
+    # ---- patch embed (weights only; the latents need no gradient) ----
+    if gp is not None:
+        _wgrad(dvis_rows, sv.tokens.view(B * Nv, -1), gp, B * Nv, D, Kp)
+        _acc_grad(grads, pe.proj.weight).add_(gp.view_as(pe.proj.weight))
+    ops.colsum(dvis_rows, dpb, B * Nv, D)
+    f32_to_param_grad(pe.proj.bias, dpb)
     if mod_text:
         dtxt = dxj[:, :Nt].reshape(B * Nt, D).contiguous()
         Kt = sv.text2d.shape[1]
-        _wgrad(dtxt, sv.text2d, _acc_grad(grads, pe.text_proj.weight), B * Nt, D, Kt)
-        bs = z32(D); ops.colsum(dtxt, bs, B * Nt, D); f32_to_param_grad(pe.text_proj.bias, bs)
+        wgrad_p(pe.text_proj.weight, dtxt, sv.text2d, B * Nt, D, Kt)
+        bias_p(pe.text_proj.bias, dtxt, B * Nt, D)
 
     # ---- modulation tables -> AdaLN linears -> conditioning (temb, action embedding) ----
     temb32 = sv.temb.float()
@@ -354,21 +593,24 @@ def backward(model, sv, dout) -> Dict[int, torch.Tensor]:
     cond_t = torch.nn.functional.silu(temb32).to(BF16).contiguous()
     d_cond_v, d_cond_t = z32(B * Ta, E), z32(B, E)
 
-    def table_bwd(lin, dtab, width, text):
-        dv = dtab[:, 1:].reshape(B * Ta, width).contiguous()
-        gw = _acc_grad(grads, lin.weight)
+    def table_bwd(lin, dtab, width, text, cv=cond_v, dcv=d_cond_v, rows_v=B * Ta):
+        dv = dtab[:, 1:].reshape(rows_v, width).contiguous()
+        train_w = lin.weight.requires_grad
+        gw = _acc_grad(grads, lin.weight) if train_w else torch.zeros_like(lin.weight, dtype=BF16)
         gb32 = z32(lin.weight.shape[0])
-        ops.small_linear_bwd(dv, cond_v, lin.weight[:width], gw[:width], gb32[:width], d_cond_v, B * Ta, width, E)
+        ops.small_linear_bwd(dv, cv, lin.weight[:width], gw[:width], gb32[:width], dcv, rows_v, width, E)
         if text:
             dt = dtab[:, 0].contiguous()
             ops.small_linear_bwd(dt, cond_t, lin.weight[width:], gw[width:], gb32[width:], d_cond_t, B, width, E)
-        if lin.bias is not None:
-            f32_to_param_grad(lin.bias, gb32)
+        f32_to_param_grad(lin.bias, gb32)
 
     for i, blk in enumerate(model.transformer_blocks):
         table_bwd(blk.norm1.linear, dmod[2 * i], 3 * D, mod_text)
         table_bwd(blk.norm2.linear, dmod[2 * i + 1], 3 * D, mod_text)
     table_bwd(model.norm_out.linear, dmodf, 2 * D, False)
+    if mv is not None:                         # MVBlock.norm1 has no action term: both row groups see silu(temb)
+        for i, mblk in enumerate(model.mv_blocks):
+            table_bwd(mblk.norm1.linear, dmv[i], 3 * D, mod_text, cv=cond_t, dcv=d_cond_t, rows_v=B)
 
     def dsilu(x):
         s = torch.sigmoid(x)
@@ -379,33 +621,67 @@ def backward(model, sv, dout) -> Dict[int, torch.Tensor]:
     if sv.action_emb is not None:
         ae = model.action_embed
         d_emb = d_pre_v
+        if sv.has_recon and drecon is not None:
+            # ActionRecon adjoint (components.py:92-104): un-slice (first row + pad rows dropped), Linear-GELU-Linear
+            ar = model.action_recon
+            n_out = ar.mlp[2].weight.shape[0]
+            dyr = z32(B, Ta * ar.compress_ratio, n_out // ar.compress_ratio)
+            dyr[:, 1 + sv.ar_pad:] = drecon.float()
+            dyr = dyr.reshape(B * Ta, n_out).contiguous()
+            w2r, w0r = ar.mlp[2], ar.mlp[0]
+            d_hr = z32(B * Ta, w2r.weight.shape[1])
+            gb = z32(n_out)
+            gw2 = _acc_grad(grads, w2r.weight) if w2r.weight.requires_grad else torch.zeros_like(w2r.weight, dtype=BF16)
+            ops.small_linear_bwd(dyr, sv.ar_h, w2r.weight, gw2, gb, d_hr, B * Ta, n_out, w2r.weight.shape[1])
+            f32_to_param_grad(w2r.bias, gb)
+            d_ur = (d_hr * _gelu_tanh_grad(sv.ar_u.float())).contiguous()
+            gb = z32(w0r.weight.shape[0])
+            d_in = z32(B * Ta, E)
+            gw0 = _acc_grad(grads, w0r.weight) if w0r.weight.requires_grad else torch.zeros_like(w0r.weight, dtype=BF16)
+            ops.small_linear_bwd(d_ur, sv.ar_in, w0r.weight, gw0, gb, d_in, B * Ta, w0r.weight.shape[0], E)
+            f32_to_param_grad(w0r.bias, gb)
+            d_emb = d_emb + d_in.view(B, Ta, E)
+        if nv_ > 1:
+            d_emb = d_emb.view(b0, nv_, Ta, E).sum(1)
         if ae.mask:
             # masked samples took the embedding from mask_embed.weight
             f32_to_param_grad(ae.mask_embed.weight, (d_emb * sv.is_mask[:, None, None]).sum((0, 1))[None])
             d_emb = d_emb * (~sv.is_mask)[:, None, None]
-        d_emb2 = d_emb.reshape(B * Ta, E).contiguous()
+        d_emb2 = d_emb.reshape(b0 * Ta, E).contiguous()
         w3, w0 = ae.mlp[3], ae.mlp[0]
-        d_h = z32(B * Ta, w3.weight.shape[1])
+        d_h = z32(b0 * Ta, w3.weight.shape[1])
         gb = z32(E)
-        ops.small_linear_bwd(d_emb2, sv.ae_h, w3.weight, _acc_grad(grads, w3.weight), gb, d_h, B * Ta, E, w3.weight.shape[1])
+        gw3 = _acc_grad(grads, w3.weight) if w3.weight.requires_grad else torch.zeros_like(w3.weight, dtype=BF16)
+        ops.small_linear_bwd(d_emb2, sv.ae_h, w3.weight, gw3, gb, d_h, b0 * Ta, E, w3.weight.shape[1])
         f32_to_param_grad(w3.bias, gb)
-        u = sv.ae_u.float()
-        a_, b_ = 0.7978845608028654, 0.044715
-        th = torch.tanh(a_ * (u + b_ * u ** 3))
-        d_u = (d_h * (0.5 * (1 + th) + 0.5 * u * (1 - th * th) * a_ * (1 + 3 * b_ * u * u))).contiguous()
+        d_u = (d_h * _gelu_tanh_grad(sv.ae_u.float())).contiguous()
         gb = z32(w0.weight.shape[0])
-        ops.small_linear_bwd(d_u, sv.ae_in, None, _acc_grad(grads, w0.weight), gb, None, B * Ta, w0.weight.shape[0],
-                             w0.weight.shape[1])
+        gw0 = _acc_grad(grads, w0.weight) if w0.weight.requires_grad else torch.zeros_like(w0.weight, dtype=BF16)
+        ops.small_linear_bwd(d_u, sv.ae_in, None, gw0, gb, None, b0 * Ta, w0.weight.shape[0], w0.weight.shape[1])
         f32_to_param_grad(w0.bias, gb)
-    te = model.time_embedding
-    d_h1 = z32(B, E)
-    gb = z32(E)
-    ops.small_linear_bwd(d_temb.contiguous(), sv.te_h1, te.linear_2.weight, _acc_grad(grads, te.linear_2.weight), gb, d_h1, B, E, E)
-    f32_to_param_grad(te.linear_2.bias, gb)
-    d_u1 = (d_h1 * dsilu(sv.te_u1.float())).contiguous()
-    gb = z32(E)
-    ops.small_linear_bwd(d_u1, sv.t_emb, None, _acc_grad(grads, te.linear_1.weight), gb, None, B, E, D)
-    f32_to_param_grad(te.linear_1.bias, gb)
+    if nv_ > 1:
+        d_temb = d_temb.view(b0, nv_, E).sum(1)
+
+    def mlp2_bwd(emb_mod, d_out, h1, u1, x_in):
+        """TimestepEmbedding (Linear-SiLU-Linear) adjoint for d_out [rows, E]."""
+        rows = d_out.shape[0]
+        l1, l2 = emb_mod.linear_1, emb_mod.linear_2
+        d_h1 = z32(rows, l2.weight.shape[1])
+        gb = z32(l2.weight.shape[0])
+        g2 = _acc_grad(grads, l2.weight) if l2.weight.requires_grad else torch.zeros_like(l2.weight, dtype=BF16)
+        ops.small_linear_bwd(d_out.contiguous(), h1, l2.weight, g2, gb, d_h1, rows, l2.weight.shape[0], l2.weight.shape[1])
+        f32_to_param_grad(l2.bias, gb)
+        d_u1 = (d_h1 * dsilu(u1.float())).contiguous()
+        gb = z32(l1.weight.shape[0])
+        g1 = _acc_grad(grads, l1.weight) if l1.weight.requires_grad else torch.zeros_like(l1.weight, dtype=BF16)
+        ops.small_linear_bwd(d_u1, x_in, None, g1, gb, None, rows, l1.weight.shape[0], l1.weight.shape[1])
+        f32_to_param_grad(l1.bias, gb)
+
+    mlp2_bwd(model.time_embedding, d_temb, sv.te_h1, sv.te_u1, sv.t_emb)
+    if sv.has_ofs:
+        rows_o = sv.o_emb.shape[0]
+        d_o = d_temb if rows_o == d_temb.shape[0] else d_temb.sum(0, keepdim=True)
+        mlp2_bwd(model.ofs_embedding, d_o, sv.oe_h1, sv.oe_u1, sv.o_emb)
     return grads
 
 
@@ -414,28 +690,36 @@ class DiTFunction(torch.autograd.Function):
     parameters are passed as inputs so autograd (and DDP's hooks) see their gradients."""
 
     @staticmethod
-    def forward(ctx, model, hidden_states, encoder_hidden_states, controls, timestep, ofs, image_rotary_emb, *params):
+    def forward(ctx, model, hidden_states, encoder_hidden_states, controls, timestep, ofs, image_rotary_emb, num_views,
+                image_rotary_emb_view, *params):
         with torch.no_grad():
             out, is_mask, recon, sv = forward_train(model, hidden_states, encoder_hidden_states, controls, timestep, ofs,
-                                                    image_rotary_emb)
+                                                    image_rotary_emb, num_views, image_rotary_emb_view)
         ctx.model, ctx.sv, ctx.params = model, sv, params
-        ctx.mark_non_differentiable(is_mask) if is_mask is not None else None
-        return (out, is_mask) if is_mask is not None else (out, torch.zeros(0, dtype=torch.bool, device=out.device))
+        dev = out.device
+        if is_mask is None:
+            is_mask = torch.zeros(0, dtype=torch.bool, device=dev)
+        ctx.mark_non_differentiable(is_mask)
+        if recon is None:
+            recon = torch.zeros(0, dtype=out.dtype, device=dev)
+            ctx.mark_non_differentiable(recon)
+        return out, is_mask, recon
 
     @staticmethod
-    def backward(ctx, dout, _dmask):
+    def backward(ctx, dout, _dmask, drecon):
         with torch.no_grad():
-            grads = backward(ctx.model, ctx.sv, dout.contiguous())
+            grads = backward(ctx.model, ctx.sv, dout.contiguous(), drecon if ctx.sv.has_recon else None)
         ctx.sv = None
         outs = []
         for p_ in ctx.params:
             g = grads.get(id(p_))
             outs.append(g.to(p_.dtype) if (g is not None and p_.requires_grad) else None)
-        return (None, None, None, None, None, None, None, *outs)
+        return (None, None, None, None, None, None, None, None, None, *outs)
 
 
-def forward_with_grad(model, hidden_states, encoder_hidden_states, controls, timestep, ofs=None, image_rotary_emb=None):
+def forward_with_grad(model, hidden_states, encoder_hidden_states, controls, timestep, ofs=None, image_rotary_emb=None,
+                      num_views=1, image_rotary_emb_view=None):
     params = tuple(p_ for p_ in model.parameters())
-    out, is_mask = DiTFunction.apply(model, hidden_states, encoder_hidden_states, controls, timestep, ofs, image_rotary_emb,
-                                     *params)
-    return out, (is_mask if is_mask.numel() else None), None
+    out, is_mask, recon = DiTFunction.apply(model, hidden_states, encoder_hidden_states, controls, timestep, ofs,
+                                            image_rotary_emb, num_views, image_rotary_emb_view, *params)
+    return out, (is_mask if is_mask.numel() else None), (recon if recon.numel() else None)
