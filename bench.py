@@ -214,6 +214,7 @@ def main():
     ts = sched.timesteps.tolist()
     controls = {"actions": actions}
 
+    @torch.no_grad()                    # the reference sampler runs under torch.no_grad (cogvideox_control.py:1228)
     def step(i, lat):
         t = ts[i % len(ts)]
         model_in = torch.cat([lat, image_latents], dim=2)                   # cogvideox_control.py:1409-1413
@@ -259,10 +260,14 @@ def main():
         for key, ms in timeline.items():
             if key[0] == "gemm":
                 _, M, N, K, epi = key
-                flop, name = 2.0 * M * N * K, f"gemm_kernel<{256 if M * N >= 224 * 256 * 192 else 128},{192 if N % 192 == 0 else (128 if N % 128 == 0 else 64)},{epi}> M={M} N={N} K={K}"
+                # kernel symbol as orv_gemm_bf16 dispatches it (gemm.hip: tile choice) so it matches the rocprofv3 name
+                bn = 192 if N % 192 == 0 else (128 if N % 128 == 0 else 64)
+                big = ((M + 255) // 256) * (N // bn) >= 224
+                sym = f"gemm_pp_kernel<{bn}, 5, {epi}>" if (big and bn != 64) else f"gemm_kernel<{256 if big else 128}, {bn}, {epi}>"
+                flop, name = 2.0 * M * N * K, f"{sym} M={M} N={N} K={K}"
             else:
                 _, b, s, h = key
-                flop, name = 4.0 * b * h * s * s * 64, f"attn_fwd_kernel B={b} S={s} H={h}"
+                flop, name = 4.0 * b * h * s * s * 64, f"attn_fwd_v1_kernel<true, true> B={b} S={s} H={h}"
             avg = sum(ms) / len(ms)
             kernels.append({"kernel": name, "launches": len(ms), "avg_ms": round(avg, 4), "total_ms": round(sum(ms), 2),
                             "tflops": round(flop / avg / 1e9, 1)})
@@ -272,7 +277,8 @@ def main():
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if dom and os.path.exists(prof):
             try:
-                traffic = json.load(open(prof)).get(dom["kernel"].split(" ")[0])
+                ent = json.load(open(prof)).get(dom["kernel"].split(" M=")[0].split(" B=")[0])
+                traffic = None if ent is None else ent.get("total_bytes")
             except Exception:
                 traffic = None
         line = {
