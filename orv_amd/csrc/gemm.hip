@@ -51,6 +51,16 @@ constexpr int GM = 4;  // super-tile height in tiles
 
 // Epilogue shared by both kernels.  acc[i][j][4q+e] = C[m][n] with m = mbase + j*32 + (lane&31),
 // n = nbase + i*32 + 8q + 4*(lane>>5) + e  (C^T accumulator layout: 4 consecutive columns per register quad).
+// Memory side: lanes l and l+32 own the two 8-byte halves of one 16-byte column group of the SAME row, so two column
+// groups (register quads 2u, 2u+1) are exchanged with v_permlane32_swap and every lane moves ONE aligned 16-byte piece
+// (lower half-wave: group 2u, upper: group 2u+1): half the store/load instructions of the 8-byte form and 32
+// contiguous bytes per row and instruction (measured: the 8-byte stores cost 15 % of the FFN1 GEMM).
+__device__ __forceinline__ void swap_halves(uint32_t& a, uint32_t& b) {
+    // a of the upper half-wave <-> b of the lower half-wave
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+
 template <int NB, int MB, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[NB][MB], int mbase, int nbase, int lane) {
     const int l31 = lane & 31, hi = lane >> 5;
@@ -72,44 +82,105 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[N
                 grow = p.gate + bidx * p.gate_b + orv_group_of(s, p.n_text, p.per_group) * p.gate_g;
             }
         }
+        // Every vector load issued here queues BEHIND the DMA pieces already in flight for the next tile (vmcnt retires in
+        // order), i.e. costs a full loaded-memory-pipeline latency: so the bias comes through the scalar cache (uniform
+        // address, s_load), and the per-row operands (residual, gate) of a row block are all requested up front.
+        uint32_t rq[NB][2][2][2];   // [block][u][quad t][dword]: residual / pre-activation operand, this lane's 4 columns
+        bool g_uniform = false;     // all rows of this 32-row block share one gate row -> gate through the scalar cache too
+        const float* g_srow = nullptr;
+        if (EPI == 2 || EPI == 3) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const uint4 rr = *(const uint4*)(rrow + nbase + i * 32 + (2 * u + hi) * 8);
+                    rq[i][u][0][0] = rr.x; rq[i][u][0][1] = rr.y; rq[i][u][1][0] = rr.z; rq[i][u][1][1] = rr.w;
+                }
+            if (EPI == 2 && p.gate) {
+                const int mf = __builtin_amdgcn_readfirstlane(mbase + j * 32), ml = min(mf + 31, p.M - 1);
+                long of = mf, ol = ml;
+                if (p.c_rows > 0) {
+                    of = (long)(mf / p.c_rows) * p.c_bstride + p.c_off + mf % p.c_rows;
+                    ol = (long)(ml / p.c_rows) * p.c_bstride + p.c_off + ml % p.c_rows;
+                }
+                const int bf_ = (int)(of / p.seq), bl_ = (int)(ol / p.seq);
+                const int gf_ = orv_group_of((int)(of % p.seq), p.n_text, p.per_group);
+                const int gl_ = orv_group_of((int)(ol % p.seq), p.n_text, p.per_group);
+                g_uniform = (bf_ == bl_) && (gf_ == gl_);
+                g_srow = p.gate + bf_ * p.gate_b + gf_ * p.gate_g;
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    // loaded: lower = group 2u cols 0-7, upper = group 2u+1 cols 0-7  ->  (quad 2u | quad 2u+1) own 4 columns
+                    swap_halves(rq[i][u][0][0], rq[i][u][1][0]);
+                    swap_halves(rq[i][u][0][1], rq[i][u][1][1]);
+                }
+        }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = nbase + i * 32 + q * 8 + hi * 4;
-                float v[4];
+            for (int u = 0; u < 2; ++u) {
+                // this lane's 16-byte piece: column group 2u + hi of the 32-column block
+                const int n16 = nbase + i * 32 + (2 * u + hi) * 8;
+                uint32_t oc[2][2], oy[2][2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
-                if (p.bias) {
-                    const uint2 bb = *(const uint2*)(p.bias + n);
-                    v[0] += bf2f(bb.x & 0xffff); v[1] += bf2f(bb.x >> 16);
-                    v[2] += bf2f(bb.y & 0xffff); v[3] += bf2f(bb.y >> 16);
-                }
-                if (yrow) {   // training: keep acc + bias (GELU pre-activation / un-gated branch output)
-                    uint2 yo; yo.x = pack2bf(v[0], v[1]); yo.y = pack2bf(v[2], v[3]);
-                    *(uint2*)(yrow + n) = yo;
-                }
-                if (EPI == 1) {
+                for (int t = 0; t < 2; ++t) {
+                    const int q = 2 * u + t;
+                    float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
+                    if (p.bias) {
+                        const int nq = __builtin_amdgcn_readfirstlane(nbase + i * 32 + q * 8);   // wave-uniform + constant address space: s_load
+                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 b8 = *(const __attribute__((address_space(4))) u32x4*)(uintptr_t)(p.bias + nq);
+                        const uint32_t bx = hi ? b8[2] : b8[0], by = hi ? b8[3] : b8[1];
+                        v[0] += bf2f(bx & 0xffff); v[1] += bf2f(bx >> 16);
+                        v[2] += bf2f(by & 0xffff); v[3] += bf2f(by >> 16);
+                    }
+                    if (yrow) {   // training: keep acc + bias (GELU pre-activation / un-gated branch output)
+                        oy[t][0] = pack2bf(v[0], v[1]); oy[t][1] = pack2bf(v[2], v[3]);
+                    }
+                    if (EPI == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+                    }
+                    if (EPI == 2) {
+                        float g[4] = {1.f, 1.f, 1.f, 1.f};
+                        if (grow) {
+                            if (g_uniform) {
+                                typedef float f32x4s __attribute__((ext_vector_type(4)));
+                                const int nq = __builtin_amdgcn_readfirstlane(nbase + i * 32 + q * 8);
+                                const f32x4s ga = *(const __attribute__((address_space(4))) f32x4s*)(uintptr_t)(g_srow + nq);
+                                const f32x4s gb = *(const __attribute__((address_space(4))) f32x4s*)(uintptr_t)(g_srow + nq + 4);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) g[e] = hi ? gb[e] : ga[e];
+                            } else {   // block straddles a frame / text boundary (about 1 in 19): per-row gate rows
+                                const float4 gg = *(const float4*)(grow + nbase + i * 32 + q * 8 + hi * 4);
+                                g[0] = gg.x; g[1] = gg.y; g[2] = gg.z; g[3] = gg.w;
+                            }
+                        }
+                        v[0] = bf2f(rq[i][u][t][0] & 0xffff) + g[0] * v[0]; v[1] = bf2f(rq[i][u][t][0] >> 16) + g[1] * v[1];
+                        v[2] = bf2f(rq[i][u][t][1] & 0xffff) + g[2] * v[2]; v[3] = bf2f(rq[i][u][t][1] >> 16) + g[3] * v[3];
+                    }
+                    if (EPI == 3) {   // backward through GELU(tanh): C = acc * gelu'(U), U = saved pre-activation
+                        v[0] *= gelu_tanh_grad(bf2f(rq[i][u][t][0] & 0xffff)); v[1] *= gelu_tanh_grad(bf2f(rq[i][u][t][0] >> 16));
+                        v[2] *= gelu_tanh_grad(bf2f(rq[i][u][t][1] & 0xffff)); v[3] *= gelu_tanh_grad(bf2f(rq[i][u][t][1] >> 16));
+                    }
+                    oc[t][0] = pack2bf(v[0], v[1]); oc[t][1] = pack2bf(v[2], v[3]);
                 }
-                if (EPI == 2) {
-                    const uint2 rr = *(const uint2*)(rrow + n);
-                    float g[4] = {1.f, 1.f, 1.f, 1.f};
-                    if (grow) { const float4 gg = *(const float4*)(grow + n); g[0] = gg.x; g[1] = gg.y; g[2] = gg.z; g[3] = gg.w; }
-                    v[0] = bf2f(rr.x & 0xffff) + g[0] * v[0]; v[1] = bf2f(rr.x >> 16) + g[1] * v[1];
-                    v[2] = bf2f(rr.y & 0xffff) + g[2] * v[2]; v[3] = bf2f(rr.y >> 16) + g[3] * v[3];
+                if (yrow) {
+                    swap_halves(oy[0][0], oy[1][0]);
+                    swap_halves(oy[0][1], oy[1][1]);
+                    *(uint4*)(yrow + n16) = make_uint4(oy[0][0], oy[0][1], oy[1][0], oy[1][1]);
                 }
-                if (EPI == 3) {   // backward through GELU(tanh): C = acc * gelu'(U), U = saved pre-activation
-                    const uint2 uu = *(const uint2*)(rrow + n);
-                    v[0] *= gelu_tanh_grad(bf2f(uu.x & 0xffff)); v[1] *= gelu_tanh_grad(bf2f(uu.x >> 16));
-                    v[2] *= gelu_tanh_grad(bf2f(uu.y & 0xffff)); v[3] *= gelu_tanh_grad(bf2f(uu.y >> 16));
-                }
-                uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+                swap_halves(oc[0][0], oc[1][0]);   // lower: (A cols 0-3 | A cols 4-7) ; upper: (B cols 0-3 | B cols 4-7)
+                swap_halves(oc[0][1], oc[1][1]);
 #ifdef ORV_GEMM_ABLATE_NOSTORE
                 if (p.dbg == 12345)
 #endif
-                *(uint2*)(crow + n) = o;
+                *(uint4*)(crow + n16) = make_uint4(oc[0][0], oc[0][1], oc[1][0], oc[1][1]);
             }
         }
     }
@@ -342,6 +413,9 @@ __device__ __forceinline__ void gemm_ring_body(const GemmArgs& p, char* smem, co
         for (int j = 0; j < MB; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    constexpr int NSTORE = NB * MB * 2;   // 16-byte C stores one wave issues per full tile (no Y output)
+    static_assert((NSLOT - 3) * NPC + NSTORE <= 63, "vmcnt immediate is 6 bits");
+    int st_pending = 0;                   // sub-stages whose DMA pieces were issued before the last epilogue's stores
 
 #ifdef ORV_GEMM_ABLATE_NOMFMA
 #define ORV_MFMA(FA, FB, kk, i, j) asm volatile("" ::"v"(FB[kk][i]), "v"(FA[kk][j]));
@@ -357,7 +431,12 @@ __device__ __forceinline__ void gemm_ring_body(const GemmArgs& p, char* smem, co
     //   ds_reads of g+1 -> fragment set NXT | MFMAs of g on fragment set CUR | DMA pieces of g+NSLOT-1 -> slot g-1
 #define ORV_SUBSTAGE(FA_CUR, FB_CUR, FA_NXT, FB_NXT)                                                                 \
     {                                                                                                                \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 3) * NPC) : "memory");                                     \
+        if (st_pending > 0) { /* epilogue stores of the previous tile still in flight: they are YOUNGER than the DMA */  \
+            --st_pending;     /* pieces this wait is about (vmcnt retires in issue order), so allow them on top      */  \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 3) * NPC + NSTORE) : "memory");                        \
+        } else {                                                                                                     \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 3) * NPC) : "memory");                                 \
+        }                                                                                                            \
         __builtin_amdgcn_s_barrier();                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         ORV_READ_FRAGS(FA_NXT, FB_NXT)                                                                               \
@@ -385,23 +464,43 @@ __device__ __forceinline__ void gemm_ring_body(const GemmArgs& p, char* smem, co
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 2) * NPC) : "memory");
     __builtin_amdgcn_s_barrier();
     ORV_READ_FRAGS(fa0, fb0)
+#ifdef ORV_GEMM_TRACE   // tools/trace_gemm.cpp: s_memtime stamps of workgroup 0 / wave 0 (R doubles as the trace buffer, EPI 0/1 only)
+    int trace_i = 0;
+#define ORV_TRACE(SLOT) if (blockIdx.x == 0 && threadIdx.x == 0 && trace_i < 16) ((unsigned long long*)p.R)[trace_i * 4 + SLOT] = __builtin_readcyclecounter();
+#else
+#define ORV_TRACE(SLOT)
+#endif
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        ORV_TRACE(0)
         for (int j = 0; j < nsub; j += 2) {            // K % 64 == 0, so nsub is even: static fragment-set names
             ORV_SUBSTAGE(fa0, fb0, fa1, fb1)
             ORV_SUBSTAGE(fa1, fb1, fa0, fb0)
         }
-        // finished tile -> memory, then drain: the stores (vmcnt counts them, out of order with the DMA loads) must not
-        // be mistaken for landed DMA pieces by the counted waits that follow.  Everything else outstanding here is old.
+        // finished tile -> memory.  vmcnt counts the epilogue's stores too and retires in issue order (loads and stores
+        // share the counter on gfx9-class hardware), so the counted DMA waits of the next NSLOT-2 sub-stages - whose pieces
+        // were issued BEFORE these stores - simply allow NSTORE more outstanding operations: the stores drain under the
+        // next tile's MFMAs instead of stalling the wave here.  Exact store count is needed for that, so tiles with rows
+        // past M (predicated stores) and launches with a Y output keep the plain drain.
         int tm, tn;
+        ORV_TRACE(1)
         tile_of_index(p, tile, ntiles, tm, tn);
         gemm_epilogue<NB, MB, EPI>(p, acc, tm * BM + wq * 64, tn * BN + grp * (BN / 2), lane);
+        ORV_TRACE(2)
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
             for (int j2 = 0; j2 < MB; ++j2)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j2][e] = 0.f;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tm * BM + BM <= p.M && !p.Y && p.dbg != 7) {
+            st_pending = NSLOT - 2;
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        ORV_TRACE(3)
+#ifdef ORV_GEMM_TRACE
+        ++trace_i;
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef ORV_SETUP_SRC
@@ -411,6 +510,7 @@ __device__ __forceinline__ void gemm_ring_body(const GemmArgs& p, char* smem, co
 #undef ORV_MFMA
 #undef ORV_ISSUE_MAIN
 #undef ORV_SUBSTAGE
+#undef ORV_TRACE
 }
 
 template <int BN, int NSLOT, int EPI>
@@ -491,7 +591,10 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
     ORV_REQUIRE(g->M > 0 && g->N > 0 && g->K > 0, "orv_gemm_bf16: empty problem M=%d N=%d K=%d", g->M, g->N, g->K);
     ORV_REQUIRE(g->K % 64 == 0, "orv_gemm_bf16: K=%d must be a multiple of 64", g->K);
     ORV_REQUIRE(g->N % 64 == 0, "orv_gemm_bf16: N=%d must be a multiple of 64", g->N);
-    ORV_REQUIRE(g->lda % 8 == 0 && g->ldw % 8 == 0 && g->ldc % 4 == 0, "orv_gemm_bf16: misaligned leading dimension");
+    ORV_REQUIRE(g->lda % 8 == 0 && g->ldw % 8 == 0 && g->ldc % 8 == 0, "orv_gemm_bf16: misaligned leading dimension");
+    ORV_REQUIRE(((uintptr_t)g->C & 15) == 0 && (!g->R || (((uintptr_t)g->R & 15) == 0 && g->ldr % 8 == 0)) &&
+                    (!g->Y || (((uintptr_t)g->Y & 15) == 0 && g->ldy % 8 == 0)),
+                "orv_gemm_bf16: C / R / Y must be 16-byte aligned with leading dimensions that are multiples of 8");
     ORV_REQUIRE((g->epilogue != 2 && g->epilogue != 3) || g->R, "orv_gemm_bf16: epilogue 2/3 needs R");
     ORV_REQUIRE(g->epilogue != 2 || !g->gate || g->grp.seq > 0, "orv_gemm_bf16: gate needs grp.seq");
     GemmArgs a;
