@@ -125,23 +125,15 @@ def train_mode(args, model, latents, image_latents, prompt, actions, sched, dev,
     B = args.batch
     model.train()
     opt = FusedAdamW(model.parameters(), lr=1e-5, betas=(0.9, 0.95), weight_decay=1e-3, max_grad_norm=1.0)
-    ac = sched.alphas_cumprod.to(dev, torch.float32)
+    from orv_amd import sft
     g = torch.Generator(device=dev).manual_seed(42 + rank)
-    x0 = latents
+    batch = sft.Batch(latents, image_latents, prompt, actions, None, None,
+                      torch.ones(latents.shape[1], dtype=torch.bool, device=dev), 1)
 
     def step():
-        noise = torch.randn(x0.shape, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
-        ts = torch.randint(0, 1000, (B,), generator=g, device=dev)
-        noisy = sched.add_noise(x0, noise, ts)
-        out = model(torch.cat([noisy, image_latents], dim=2), prompt, {"actions": actions}, ts, return_dict=False)[0]
-        pred = sched.get_velocity(out, noisy, ts)
-        wgt = (1 / (1 - ac[ts]).clamp_min(1e-4))[:, None, None, None, None]
-        loss = torch.mean((wgt * (pred.float() - x0.float()) ** 2).reshape(B, -1), dim=1).mean()
-        loss.backward()
-        allreduce_gradients(model.parameters())
-        opt.step()
-        opt.zero_grad()
-        return loss
+        # orv_amd.sft.sft_step = train script :1005-1104 (noise + timestep draw, add_noise, forward, x0 loss, backward,
+        # gradient all-reduce when world > 1, global-norm clip, fused AdamW)
+        return sft.sft_step(model, sched, opt, batch, generator=g, data_parallel=world > 1)[0]
 
     def barrier():
         torch.cuda.synchronize()

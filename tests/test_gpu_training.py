@@ -181,3 +181,47 @@ def test_sft_step_lowers_loss():
         assert torch.isfinite(loss) and gnorm > 0
         losses.append(loss.item())
     assert losses[-1] < 0.7 * losses[0], losses
+
+
+def test_sft_batch_and_loss_match_oracle():
+    """orv_amd.sft (train script :862-1090): moments -> latents -> padded batch -> weighted x0 loss + action reconstruction
+    losses, against the oracle's restatement on the same latents / noise / timesteps."""
+    from oracle import leaf, pipeline as opipe
+    from orv_amd import schedulers, sft
+    from orv_amd.cogvideox_control import CogVideoXTransformer3DModelTraj
+    dev = torch.device("cuda:0")
+    cfg, extra, ins, w, outs = load_golden("fwd_train_recon")
+    m = CogVideoXTransformer3DModelTraj(**cfg)
+    m.load_state_dict(w)
+    m = m.to(dev, BF).train()
+    mask = torch.tensor(extra["mask"])
+    m.action_embed.forced_mask = mask
+    g = torch.Generator(device=dev).manual_seed(11)
+    B, F, C, H, W = 2, ins["hidden_states"].shape[1], 16, 8, 12
+    cpu_g = torch.Generator().manual_seed(3)
+    batch = {"latents": torch.randn(B, 2 * C, F, H, W, generator=cpu_g), "images": torch.randn(B, 2 * C, 1, H, W, generator=cpu_g),
+             "prompt_embeds": ins["encoder_hidden_states"], "controls": {"actions": ins["actions"]}}
+    b = sft.prepare_batch(batch, dev, generator=g)
+    assert b.video_latents.shape == (B, F, C, H, W) and b.image_latents.shape == (B, F, C, H, W)
+    assert torch.count_nonzero(b.image_latents[:, 1:]) == 0 and bool(b.frame_mask.all())
+    # the fused sampler = mean + exp(0.5 clamp(logvar)) * eps, scaled and permuted
+    mom = batch["latents"].to(dev, BF).float()
+    mean, logvar = mom[:, :C], mom[:, C:].clamp(-30, 20)
+    lat = b.video_latents.float().permute(0, 2, 1, 3, 4)
+    z = (lat / sft.VAE_SCALING_FACTOR - mean) / torch.exp(0.5 * logvar)
+    assert abs(z.mean().item()) < 0.05 and abs(z.std().item() - 1) < 0.05
+    kw = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+              prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=3.0, timestep_spacing="trailing")
+    sched = schedulers.CogVideoXDDIMScheduler(**kw)
+    noise = torch.randn(b.video_latents.shape, generator=cpu_g).to(BF)
+    ts = torch.tensor([250, 800])
+    loss, parts = sft.sft_loss(m, sched, b, noise.to(dev), ts.to(dev))
+    osched = leaf.CogVideoXDDIMScheduler(**kw, clip_sample=False, set_alpha_to_one=True)
+    oloss, _, orecon = opipe.sft_loss(w, cfg, osched, b.video_latents.float().cpu(), b.image_latents.float().cpu(),
+                                      ins["encoder_hidden_states"], ins["actions"], noise.float(), ts, is_mask=mask)
+    assert abs(parts["denoise"].item() - oloss.item()) <= 3e-2 * abs(oloss.item())
+    rot, pos, grip = dit.compute_action_loss(ins["actions"], orecon, sft.ACTION_LOSS_WEIGHT, mask=~mask)
+    for got, ref in ((parts["rot"], rot), (parts["pos"], pos), (parts["grip"], grip)):
+        assert abs(got.item() - ref.item()) <= 3e-2 * abs(ref.item()) + 1e-3
+    loss.backward()
+    assert m.action_recon.mlp[2].weight.grad is not None and m.transformer_blocks[0].ff.net[2].weight.grad is not None

@@ -5,7 +5,7 @@ TAG=${1:-r1}; shift
 cd /tmp && export TMPDIR=/tmp
 OUT=/root/repo/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o $TAG -- python /root/repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > $OUT/bench_stdout.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o $TAG -- python /root/repo/bench.py --no-cpu-baseline "$@" > $OUT/bench_stdout.log 2>&1
 python3 - "$OUT/${TAG}_kernel_stats.csv" > $OUT/${TAG}_kernel_stats_summary.txt <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
