@@ -615,6 +615,15 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
     a.tiles_m = big ? (g->M + 255) / 256 : (g->M + 127) / 128;
     static int algo = -1;   // ORV_GEMM_ALGO=0 forces the simple double-buffered kernel (A/B testing)
     if (algo < 0) { const char* e = getenv("ORV_GEMM_ALGO"); algo = e ? atoi(e) : 1; }
+    static int wide = -1;   // ORV_GEMM_BN256=0 keeps 192-wide tiles where N divides by both (A/B testing)
+    if (wide < 0) { const char* e = getenv("ORV_GEMM_BN256"); wide = e ? atoi(e) : 1; }
+    if (big && algo == 1 && wide && g->N % 256 == 0 && ((g->M + 255) / 256) * (g->N / 256) >= 4 * 256) {
+        // 256 x 256 tile: 7.8 instead of 9.1 B/kFLOP through the LDS-DMA path and 10 % fewer LDS fragment reads per MFMA -
+        // energy per FLOP is what a power-capped GEMM is bound by.  Only with >= 4 rounds of tiles (tail quantisation).
+        a.tiles_n = g->N / 256;
+        a.tiles_m = (g->M + 255) / 256;
+        return launch_pp<256, 5>(a, g->epilogue, st);
+    }
     if (big && algo == 1) {
         if (bn == 192) return launch_pp<192, 5>(a, g->epilogue, st);
         if (bn == 128) return launch_pp<128, 5>(a, g->epilogue, st);

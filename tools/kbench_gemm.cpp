@@ -51,7 +51,7 @@ int main(int argc,char**argv){
   int bad=0;
   bad+=check(64,128,128,0,64,8,0); bad+=check(100,192,256,1,50,8,14); bad+=check(300,64,1920,0,300,0,0);
   bad+=check(700,384,512,2,350,30,64); bad+=check(3226,1920,1920,2,3226,226,600); bad+=check(3226,7680,1920,1,3226,226,600);
-  bad+=check(12904,5760,1920,0,3226,226,600);
+  bad+=check(12904,5760,1920,0,3226,226,600); bad+=check(12904,7680,256,1,3226,226,600); bad+=check(13000,5120,128,2,3250,250,600);
   if(bad){ printf("CORRECTNESS FAILURES: %d\n",bad); return 1; }
   for(int M: {12904, 3226}){ bench(M,5760,1920,0,20); bench(M,1920,1920,2,20); bench(M,7680,1920,1,20); bench(M,1920,7680,2,20); }
   bench(8192,8192,8192,0,5);
