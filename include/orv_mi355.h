@@ -159,12 +159,14 @@ int orv_colsum(const void* src, int ld, float* out, int R, int C, void* stream);
  * dgate[b,g,:] += sum_rows dout * y (fp32 atomics into a table laid out like `gate`). */
 int orv_gated_residual_bwd(const void* dout, const void* y, const float* gate, float* dgate, void* dy, long mod_b,
                            long mod_g, orv_groups_t grp, int batch, int D, void* stream);
-/* Adjoint of orv_layernorm_modulate: dx[xmap(r)] = LN-path gradient (+ dres[xmap(r)] if given), and fp32-atomic sums
- * dscale/dshift (tables like scale/shift), dgamma/dbeta [D] (any may be NULL when the forward had none). */
+/* Adjoint of orv_layernorm_modulate: dx[xmap(r)] = LN-path gradient (+ dres[xmap(r)] if given), and fp32 sums
+ * dscale/dshift (tables like scale/shift; atomics), dgamma/dbeta [D] (accumulated; per-workgroup partials in `scratch`,
+ * orv_layernorm_modulate_bwd_scratch() floats, then reduced).  Any output may be NULL when the forward had none. */
+long orv_layernorm_modulate_bwd_scratch(orv_groups_t grp, int batch, int D);
 int orv_layernorm_modulate_bwd(const void* dy, const void* x, orv_rowmap_t xmap, const void* dres, void* dx,
                                const void* gamma, const void* beta, const float* scale, float* dscale, float* dshift,
-                               float* dgamma, float* dbeta, long mod_b, long mod_g, orv_groups_t grp, int batch, int D,
-                               float eps, void* stream);
+                               float* dgamma, float* dbeta, float* scratch, long mod_b, long mod_g, orv_groups_t grp,
+                               int batch, int D, float eps, void* stream);
 /* Small-row (R <= 4096) linear adjoint for the conditioning MLPs / AdaLN linears: dW[N,K] (+)= dy^T x (bf16),
  * db[N] (+)= colsum(dy) (fp32), dx[R,K] += dy W (fp32 atomics).  dy fp32 [R, ldy].  Any of dW/dx may be NULL. */
 int orv_small_linear_bwd(const float* dy, int ldy, const void* x, int ldx, const void* W, void* dW, float* db, float* dx,

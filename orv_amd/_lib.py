@@ -55,9 +55,10 @@ SIGNATURES = {
     "orv_colsum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "orv_gated_residual_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, Groups, c_int, c_int,
                                        c_void_p]),
+    "orv_layernorm_modulate_bwd_scratch": (c_long, [Groups, c_int, c_int]),
     "orv_layernorm_modulate_bwd": (c_int, [c_void_p, c_void_p, RowMap, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                           c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, Groups, c_int, c_int,
-                                           c_float, c_void_p]),
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, Groups, c_int,
+                                           c_int, c_float, c_void_p]),
     "orv_small_linear_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                      c_int, c_int, c_int, c_void_p]),
     "orv_adamw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float, c_float, c_int,

@@ -114,167 +114,201 @@ __global__ __launch_bounds__(256) void gated_bwd_kernel(const bf16_t* __restrict
 }
 
 // ---- LayerNorm-modulate backward.  Forward: xh = (x - mu) rstd ; z = xh*gamma + beta ; y = z*(1+sc) + sh.
-//      Given dy: dsh += dy ; dsc += dy*z ; dz = dy*(1+sc) ; dbeta += dz ; dgamma += dz*xh ;
-//      dxh = dz*gamma ; dx = rstd*(dxh - mean(dxh) - xh*mean(dxh*xh)) ; dx_out = dx (+ dres).
-//      One wave walks RPW consecutive rows; per-column sums stay in registers (dsc/dsh until the group changes).
+//      Given dy: dxh = dy*(1+sc)*gamma ; dx = rstd*(dxh - mean(dxh) - xh*mean(dxh*xh)) (+ dres).
+//      All rows of a workgroup belong to ONE (batch, token group), so (1+sc) is a per-column constant of the block and only
+//      two column sums are needed:  A1 = sum dy, A2 = sum dy*xh  ->  dshift = A1, dscale = gamma*A2 + beta*A1,
+//      dbeta = (1+sc)*A1, dgamma = (1+sc)*A2.
+//      Layout: the 256 threads split the COLUMNS (thread -> 8-column chunks tid, tid+256), every thread walks the block's rows
+//      four at a time (8 independent 16-byte loads in flight per thread); the three row reductions (mean, variance,
+//      the two dx means) go wave_sum -> LDS -> all threads, one barrier each for the four rows together.  Column sums stay
+//      private to a thread: no cross-wave reduction.  dscale/dshift: fp32 atomics (~38 blocks per table row);
+//      dgamma/dbeta: per-block partials + reduce kernel (every block would hit the same D addresses otherwise).
+constexpr int LNB_RB = 16;   // rows per workgroup
+constexpr int LNB_R = 4;     // rows in flight
+
+struct LnBwdArgs {
+    const bf16_t *dy, *x, *dres; bf16_t* dx;
+    const bf16_t *gamma, *beta;
+    const float* scale; float *dscale, *dshift;
+    float* part;           // [blocks][2][D] (dgamma | dbeta partials) or null
+    long mod_b, mod_g;
+    int seq, n_text, per_group, D;
+    float eps;
+    orv_rowmap_t xmap;
+    int bt, bg, bpb;       // blocks per text group / per video group / per batch element
+};
+
 template <int CH>
-__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
-                                                         const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
-                                                         const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
-                                                         const float* __restrict__ scale, float* __restrict__ dscale,
-                                                         float* __restrict__ dshift, float* __restrict__ dgamma,
-                                                         float* __restrict__ dbeta, long mod_b, long mod_g, int seq,
-                                                         int n_text, int per_group, int rows, int D, float eps, int rpw,
-                                                         orv_rowmap_t xmap) {
-    const int lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nchunk = D >> 3;
-    const int r0 = min(wid * rpw, rows), r1 = min(rows, r0 + rpw);     // waves past the end run zero rows (they still join the barrier)
-    float gam[CH][8], bet[CH][8], a_sc[CH][8], a_sh[CH][8], a_g[CH][8], a_b[CH][8];
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const LnBwdArgs p) {
+    __shared__ float red[3][2][LNB_R][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = p.D, nchunk = D >> 3;
+    // ---- block -> (batch, group, rows [s0, s1) of the sequence) ----
+    const int b = blockIdx.x / p.bpb, r = blockIdx.x % p.bpb;
+    int g, s0, s1;
+    if (r < p.bt) { g = 0; s0 = r * LNB_RB; s1 = min(p.n_text, s0 + LNB_RB); }
+    else {
+        const int q = r - p.bt, gi = q / p.bg, ck = q % p.bg;
+        const int gsz = p.per_group > 0 ? p.per_group : p.seq - p.n_text;
+        const int gstart = p.n_text + gi * gsz;
+        g = 1 + gi;
+        s0 = gstart + ck * LNB_RB;
+        s1 = min(min(gstart + gsz, p.seq), s0 + LNB_RB);
+    }
+    const long off = p.scale ? b * p.mod_b + g * p.mod_g : 0;
+
+    float gam[CH][8], osc[CH][8], a1[CH][8], a2[CH][8];   // gamma, 1 + scale, the two column sums
+    bool live[CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-        const int c = lane + 64 * i;
+        const int c = tid + 256 * i;
+        live[i] = c < nchunk;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            gam[i][e] = (gamma && c < nchunk) ? bf2f(gamma[c * 8 + e]) : 1.f;
-            bet[i][e] = (beta && c < nchunk) ? bf2f(beta[c * 8 + e]) : 0.f;
-            a_sc[i][e] = a_sh[i][e] = a_g[i][e] = a_b[i][e] = 0.f;
+            gam[i][e] = (p.gamma && live[i]) ? bf2f(p.gamma[c * 8 + e]) : 1.f;
+            osc[i][e] = (p.scale && live[i]) ? 1.f + p.scale[off + c * 8 + e] : 1.f;
+            a1[i][e] = a2[i][e] = 0.f;
         }
     }
-    long cur_off = -1;
-    for (int row = r0; row < r1; ++row) {
-        long off = 0;
-        if (scale) {
-            const int b = row / seq, s = row % seq;
-            off = b * mod_b + orv_group_of(s, n_text, per_group) * mod_g;
-            if (off != cur_off) {
-                if (cur_off >= 0) {
+    const float invD = 1.f / (float)D;
+
+    for (int rb = s0; rb < s1; rb += LNB_R) {
+        const int nr = min(LNB_R, s1 - rb);
+        float xv[LNB_R][CH][8], dv[LNB_R][CH][8];
+        long xrow[LNB_R];
+        float ps[LNB_R];
 #pragma unroll
-                    for (int i = 0; i < CH; ++i) {
-                        const int c = lane + 64 * i;
-                        if (c < nchunk)
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                atomicAdd(dscale + cur_off + c * 8 + e, a_sc[i][e]);
-                                atomicAdd(dshift + cur_off + c * 8 + e, a_sh[i][e]);
-                                a_sc[i][e] = a_sh[i][e] = 0.f;
-                            }
-                    }
-                }
-                cur_off = off;
-            }
-        }
-        const long xrow = xmap.rows > 0 ? (long)(row / xmap.rows) * xmap.bstride + xmap.off + row % xmap.rows : row;
-        float xv[CH][8], dv[CH][8];
-        float s1 = 0.f;
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nchunk) {
-                const uint4 ux = *(const uint4*)(x + xrow * D + c * 8);
-                const uint4 ud = *(const uint4*)(dy + (long)row * D + c * 8);
-                const uint32_t wx[4] = {ux.x, ux.y, ux.z, ux.w}, wd[4] = {ud.x, ud.y, ud.z, ud.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    xv[i][2 * e] = bf2f(wx[e] & 0xffff); xv[i][2 * e + 1] = bf2f(wx[e] >> 16);
-                    dv[i][2 * e] = bf2f(wd[e] & 0xffff); dv[i][2 * e + 1] = bf2f(wd[e] >> 16);
-                    s1 += xv[i][2 * e] + xv[i][2 * e + 1];
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xv[i][e] = dv[i][e] = 0.f;
-            }
-        }
-        const float mean = wave_sum(s1) / (float)D;
-        float sq = 0.f;
-#pragma unroll
-        for (int i = 0; i < CH; ++i)
-            if (lane + 64 * i < nchunk)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const float d = xv[i][e] - mean; sq += d * d; }
-        const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
-        float m1 = 0.f, m2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int c = lane + 64 * i;
-            if (c >= nchunk) continue;
-            float sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (scale) {
-                const float4 s0 = *(const float4*)(scale + off + c * 8), s4 = *(const float4*)(scale + off + c * 8 + 4);
-                sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s4.x; sc[5] = s4.y; sc[6] = s4.z; sc[7] = s4.w;
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float xh = (xv[i][e] - mean) * rstd;
-                const float z = xh * gam[i][e] + bet[i][e];
-                const float d = dv[i][e];
-                a_sh[i][e] += d;
-                a_sc[i][e] += d * z;
-                const float dz = d * (1.f + sc[e]);
-                a_b[i][e] += dz;
-                a_g[i][e] += dz * xh;
-                const float dxh = dz * gam[i][e];
-                xv[i][e] = xh;       // keep xh
-                dv[i][e] = dxh;      // keep dxh
-                m1 += dxh;
-                m2 += dxh * xh;
-            }
-        }
-        m1 = wave_sum(m1) / (float)D;
-        m2 = wave_sum(m2) / (float)D;
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int c = lane + 64 * i;
-            if (c >= nchunk) continue;
-            float o[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = rstd * (dv[i][e] - m1 - xv[i][e] * m2);
-            if (dres) {
-                const uint4 ur = *(const uint4*)(dres + xrow * D + c * 8);
-                const uint32_t wr[4] = {ur.x, ur.y, ur.z, ur.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { o[2 * e] += bf2f(wr[e] & 0xffff); o[2 * e + 1] += bf2f(wr[e] >> 16); }
-            }
-            *(uint4*)(dx + xrow * D + c * 8) = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-        const int c = lane + 64 * i;
-        if (c >= nchunk) continue;
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (scale && cur_off >= 0) { atomicAdd(dscale + cur_off + c * 8 + e, a_sc[i][e]); atomicAdd(dshift + cur_off + c * 8 + e, a_sh[i][e]); }
-    }
-    // dgamma / dbeta: every wave of the grid adds into the same D addresses -> reduce the 4 waves of the block in LDS first
-    // (callers guarantee whole blocks are live: rows are padded out by the r0 >= rows early-exit only in the last block)
-    if (dgamma || dbeta) {
-        __shared__ float red_g[3][4096], red_b[3][4096];
-        const int w = threadIdx.x >> 6;
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nchunk && w > 0)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { red_g[w - 1][c * 8 + e] = a_g[i][e]; red_b[w - 1][c * 8 + e] = a_b[i][e]; }
-        }
-        __syncthreads();
-        if (w == 0) {
-            const int live = min(4, (rows - (int)blockIdx.x * 4 * rpw + rpw - 1) / rpw);    // waves of this block that had rows
+        for (int k = 0; k < LNB_R; ++k) {
+            const long row = (long)b * p.seq + rb + min(k, nr - 1);
+            xrow[k] = p.xmap.rows > 0 ? (row / p.xmap.rows) * p.xmap.bstride + p.xmap.off + row % p.xmap.rows : row;
+            ps[k] = 0.f;
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
-                const int c = lane + 64 * i;
-                if (c >= nchunk) continue;
+                if (live[i] && k < nr) {
+                    const int c = tid + 256 * i;
+                    const uint4 ux = *(const uint4*)(p.x + xrow[k] * D + c * 8);
+                    const uint4 ud = *(const uint4*)(p.dy + row * D + c * 8);
+                    const uint32_t wx[4] = {ux.x, ux.y, ux.z, ux.w}, wd[4] = {ud.x, ud.y, ud.z, ud.w};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float g = a_g[i][e], bsum = a_b[i][e];
-                    for (int k = 1; k < live; ++k) { g += red_g[k - 1][c * 8 + e]; bsum += red_b[k - 1][c * 8 + e]; }
-                    if (dgamma) atomicAdd(dgamma + c * 8 + e, g);
-                    if (dbeta) atomicAdd(dbeta + c * 8 + e, bsum);
+                    for (int e = 0; e < 4; ++e) {
+                        xv[k][i][2 * e] = bf2f(wx[e] & 0xffff); xv[k][i][2 * e + 1] = bf2f(wx[e] >> 16);
+                        dv[k][i][2 * e] = bf2f(wd[e] & 0xffff); dv[k][i][2 * e + 1] = bf2f(wd[e] >> 16);
+                        ps[k] += xv[k][i][2 * e] + xv[k][i][2 * e + 1];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xv[k][i][e] = dv[k][i][e] = 0.f;
                 }
             }
         }
+        // block-wide sums of LNB_R values per phase: wave_sum, one LDS slot per wave, one barrier (3 phase buffers, so the
+        // next phase never overwrites what a slower wave is still reading)
+#define ORV_BLOCK_SUM(PH, SLOT, V)                                                                   \
+        {                                                                                            \
+            _Pragma("unroll") for (int k = 0; k < LNB_R; ++k) {                                      \
+                const float w_ = wave_sum(V[k]);                                                     \
+                if (lane == 0) red[PH][SLOT][k][wave] = w_;                                          \
+            }                                                                                        \
+        }
+#define ORV_BLOCK_GET(PH, SLOT, k) (red[PH][SLOT][k][0] + red[PH][SLOT][k][1] + red[PH][SLOT][k][2] + red[PH][SLOT][k][3])
+        ORV_BLOCK_SUM(0, 0, ps)
+        __syncthreads();
+        float mean[LNB_R], rstd[LNB_R];
+#pragma unroll
+        for (int k = 0; k < LNB_R; ++k) {
+            mean[k] = ORV_BLOCK_GET(0, 0, k) * invD;
+            ps[k] = 0.f;
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+                if (live[i])
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float d = xv[k][i][e] - mean[k]; ps[k] += d * d; }
+        }
+        ORV_BLOCK_SUM(1, 0, ps)
+        __syncthreads();
+        float pm1[LNB_R], pm2[LNB_R];
+#pragma unroll
+        for (int k = 0; k < LNB_R; ++k) {
+            rstd[k] = rsqrtf(ORV_BLOCK_GET(1, 0, k) * invD + p.eps);
+            pm1[k] = pm2[k] = 0.f;
+            if (k < nr) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i)
+                    if (live[i])
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float xh = (xv[k][i][e] - mean[k]) * rstd[k];
+                            const float d = dv[k][i][e];
+                            a1[i][e] += d;
+                            a2[i][e] += d * xh;
+                            const float dxh = d * osc[i][e] * gam[i][e];
+                            xv[k][i][e] = xh;
+                            dv[k][i][e] = dxh;
+                            pm1[k] += dxh;
+                            pm2[k] += dxh * xh;
+                        }
+            }
+        }
+        ORV_BLOCK_SUM(2, 0, pm1)
+        ORV_BLOCK_SUM(2, 1, pm2)
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < LNB_R; ++k) {
+            if (k >= nr) continue;
+            const float m1 = ORV_BLOCK_GET(2, 0, k) * invD, m2 = ORV_BLOCK_GET(2, 1, k) * invD;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                if (!live[i]) continue;
+                const int c = tid + 256 * i;
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rstd[k] * (dv[k][i][e] - m1 - xv[k][i][e] * m2);
+                if (p.dres) {
+                    const uint4 ur = *(const uint4*)(p.dres + xrow[k] * D + c * 8);
+                    const uint32_t wr[4] = {ur.x, ur.y, ur.z, ur.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[2 * e] += bf2f(wr[e] & 0xffff); o[2 * e + 1] += bf2f(wr[e] >> 16); }
+                }
+                *(uint4*)(p.dx + xrow[k] * D + c * 8) =
+                    make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+            }
+        }
+#undef ORV_BLOCK_SUM
+#undef ORV_BLOCK_GET
     }
+    // ---- column sums out ----
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        if (!live[i]) continue;
+        const int c = tid + 256 * i;
+        if (p.scale) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float bet = p.beta ? bf2f(p.beta[c * 8 + e]) : 0.f;
+                atomicAdd(p.dshift + off + c * 8 + e, a1[i][e]);
+                atomicAdd(p.dscale + off + c * 8 + e, gam[i][e] * a2[i][e] + bet * a1[i][e]);
+            }
+        }
+        if (p.part) {
+            float* pg = p.part + (long)blockIdx.x * 2 * D + c * 8;
+            *(float4*)(pg) = make_float4(osc[i][0] * a2[i][0], osc[i][1] * a2[i][1], osc[i][2] * a2[i][2], osc[i][3] * a2[i][3]);
+            *(float4*)(pg + 4) = make_float4(osc[i][4] * a2[i][4], osc[i][5] * a2[i][5], osc[i][6] * a2[i][6], osc[i][7] * a2[i][7]);
+            *(float4*)(pg + D) = make_float4(osc[i][0] * a1[i][0], osc[i][1] * a1[i][1], osc[i][2] * a1[i][2], osc[i][3] * a1[i][3]);
+            *(float4*)(pg + D + 4) = make_float4(osc[i][4] * a1[i][4], osc[i][5] * a1[i][5], osc[i][6] * a1[i][6], osc[i][7] * a1[i][7]);
+        }
+    }
+}
+
+// out0[j] += sum_blocks part[blk][0][j] ; out1[j] += sum_blocks part[blk][1][j]   (grid: D/256 x slabs of 64 blocks)
+__global__ __launch_bounds__(256) void ln_partials_reduce_kernel(const float* __restrict__ part, int nblk, int D,
+                                                                 float* __restrict__ out0, float* __restrict__ out1) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= D) return;
+    const int b0 = blockIdx.y * 64, b1 = min(nblk, b0 + 64);
+    float s0 = 0.f, s1 = 0.f;
+    for (int b = b0; b < b1; ++b) { s0 += part[(long)b * 2 * D + j]; s1 += part[(long)b * 2 * D + D + j]; }
+    if (out0) atomicAdd(out0 + j, s0);
+    if (out1) atomicAdd(out1 + j, s1);
 }
 
 // ---- small-row linear backward (rows <= 64; the conditioning MLPs and AdaLN linears):
@@ -397,24 +431,45 @@ extern "C" int orv_gated_residual_bwd(const void* dout, const void* y, const flo
     return orv_check_launch("orv_gated_residual_bwd");
 }
 
+static void ln_bwd_blocks(orv_groups_t grp, int& bt, int& bg, int& bpb) {
+    const int vid = grp.seq - grp.n_text;
+    const int gsz = grp.per_group > 0 ? grp.per_group : vid;
+    const int ngroups = gsz > 0 ? (vid + gsz - 1) / gsz : 0;
+    bt = (grp.n_text + LNB_RB - 1) / LNB_RB;
+    bg = gsz > 0 ? (gsz + LNB_RB - 1) / LNB_RB : 0;
+    bpb = bt + ngroups * bg;
+}
+
+extern "C" long orv_layernorm_modulate_bwd_scratch(orv_groups_t grp, int batch, int D) {
+    int bt, bg, bpb;
+    ln_bwd_blocks(grp, bt, bg, bpb);
+    return (long)batch * bpb * 2 * D;
+}
+
 extern "C" int orv_layernorm_modulate_bwd(const void* dy, const void* x, orv_rowmap_t xmap, const void* dres, void* dx,
                                           const void* gamma, const void* beta, const float* scale, float* dscale,
-                                          float* dshift, float* dgamma, float* dbeta, long mod_b, long mod_g,
+                                          float* dshift, float* dgamma, float* dbeta, float* scratch, long mod_b, long mod_g,
                                           orv_groups_t grp, int batch, int D, float eps, void* stream) {
     ORV_REQUIRE(dy && x && dx, "orv_layernorm_modulate_bwd: null operand");
     ORV_REQUIRE(D % 8 == 0 && D <= 4096, "orv_layernorm_modulate_bwd: D=%d unsupported", D);
     ORV_REQUIRE(!scale || (dscale && dshift), "orv_layernorm_modulate_bwd: dscale/dshift required with scale");
-    const int rows = batch * grp.seq, rpw = rows >= 8192 ? 12 : 4;
-    const int waves = (rows + rpw - 1) / rpw;
-    dim3 grid((waves + 3) / 4);
-    const int ch = (D / 8 + 63) / 64;
+    ORV_REQUIRE(!(dgamma || dbeta) || scratch, "orv_layernorm_modulate_bwd: scratch required for dgamma/dbeta");
+    ORV_REQUIRE(grp.per_group <= 0 || (grp.seq - grp.n_text) % grp.per_group == 0,
+                "orv_layernorm_modulate_bwd: video rows must be a whole number of groups");
+    LnBwdArgs a;
+    a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x; a.dres = (const bf16_t*)dres; a.dx = (bf16_t*)dx;
+    a.gamma = (const bf16_t*)gamma; a.beta = (const bf16_t*)beta; a.scale = scale; a.dscale = dscale; a.dshift = dshift;
+    a.part = (dgamma || dbeta) ? scratch : nullptr;
+    a.mod_b = mod_b; a.mod_g = mod_g; a.seq = grp.seq; a.n_text = grp.n_text; a.per_group = grp.per_group; a.D = D;
+    a.eps = eps; a.xmap = xmap;
+    ln_bwd_blocks(grp, a.bt, a.bg, a.bpb);
+    const int nblk = batch * a.bpb;
     hipStream_t st = (hipStream_t)stream;
-#define ORV_CASE(C)                                                                                                     \
-    hipLaunchKernelGGL(ln_mod_bwd_kernel<C>, grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x,               \
-                       (const bf16_t*)dres, (bf16_t*)dx, (const bf16_t*)gamma, (const bf16_t*)beta, scale, dscale, dshift, \
-                       dgamma, dbeta, mod_b, mod_g, grp.seq, grp.n_text, grp.per_group, rows, D, eps, rpw, xmap)
-    if (ch <= 1) ORV_CASE(1); else if (ch <= 2) ORV_CASE(2); else if (ch <= 4) ORV_CASE(4); else ORV_CASE(6);
-#undef ORV_CASE
+    if (D <= 2048) hipLaunchKernelGGL(ln_mod_bwd_kernel<1>, dim3(nblk), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(ln_mod_bwd_kernel<2>, dim3(nblk), dim3(256), 0, st, a);
+    if (a.part)
+        hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((D + 255) / 256, (nblk + 63) / 64), dim3(256), 0, st, scratch, nblk, D,
+                           dgamma, dbeta);
     return orv_check_launch("orv_layernorm_modulate_bwd");
 }
 
