@@ -175,6 +175,12 @@ int orv_small_linear_bwd(const float* dy, int ldy, const void* x, int ldx, const
  * `clip_coef` (device scalar or NULL) multiplies the gradient (global-norm clipping, train...sft.py:1095-1100). */
 int orv_adamw(void* p, const void* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
               float weight_decay, int step, const float* clip_coef, void* stream);
+/* The same AdamW update over ONE flat buffer (every parameter a segment padded to 2048 elements; seg_start[nseg] int64
+ * element offsets and seg_active[nseg] bytes on the device): one launch per optimizer step instead of one per parameter.
+ * Segments with seg_active == 0 (no gradient this step) are left untouched, as torch.optim.AdamW does. */
+int orv_adamw_flat(void* p, const void* g, float* m, float* v, long n, const long* seg_start,
+                   const unsigned char* seg_active, int nseg, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, const float* clip_coef, void* stream);
 /* out[0] += sum g^2 (gradient-norm reduction, orv/utils.py:166-174). */
 int orv_sumsq(const void* g, long n, float* out, void* stream);
 

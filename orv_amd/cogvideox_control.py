@@ -32,7 +32,7 @@ from typing import Any, Callable, Dict, List, Optional, Tuple, Union
 import torch
 from torch import nn
 
-from . import ops
+from . import _state, ops
 from .components import ActionEmbed, ActionRecon, Transformer3DModelTrajOutput
 from .embeddings import sincos_3d
 from .schedulers import CogVideoXDDIMScheduler, CogVideoXDPMScheduler, retrieve_timesteps
@@ -102,7 +102,7 @@ class Attention(_NoForward):
     def packed_qkv(self):
         """[3*inner, query_dim] weight and [3*inner] bias for the single fused QKV GEMM (cached per weight version)."""
         ws = (self.to_q.weight, self.to_k.weight, self.to_v.weight)
-        key = tuple((w.data_ptr(), w._version) for w in ws)
+        key = tuple((w.data_ptr(), w._version) for w in ws) + (_state.weights_epoch[0],)
         if self._packed is None or self._packed[0] != key:
             w = torch.cat([x.detach() for x in ws], dim=0).contiguous()
             b = None

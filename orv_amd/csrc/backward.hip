@@ -36,80 +36,105 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
     }
 }
 
-// ---- out[c] (+)= sum_r src[r, c]  (bias gradients).  One block = 64 columns x a slab of rows; fp32 atomics across slabs.
+// ---- out[c] += sum_r src[r, c]  (bias gradients).  One block = 512 columns x a slab of rows: thread -> (8-column chunk,
+//      row phase 0..3), 16-byte loads, four rows in flight; LDS combine of the 4 phases, fp32 atomics across slabs.
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ src, long ld, float* __restrict__ out, int R,
                                                      int C, int rows_per_block) {
-    __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    __shared__ float red[3][64][8];
+    const int cc = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c0 = (blockIdx.x * 64 + cc) * 8;
     const int rb = blockIdx.y * rows_per_block, re = min(R, rb + rows_per_block);
-    float s = 0.f;
-    if (c < C)
-        for (int r = rb + w; r < re; r += 4) s += bf2f(src[(long)r * ld + c]);
-    red[w][threadIdx.x & 63] = s;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c0 < C) {
+        for (int r = rb + ph; r < re; r += 16) {
+            uint4 u[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[k] = (r + 4 * k < re) ? *(const uint4*)(src + (long)(r + 4 * k) * ld + c0) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t w[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s[2 * e] += bf2f(w[e] & 0xffff); s[2 * e + 1] += bf2f(w[e] >> 16); }
+            }
+        }
+    }
+    if (ph > 0)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[ph - 1][cc][e] = s[e];
     __syncthreads();
-    if (w == 0 && c < C) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (ph == 0 && c0 < C)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(out + c0 + e, s[e] + red[0][cc][e] + red[1][cc][e] + red[2][cc][e]);
 }
 
 // ---- gated residual backward (cogvideox_control.py:419-421,442-443):  out = x + gate[b,g] * y
-//      dy = gate * dout (bf16);  dgate[b,g,:] += sum_{rows of group} dout * y.  One wave walks RPW consecutive rows and keeps
-//      the gate-gradient partial sums in registers until the group changes (rows of a group are contiguous).
+//      dy = gate * dout (bf16);  dgate[b,g,:] += sum_{rows of group} dout * y.
+//      Same decomposition as the LayerNorm adjoint below: a workgroup owns GRB rows of ONE (batch, token group), its 256
+//      threads split the columns, four rows of loads in flight per thread, the column sums stay in registers and leave as
+//      one fp32 atomic per column and workgroup.
+constexpr int GRB = 32;
 template <int CH>
 __global__ __launch_bounds__(256) void gated_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ y,
                                                         const float* __restrict__ gate, float* __restrict__ dgate,
                                                         bf16_t* __restrict__ dy, long mod_b, long mod_g, int seq, int n_text,
-                                                        int per_group, int rows, int D, int rpw) {
-    const int lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nchunk = D >> 3;
-    const int r0 = wid * rpw, r1 = min(rows, r0 + rpw);
-    if (r0 >= rows) return;
-    float acc[CH][8];
+                                                        int per_group, int D, int bt, int bg, int bpb) {
+    const int tid = threadIdx.x, nchunk = D >> 3;
+    const int b = blockIdx.x / bpb, r = blockIdx.x % bpb;
+    int g, s0, s1;
+    if (r < bt) { g = 0; s0 = r * GRB; s1 = min(n_text, s0 + GRB); }
+    else {
+        const int q = r - bt, gi = q / bg, ck = q % bg;
+        const int gsz = per_group > 0 ? per_group : seq - n_text;
+        const int gstart = n_text + gi * gsz;
+        g = 1 + gi;
+        s0 = gstart + ck * GRB;
+        s1 = min(min(gstart + gsz, seq), s0 + GRB);
+    }
+    const long off = b * mod_b + g * mod_g;
+    float gg[CH][8], acc[CH][8];
 #pragma unroll
-    for (int i = 0; i < CH; ++i)
+    for (int i = 0; i < CH; ++i) {
+        const int c = tid + 256 * i;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
-    long cur_off = -1;
-    for (int row = r0; row < r1; ++row) {
-        const int b = row / seq, s = row % seq;
-        const long off = b * mod_b + orv_group_of(s, n_text, per_group) * mod_g;
-        if (off != cur_off) {
-            if (cur_off >= 0) {
+        for (int e = 0; e < 8; ++e) { gg[i][e] = c < nchunk ? gate[off + c * 8 + e] : 0.f; acc[i][e] = 0.f; }
+    }
+    for (int rb = s0; rb < s1; rb += 4) {
+        uint4 ud[4][CH], uy[4][CH];
 #pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                    const int c = lane + 64 * i;
-                    if (c < nchunk)
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) { atomicAdd(dgate + cur_off + c * 8 + e, acc[i][e]); acc[i][e] = 0.f; }
+            for (int i = 0; i < CH; ++i) {
+                const int c = tid + 256 * i;
+                const long row = (long)b * seq + min(rb + k, s1 - 1);
+                if (c < nchunk) { ud[k][i] = *(const uint4*)(dout + row * D + c * 8); uy[k][i] = *(const uint4*)(y + row * D + c * 8); }
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (rb + k >= s1) continue;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int c = tid + 256 * i;
+                if (c >= nchunk) continue;
+                const uint32_t wd[4] = {ud[k][i].x, ud[k][i].y, ud[k][i].z, ud[k][i].w};
+                const uint32_t wy[4] = {uy[k][i].x, uy[k][i].y, uy[k][i].z, uy[k][i].w};
+                uint32_t o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d0 = bf2f(wd[e] & 0xffff), d1 = bf2f(wd[e] >> 16);
+                    acc[i][2 * e] += d0 * bf2f(wy[e] & 0xffff);
+                    acc[i][2 * e + 1] += d1 * bf2f(wy[e] >> 16);
+                    o[e] = pack2bf(d0 * gg[i][2 * e], d1 * gg[i][2 * e + 1]);
                 }
+                *(uint4*)(dy + ((long)b * seq + rb + k) * D + c * 8) = make_uint4(o[0], o[1], o[2], o[3]);
             }
-            cur_off = off;
-        }
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int c = lane + 64 * i;
-            if (c >= nchunk) continue;
-            const uint4 ud = *(const uint4*)(dout + (long)row * D + c * 8);
-            const uint4 uy = *(const uint4*)(y + (long)row * D + c * 8);
-            const float4 g0 = *(const float4*)(gate + off + c * 8), g1 = *(const float4*)(gate + off + c * 8 + 4);
-            const uint32_t wd[4] = {ud.x, ud.y, ud.z, ud.w}, wy[4] = {uy.x, uy.y, uy.z, uy.w};
-            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-            uint32_t o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float d0 = bf2f(wd[e] & 0xffff), d1 = bf2f(wd[e] >> 16);
-                acc[i][2 * e] += d0 * bf2f(wy[e] & 0xffff);
-                acc[i][2 * e + 1] += d1 * bf2f(wy[e] >> 16);
-                o[e] = pack2bf(d0 * gg[2 * e], d1 * gg[2 * e + 1]);
-            }
-            *(uint4*)(dy + (long)row * D + c * 8) = make_uint4(o[0], o[1], o[2], o[3]);
         }
     }
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-        const int c = lane + 64 * i;
+        const int c = tid + 256 * i;
         if (c < nchunk)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(dgate + cur_off + c * 8 + e, acc[i][e]);
+            for (int e = 0; e < 8; ++e) atomicAdd(dgate + off + c * 8 + e, acc[i][e]);
     }
 }
 
@@ -375,6 +400,39 @@ __global__ void adamw_kernel(bf16_t* __restrict__ p, const bf16_t* __restrict__ 
     p[i] = f2bf(pv);
 }
 
+// ---- the same update over ONE flat buffer holding every parameter (segments padded to 2048 elements): a workgroup owns
+//      2048 consecutive elements = one segment; segments whose parameter had no gradient this step are skipped
+//      (torch.optim semantics: no decay, no moment update).  16-byte accesses throughout (22 bytes of traffic per element).
+__global__ __launch_bounds__(256) void adamw_flat_kernel(bf16_t* __restrict__ p, const bf16_t* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v,
+                                                         const long* __restrict__ seg_start, const uint8_t* __restrict__ active,
+                                                         int nseg, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                         float bc2, const float* __restrict__ clip) {
+    const long e0 = (long)blockIdx.x * 2048;
+    int lo = 0, hi = nseg - 1;                 // last segment with seg_start <= e0 (wave-uniform binary search)
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (seg_start[mid] <= e0) lo = mid; else hi = mid - 1; }
+    if (!active[lo]) return;
+    const long i = e0 + threadIdx.x * 8;
+    const float c = clip ? *clip : 1.f;
+    const uint4 up = *(const uint4*)(p + i), ug = *(const uint4*)(g + i);
+    float4 m0 = *(const float4*)(m + i), m1 = *(const float4*)(m + i + 4), v0 = *(const float4*)(v + i), v1 = *(const float4*)(v + i + 4);
+    float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w}, vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    const uint32_t wp[4] = {up.x, up.y, up.z, up.w}, wg[4] = {ug.x, ug.y, ug.z, ug.w};
+    float pv[8];
+    const float decay = 1.f - lr * wd, ibc1 = 1.f / bc1, ibc2 = 1.f / bc2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float gr = bf2f((e & 1) ? wg[e >> 1] >> 16 : wg[e >> 1] & 0xffff) * c;
+        const float pe = bf2f((e & 1) ? wp[e >> 1] >> 16 : wp[e >> 1] & 0xffff);
+        mm[e] = b1 * mm[e] + (1.f - b1) * gr;
+        vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
+        pv[e] = pe * decay - lr * (mm[e] * ibc1) / (sqrtf(vv[e] * ibc2) + eps);
+    }
+    *(float4*)(m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]); *(float4*)(m + i + 4) = make_float4(mm[4], mm[5], mm[6], mm[7]);
+    *(float4*)(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]); *(float4*)(v + i + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
+    *(uint4*)(p + i) = make_uint4(pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3]), pack2bf(pv[4], pv[5]), pack2bf(pv[6], pv[7]));
+}
+
 // ---- out[0] += sum g^2 (global gradient norm)
 __global__ __launch_bounds__(256) void sumsq_kernel(const bf16_t* __restrict__ g, long n, float* __restrict__ out) {
     __shared__ float red[4];
@@ -408,37 +466,42 @@ extern "C" int orv_transpose_bf16(const void* src, int ld_src, void* dst, int ld
 
 extern "C" int orv_colsum(const void* src, int ld, float* out, int R, int C, void* stream) {
     ORV_REQUIRE(src && out && R > 0 && C > 0, "orv_colsum: bad arguments");
-    const int rpb = 512;
-    dim3 grid((C + 63) / 64, (R + rpb - 1) / rpb);
+    ORV_REQUIRE(C % 8 == 0 && ld % 8 == 0 && ((uintptr_t)src & 15) == 0, "orv_colsum: C / ld must be multiples of 8, src 16-byte aligned");
+    const int cblocks = (C + 511) / 512;
+    int rpb = 256;
+    while (rpb > 32 && (long)cblocks * ((R + rpb - 1) / rpb) < 512) rpb >>= 1;   // enough workgroups for 256 CUs
+    dim3 grid(cblocks, (R + rpb - 1) / rpb);
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (long)ld, out, R, C, rpb);
     return orv_check_launch("orv_colsum");
+}
+
+static void group_blocks(orv_groups_t grp, int rb, int& bt, int& bg, int& bpb) {
+    const int vid = grp.seq - grp.n_text;
+    const int gsz = grp.per_group > 0 ? grp.per_group : vid;
+    const int ngroups = gsz > 0 ? (vid + gsz - 1) / gsz : 0;
+    bt = (grp.n_text + rb - 1) / rb;
+    bg = gsz > 0 ? (gsz + rb - 1) / rb : 0;
+    bpb = bt + ngroups * bg;
 }
 
 extern "C" int orv_gated_residual_bwd(const void* dout, const void* y, const float* gate, float* dgate, void* dy,
                                       long mod_b, long mod_g, orv_groups_t grp, int batch, int D, void* stream) {
     ORV_REQUIRE(dout && y && gate && dgate && dy, "orv_gated_residual_bwd: null operand");
     ORV_REQUIRE(D % 8 == 0 && D <= 4096, "orv_gated_residual_bwd: D=%d unsupported", D);
-    const int rows = batch * grp.seq, rpw = 8;
-    const int waves = (rows + rpw - 1) / rpw;
-    dim3 grid((waves + 3) / 4);
-    const int ch = (D / 8 + 63) / 64;
+    ORV_REQUIRE(grp.per_group <= 0 || (grp.seq - grp.n_text) % grp.per_group == 0,
+                "orv_gated_residual_bwd: video rows must be a whole number of groups");
+    int bt, bg, bpb;
+    group_blocks(grp, GRB, bt, bg, bpb);
     hipStream_t st = (hipStream_t)stream;
 #define ORV_CASE(C)                                                                                                    \
-    hipLaunchKernelGGL(gated_bwd_kernel<C>, grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)y, gate, dgate, \
-                       (bf16_t*)dy, mod_b, mod_g, grp.seq, grp.n_text, grp.per_group, rows, D, rpw)
-    if (ch <= 1) ORV_CASE(1); else if (ch <= 2) ORV_CASE(2); else if (ch <= 4) ORV_CASE(4); else if (ch <= 6) ORV_CASE(6); else ORV_CASE(8);
+    hipLaunchKernelGGL(gated_bwd_kernel<C>, dim3(batch * bpb), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)y, gate, \
+                       dgate, (bf16_t*)dy, mod_b, mod_g, grp.seq, grp.n_text, grp.per_group, D, bt, bg, bpb)
+    if (D <= 2048) ORV_CASE(1); else ORV_CASE(2);
 #undef ORV_CASE
     return orv_check_launch("orv_gated_residual_bwd");
 }
 
-static void ln_bwd_blocks(orv_groups_t grp, int& bt, int& bg, int& bpb) {
-    const int vid = grp.seq - grp.n_text;
-    const int gsz = grp.per_group > 0 ? grp.per_group : vid;
-    const int ngroups = gsz > 0 ? (vid + gsz - 1) / gsz : 0;
-    bt = (grp.n_text + LNB_RB - 1) / LNB_RB;
-    bg = gsz > 0 ? (gsz + LNB_RB - 1) / LNB_RB : 0;
-    bpb = bt + ngroups * bg;
-}
+static void ln_bwd_blocks(orv_groups_t grp, int& bt, int& bg, int& bpb) { group_blocks(grp, LNB_RB, bt, bg, bpb); }
 
 extern "C" long orv_layernorm_modulate_bwd_scratch(orv_groups_t grp, int batch, int D) {
     int bt, bg, bpb;
@@ -500,6 +563,18 @@ extern "C" int orv_adamw(void* p, const void* g, float* m, float* v, long n, flo
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)p,
                        (const bf16_t*)g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, clip_coef);
     return orv_check_launch("orv_adamw");
+}
+
+extern "C" int orv_adamw_flat(void* p, const void* g, float* m, float* v, long n, const long* seg_start,
+                              const unsigned char* seg_active, int nseg, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, int step, const float* clip_coef, void* stream) {
+    ORV_REQUIRE(p && g && m && v && seg_start && seg_active && nseg > 0 && step > 0, "orv_adamw_flat: bad arguments");
+    ORV_REQUIRE(n > 0 && n % 2048 == 0, "orv_adamw_flat: n=%ld must be a multiple of 2048 (pad every segment)", n);
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)(n / 2048)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)p,
+                       (const bf16_t*)g, m, v, seg_start, seg_active, nseg, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
+                       clip_coef);
+    return orv_check_launch("orv_adamw_flat");
 }
 
 extern "C" int orv_sumsq(const void* g, long n, float* out, void* stream) {

@@ -1,50 +1,115 @@
 """Fused AdamW + global-norm clipping for the bf16-parameter training of the reference
 (/root/reference/config/base_train.yaml:143-153: AdamW, betas 0.9/0.95, wd 1e-3, eps 1e-8, max_grad_norm 1.0;
-/root/reference/orv/pipeline/train_cogvideox_control_to_video_sft.py:1095-1104: clip then step).  One ``orv_sumsq`` launch
-per gradient accumulates the squared norm on the device, the clip coefficient stays on the device (no host sync in the
-step), and ``orv_adamw`` applies clip + moment update + decoupled weight decay + bf16 write in one pass per parameter.
-Moments are fp32 (the reference keeps them in the parameter dtype; 13.5 GB for 1.69 B parameters is affordable here)."""
+/root/reference/orv/pipeline/train_cogvideox_control_to_video_sft.py:1095-1104: clip then step).
+
+MI355X layout: every trainable parameter becomes a view into ONE flat bf16 buffer (segments padded to 2048 elements), with
+flat bf16 gradient and fp32 moment buffers beside it (1.69 B parameters: 3.4 + 3.4 + 6.8 + 6.8 GB of the 288 GB).  A step
+is then: gather the autograd gradients into the flat buffer (multi-tensor copy) -> optional RCCL all-reduce of the flat
+buffer in 256 MB pieces -> ONE ``orv_sumsq`` -> clip coefficient on the device (no host sync before the update) -> ONE
+``orv_adamw_flat`` (clip + moments + decoupled decay + bf16 write, 16-byte accesses).  Parameters that received no gradient
+in a step are skipped exactly as ``torch.optim.AdamW`` skips them (segment activity mask).  Moments are fp32 (the reference
+keeps them in the parameter dtype)."""
 from __future__ import annotations
 
-from typing import Iterable
+from typing import Iterable, List, Optional
 
 import torch
 
-from . import ops
+from . import _state, ops
+
+_SEG = 2048          # elements per workgroup of orv_adamw_flat; every segment is padded to a multiple of it
+_AR_CHUNK = 128 * 1024 * 1024   # bf16 elements per all-reduce call (256 MB: large enough that xGMI link bandwidth, not
+#                                 launch latency, bounds the ring)
 
 
 class FusedAdamW:
     def __init__(self, params: Iterable[torch.nn.Parameter], lr=1e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=1e-3,
                  max_grad_norm: float = 1.0):
-        self.params = [p for p in params if p.requires_grad]
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
-        self.state = {}
         self.step_count = 0
         self.param_groups = [{"lr": lr, "params": self.params}]      # lr schedulers poke param_groups[0]["lr"]
+        self._flat = None
+
+    # ---- flat storage ----
+    def _build(self):
+        dev = self.params[0].device
+        for p in self.params:
+            if p.dtype != torch.bfloat16 or p.device != dev:
+                raise RuntimeError("FusedAdamW: parameters must be bf16 tensors on one GPU (call model.to(device, bfloat16) first)")
+        offs, o = [], 0
+        for p in self.params:
+            offs.append(o)
+            o += (p.numel() + _SEG - 1) // _SEG * _SEG
+        total = o
+        flat_p = torch.zeros(total, dtype=torch.bfloat16, device=dev)
+        views_p, views_g = [], []
+        flat_g = torch.zeros(total, dtype=torch.bfloat16, device=dev)
+        for p, off in zip(self.params, offs):
+            v = flat_p[off:off + p.numel()].view(p.shape)
+            v.copy_(p.data)
+            p.data = v                                   # the module keeps its Parameter objects; only their storage moves
+            views_p.append(v)
+            views_g.append(flat_g[off:off + p.numel()].view(p.shape))
+        self._flat = dict(
+            p=flat_p, g=flat_g, m=torch.zeros(total, dtype=torch.float32, device=dev),
+            v=torch.zeros(total, dtype=torch.float32, device=dev), views_g=views_g,
+            seg_start=torch.tensor(offs + [total], dtype=torch.int64, device=dev),
+            active=torch.zeros(len(self.params), dtype=torch.uint8, device=dev), active_host=[False] * len(self.params))
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
             p.grad = None
 
     @torch.no_grad()
-    def step(self) -> float:
-        """Returns the pre-clip global gradient norm (one host read, after all kernels are queued)."""
-        live = [p for p in self.params if p.grad is not None]
-        if not live:
+    def step(self, average_over: Optional[int] = None) -> float:
+        """One update.  ``average_over=world_size`` first averages the flat gradient buffer over the default process group
+        (data parallel, one exchange per step).  Returns the pre-clip global gradient norm (the only host read, issued after
+        every kernel of the step is queued)."""
+        if not self.params:
             return 0.0
-        dev = live[0].device
+        if self._flat is None:
+            self._build()
+        f = self._flat
+        live = [p.grad is not None for p in self.params]
+        if not any(live):
+            return 0.0
+        srcs = [p.grad for p, a in zip(self.params, live) if a]
+        dsts = [v for v, a in zip(f["views_g"], live) if a]
+        torch._foreach_copy_(dsts, srcs)
+        if live != f["active_host"]:
+            for v, was, now in zip(f["views_g"], f["active_host"], live):
+                if was and not now:
+                    v.zero_()                            # stale gradient of a parameter that got none this step
+            f["active"].copy_(torch.tensor(live, dtype=torch.uint8))
+            f["active_host"] = live
+        if average_over and average_over > 1:
+            import torch.distributed as dist
+            g = f["g"]
+            for s in range(0, g.numel(), _AR_CHUNK):
+                dist.all_reduce(g[s:s + _AR_CHUNK])
+            g.mul_(1.0 / average_over)
+        dev = f["p"].device
         ss = torch.zeros(1, dtype=torch.float32, device=dev)
-        for p in live:
-            ops.sumsq(p.grad.contiguous(), ss)
+        ops.sumsq(f["g"], ss)
         norm = ss.sqrt()
         clip = torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0) if self.max_grad_norm else torch.ones_like(norm)
         self.step_count += 1
-        lr = self.param_groups[0]["lr"]
-        for p in live:
-            st = self.state.get(id(p))
-            if st is None:
-                st = (torch.zeros(p.shape, dtype=torch.float32, device=dev), torch.zeros(p.shape, dtype=torch.float32, device=dev))
-                self.state[id(p)] = st
-            ops.adamw(p.data, p.grad.contiguous(), st[0], st[1], lr, self.betas[0], self.betas[1], self.eps,
-                      self.weight_decay, self.step_count, clip)
+        ops.adamw_flat(f["p"], f["g"], f["m"], f["v"], f["seg_start"], f["active"], self.param_groups[0]["lr"], self.betas[0],
+                       self.betas[1], self.eps, self.weight_decay, self.step_count, clip)
+        _state.bump_weights_epoch()      # parameters changed without a tensor._version bump: drop derived-weight caches
         return float(norm.item())
+
+    # ---- checkpointing (torch.optim-like) ----
+    def state_dict(self):
+        if self._flat is None:
+            return {"step": self.step_count, "exp_avg": None, "exp_avg_sq": None}
+        return {"step": self.step_count, "exp_avg": self._flat["m"], "exp_avg_sq": self._flat["v"]}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        if sd.get("exp_avg") is not None:
+            if self._flat is None:
+                self._build()
+            self._flat["m"].copy_(sd["exp_avg"])
+            self._flat["v"].copy_(sd["exp_avg_sq"])

@@ -141,17 +141,18 @@ def sft_loss(transformer, scheduler, b: Batch, noise: torch.Tensor, timesteps: t
 def sft_step(transformer, scheduler, optimizer, b: Batch, generator: Optional[torch.Generator] = None,
              use_rope: bool = False, is_ofs_embed: bool = False, data_parallel: bool = False):
     """One optimizer step (:1005-1104).  ``optimizer`` is ``orv_amd.optim.FusedAdamW`` (global-norm clip inside, on
-    device).  With ``data_parallel`` the bf16 gradients are averaged over the RCCL group in 256 MB buckets first."""
+    device).  With ``data_parallel`` the flat bf16 gradient buffer is averaged over the RCCL group in 256 MB pieces first."""
     dev = b.video_latents.device
     noise = torch.randn(b.video_latents.shape, device=dev, dtype=torch.float32, generator=generator).to(b.video_latents.dtype)
     timesteps = torch.randint(0, scheduler.config.num_train_timesteps, (b.video_latents.shape[0],), dtype=torch.int64,
                               device=dev, generator=generator)                          # :1013-1019
     loss, parts = sft_loss(transformer, scheduler, b, noise, timesteps, use_rope, is_ofs_embed)
     loss.backward()
+    world = 1
     if data_parallel:
-        from .sharding import allreduce_gradients
-        allreduce_gradients(transformer.parameters())
-    grad_norm = optimizer.step()
+        import torch.distributed as dist
+        world = dist.get_world_size()
+    grad_norm = optimizer.step(average_over=world)       # gradients are averaged inside, on the flat buffer
     optimizer.zero_grad()
     parts["grad_norm"] = grad_norm
     return loss.detach(), parts

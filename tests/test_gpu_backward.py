@@ -189,3 +189,40 @@ def test_small_linear_bwd_adamw_sumsq():
     ss = torch.zeros(1, device=dev)
     ops.sumsq(gr.to(dev, BF), ss)
     assert abs(ss.item() - float((gr ** 2).sum())) <= 1e-3 * float((gr ** 2).sum())
+
+
+def test_fused_adamw_flat_matches_torch_adamw():
+    """FusedAdamW (flat buffers, one sumsq + one adamw launch, device-side clip) against torch.optim.AdamW +
+    clip_grad_norm_ in fp32 on the same bf16-rounded gradients; a parameter without gradient is left untouched; derived
+    weight caches (packed QKV) see the update."""
+    from orv_amd.cogvideox_control import Attention
+    from orv_amd.optim import FusedAdamW
+    dev = _dev()
+    torch.manual_seed(0)
+    at = Attention(128, 2, 64, bias=True, out_bias=True).to(dev, BF)
+    extra = torch.nn.Parameter(torch.randn(777, device=dev).to(BF))          # odd size: exercises the segment padding
+    unused = torch.nn.Parameter(torch.randn(33, device=dev).to(BF))
+    params = list(at.parameters()) + [extra, unused]
+    ref = [p.detach().float().clone().requires_grad_(True) for p in params]
+    topt = torch.optim.AdamW(ref, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=1e-3)
+    opt = FusedAdamW(params, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=1e-3, max_grad_norm=1.0)
+    unused0 = unused.detach().clone()
+    for it in range(3):
+        for p, r in zip(params, ref):
+            if p is unused:
+                continue
+            g = (torch.randn(p.shape, device=dev) * (3.0 if it == 0 else 0.05)).to(BF)    # step 0 clips, later ones do not
+            p.grad = g.clone()
+            r.grad = g.float()
+        tn = torch.nn.utils.clip_grad_norm_([r for r in ref if r.grad is not None], 1.0)
+        topt.step()
+        n = opt.step()
+        opt.zero_grad()
+        assert abs(n - tn.item()) <= 2e-3 * tn.item()
+    for p, r in zip(params, ref):
+        if p is unused:
+            assert torch.equal(p.detach(), unused0)
+            continue
+        close(p.detach().float().cpu(), r.detach().cpu(), rtol=2e-2, afrac=1e-2)       # bf16 parameter storage
+    w, b = at.packed_qkv()
+    assert torch.equal(w, torch.cat([at.to_q.weight, at.to_k.weight, at.to_v.weight]).detach())
