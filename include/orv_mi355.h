@@ -156,12 +156,13 @@ int orv_transpose_bf16(const void* src, int ld_src, void* dst, int ld_dst, int R
 /* out[c] += sum_r src[r, c] (fp32 atomics): bias gradients. */
 int orv_colsum(const void* src, int ld, float* out, int R, int C, void* stream);
 /* Adjoint of out = x + gate[b,g(row)] * y (cogvideox_control.py:419-421,442-443): dy = gate * dout (bf16),
- * dgate[b,g,:] += sum_rows dout * y (fp32 atomics into a table laid out like `gate`). */
-int orv_gated_residual_bwd(const void* dout, const void* y, const float* gate, float* dgate, void* dy, long mod_b,
-                           long mod_g, orv_groups_t grp, int batch, int D, void* stream);
+ * dgate[b,g,:] += sum_rows dout * y (table laid out like `gate`; per-workgroup partials in `scratch`, then reduced). */
+long orv_gated_residual_bwd_scratch(orv_groups_t grp, int batch, int D);   /* floats of per-workgroup partial sums */
+int orv_gated_residual_bwd(const void* dout, const void* y, const float* gate, float* dgate, void* dy, float* scratch,
+                           long mod_b, long mod_g, orv_groups_t grp, int batch, int D, void* stream);
 /* Adjoint of orv_layernorm_modulate: dx[xmap(r)] = LN-path gradient (+ dres[xmap(r)] if given), and fp32 sums
- * dscale/dshift (tables like scale/shift; atomics), dgamma/dbeta [D] (accumulated; per-workgroup partials in `scratch`,
- * orv_layernorm_modulate_bwd_scratch() floats, then reduced).  Any output may be NULL when the forward had none. */
+ * dscale/dshift (tables like scale/shift, +=), dgamma/dbeta [D] (+=): per-workgroup partial column sums go to `scratch`
+ * (orv_layernorm_modulate_bwd_scratch() floats) and are reduced by two small kernels.  Any output may be NULL. */
 long orv_layernorm_modulate_bwd_scratch(orv_groups_t grp, int batch, int D);
 int orv_layernorm_modulate_bwd(const void* dy, const void* x, orv_rowmap_t xmap, const void* dres, void* dx,
                                const void* gamma, const void* beta, const float* scale, float* dscale, float* dshift,

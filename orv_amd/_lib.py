@@ -53,8 +53,9 @@ SIGNATURES = {
                                   c_float, c_void_p]),
     "orv_transpose_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "orv_colsum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
-    "orv_gated_residual_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, Groups, c_int, c_int,
-                                       c_void_p]),
+    "orv_gated_residual_bwd_scratch": (c_long, [Groups, c_int, c_int]),
+    "orv_gated_residual_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, Groups, c_int,
+                                       c_int, c_void_p]),
     "orv_layernorm_modulate_bwd_scratch": (c_long, [Groups, c_int, c_int]),
     "orv_layernorm_modulate_bwd": (c_int, [c_void_p, c_void_p, RowMap, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, Groups, c_int,

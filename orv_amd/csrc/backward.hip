@@ -67,6 +67,26 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
         for (int e = 0; e < 8; ++e) atomicAdd(out + c0 + e, s[e] + red[0][cc][e] + red[1][cc][e] + red[2][cc][e]);
 }
 
+// out[b, g, j] += sum over the workgroups of (b, g) of part[blk * stride + sel * D + j]   (sel = sel0 -> out0, sel1 -> out1)
+// The workgroups of one (batch, token group) are consecutive and each table entry has one writer: plain +=.
+__global__ __launch_bounds__(256) void groups_reduce_kernel(const float* __restrict__ part, long stride, int sel0, int sel1,
+                                                            int D, float* __restrict__ out0, float* __restrict__ out1,
+                                                            long mod_b, long mod_g, int bt, int bg, int bpb, int ngroups) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= D) return;
+    const int b = blockIdx.y / (1 + ngroups), g = blockIdx.y % (1 + ngroups);
+    const int first = b * bpb + (g == 0 ? 0 : bt + (g - 1) * bg), count = g == 0 ? bt : bg;
+    if (count == 0) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (int k = 0; k < count; ++k) {
+        s0 += part[(long)(first + k) * stride + (long)sel0 * D + j];
+        if (out1) s1 += part[(long)(first + k) * stride + (long)sel1 * D + j];
+    }
+    const long off = b * mod_b + g * mod_g + j;
+    out0[off] += s0;
+    if (out1) out1[off] += s1;
+}
+
 // ---- gated residual backward (cogvideox_control.py:419-421,442-443):  out = x + gate[b,g] * y
 //      dy = gate * dout (bf16);  dgate[b,g,:] += sum_{rows of group} dout * y.
 //      Same decomposition as the LayerNorm adjoint below: a workgroup owns GRB rows of ONE (batch, token group), its 256
@@ -77,7 +97,7 @@ template <int CH>
 __global__ __launch_bounds__(256) void gated_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ y,
                                                         const float* __restrict__ gate, float* __restrict__ dgate,
                                                         bf16_t* __restrict__ dy, long mod_b, long mod_g, int seq, int n_text,
-                                                        int per_group, int D, int bt, int bg, int bpb) {
+                                                        int per_group, int D, int bt, int bg, int bpb, float* __restrict__ part) {
     const int tid = threadIdx.x, nchunk = D >> 3;
     const int b = blockIdx.x / bpb, r = blockIdx.x % bpb;
     int g, s0, s1;
@@ -132,9 +152,11 @@ __global__ __launch_bounds__(256) void gated_bwd_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
         const int c = tid + 256 * i;
-        if (c < nchunk)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(dgate + off + c * 8 + e, acc[i][e]);
+        if (c < nchunk) {
+            float* pg = part + (long)blockIdx.x * D + c * 8;      // per-workgroup partial, summed by groups_reduce_kernel
+            *(float4*)pg = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+            *(float4*)(pg + 4) = make_float4(acc[i][4], acc[i][5], acc[i][6], acc[i][7]);
+        }
     }
 }
 
@@ -155,7 +177,8 @@ struct LnBwdArgs {
     const bf16_t *dy, *x, *dres; bf16_t* dx;
     const bf16_t *gamma, *beta;
     const float* scale; float *dscale, *dshift;
-    float* part;           // [blocks][2][D] (dgamma | dbeta partials) or null
+    float* part;           // [blocks][4][D] partial column sums (dgamma | dbeta | dscale | dshift)
+    int want_gb;
     long mod_b, mod_g;
     int seq, n_text, per_group, D;
     float eps;
@@ -301,25 +324,29 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const LnBwdArgs p) {
 #undef ORV_BLOCK_SUM
 #undef ORV_BLOCK_GET
     }
-    // ---- column sums out ----
+    // ---- column sums out: per-workgroup partials [blk][4][D] = dgamma | dbeta | dscale | dshift (plain stores; 3 M fp32
+    //      atomics into the modulation tables cost 90 us per call), summed by the two reduce kernels below ----
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
         if (!live[i]) continue;
         const int c = tid + 256 * i;
-        if (p.scale) {
+        float* pg = p.part + (long)blockIdx.x * 4 * D + c * 8;
+        float o0[8], o1[8], o2[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float bet = p.beta ? bf2f(p.beta[c * 8 + e]) : 0.f;
-                atomicAdd(p.dshift + off + c * 8 + e, a1[i][e]);
-                atomicAdd(p.dscale + off + c * 8 + e, gam[i][e] * a2[i][e] + bet * a1[i][e]);
-            }
+        for (int e = 0; e < 8; ++e) {
+            const float bet = p.beta ? bf2f(p.beta[c * 8 + e]) : 0.f;
+            o0[e] = osc[i][e] * a2[i][e];
+            o1[e] = osc[i][e] * a1[i][e];
+            o2[e] = gam[i][e] * a2[i][e] + bet * a1[i][e];
         }
-        if (p.part) {
-            float* pg = p.part + (long)blockIdx.x * 2 * D + c * 8;
-            *(float4*)(pg) = make_float4(osc[i][0] * a2[i][0], osc[i][1] * a2[i][1], osc[i][2] * a2[i][2], osc[i][3] * a2[i][3]);
-            *(float4*)(pg + 4) = make_float4(osc[i][4] * a2[i][4], osc[i][5] * a2[i][5], osc[i][6] * a2[i][6], osc[i][7] * a2[i][7]);
-            *(float4*)(pg + D) = make_float4(osc[i][0] * a1[i][0], osc[i][1] * a1[i][1], osc[i][2] * a1[i][2], osc[i][3] * a1[i][3]);
-            *(float4*)(pg + D + 4) = make_float4(osc[i][4] * a1[i][4], osc[i][5] * a1[i][5], osc[i][6] * a1[i][6], osc[i][7] * a1[i][7]);
+        if (p.want_gb) {
+            *(float4*)(pg) = make_float4(o0[0], o0[1], o0[2], o0[3]); *(float4*)(pg + 4) = make_float4(o0[4], o0[5], o0[6], o0[7]);
+            *(float4*)(pg + D) = make_float4(o1[0], o1[1], o1[2], o1[3]); *(float4*)(pg + D + 4) = make_float4(o1[4], o1[5], o1[6], o1[7]);
+        }
+        if (p.scale) {
+            *(float4*)(pg + 2 * D) = make_float4(o2[0], o2[1], o2[2], o2[3]); *(float4*)(pg + 2 * D + 4) = make_float4(o2[4], o2[5], o2[6], o2[7]);
+            *(float4*)(pg + 3 * D) = make_float4(a1[i][0], a1[i][1], a1[i][2], a1[i][3]);
+            *(float4*)(pg + 3 * D + 4) = make_float4(a1[i][4], a1[i][5], a1[i][6], a1[i][7]);
         }
     }
 }
@@ -331,7 +358,7 @@ __global__ __launch_bounds__(256) void ln_partials_reduce_kernel(const float* __
     if (j >= D) return;
     const int b0 = blockIdx.y * 64, b1 = min(nblk, b0 + 64);
     float s0 = 0.f, s1 = 0.f;
-    for (int b = b0; b < b1; ++b) { s0 += part[(long)b * 2 * D + j]; s1 += part[(long)b * 2 * D + D + j]; }
+    for (int b = b0; b < b1; ++b) { s0 += part[(long)b * 4 * D + j]; s1 += part[(long)b * 4 * D + D + j]; }
     if (out0) atomicAdd(out0 + j, s0);
     if (out1) atomicAdd(out1 + j, s1);
 }
@@ -484,9 +511,15 @@ static void group_blocks(orv_groups_t grp, int rb, int& bt, int& bg, int& bpb) {
     bpb = bt + ngroups * bg;
 }
 
-extern "C" int orv_gated_residual_bwd(const void* dout, const void* y, const float* gate, float* dgate, void* dy,
+extern "C" long orv_gated_residual_bwd_scratch(orv_groups_t grp, int batch, int D) {
+    int bt, bg, bpb;
+    group_blocks(grp, GRB, bt, bg, bpb);
+    return (long)batch * bpb * D;
+}
+
+extern "C" int orv_gated_residual_bwd(const void* dout, const void* y, const float* gate, float* dgate, void* dy, float* scratch,
                                       long mod_b, long mod_g, orv_groups_t grp, int batch, int D, void* stream) {
-    ORV_REQUIRE(dout && y && gate && dgate && dy, "orv_gated_residual_bwd: null operand");
+    ORV_REQUIRE(dout && y && gate && dgate && dy && scratch, "orv_gated_residual_bwd: null operand");
     ORV_REQUIRE(D % 8 == 0 && D <= 4096, "orv_gated_residual_bwd: D=%d unsupported", D);
     ORV_REQUIRE(grp.per_group <= 0 || (grp.seq - grp.n_text) % grp.per_group == 0,
                 "orv_gated_residual_bwd: video rows must be a whole number of groups");
@@ -495,9 +528,12 @@ extern "C" int orv_gated_residual_bwd(const void* dout, const void* y, const flo
     hipStream_t st = (hipStream_t)stream;
 #define ORV_CASE(C)                                                                                                    \
     hipLaunchKernelGGL(gated_bwd_kernel<C>, dim3(batch * bpb), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)y, gate, \
-                       dgate, (bf16_t*)dy, mod_b, mod_g, grp.seq, grp.n_text, grp.per_group, D, bt, bg, bpb)
+                       dgate, (bf16_t*)dy, mod_b, mod_g, grp.seq, grp.n_text, grp.per_group, D, bt, bg, bpb, scratch)
     if (D <= 2048) ORV_CASE(1); else ORV_CASE(2);
 #undef ORV_CASE
+    const int ngroups = bg > 0 ? (bpb - bt) / bg : 0;
+    hipLaunchKernelGGL(groups_reduce_kernel, dim3((D + 255) / 256, batch * (1 + ngroups)), dim3(256), 0, st, scratch, (long)D, 0, 0, D,
+                       dgate, (float*)nullptr, mod_b, mod_g, bt, bg, bpb, ngroups);
     return orv_check_launch("orv_gated_residual_bwd");
 }
 
@@ -506,7 +542,7 @@ static void ln_bwd_blocks(orv_groups_t grp, int& bt, int& bg, int& bpb) { group_
 extern "C" long orv_layernorm_modulate_bwd_scratch(orv_groups_t grp, int batch, int D) {
     int bt, bg, bpb;
     ln_bwd_blocks(grp, bt, bg, bpb);
-    return (long)batch * bpb * 2 * D;
+    return (long)batch * bpb * 4 * D;
 }
 
 extern "C" int orv_layernorm_modulate_bwd(const void* dy, const void* x, orv_rowmap_t xmap, const void* dres, void* dx,
@@ -516,13 +552,13 @@ extern "C" int orv_layernorm_modulate_bwd(const void* dy, const void* x, orv_row
     ORV_REQUIRE(dy && x && dx, "orv_layernorm_modulate_bwd: null operand");
     ORV_REQUIRE(D % 8 == 0 && D <= 4096, "orv_layernorm_modulate_bwd: D=%d unsupported", D);
     ORV_REQUIRE(!scale || (dscale && dshift), "orv_layernorm_modulate_bwd: dscale/dshift required with scale");
-    ORV_REQUIRE(!(dgamma || dbeta) || scratch, "orv_layernorm_modulate_bwd: scratch required for dgamma/dbeta");
+    ORV_REQUIRE(!(dgamma || dbeta || scale) || scratch, "orv_layernorm_modulate_bwd: scratch required for the column sums");
     ORV_REQUIRE(grp.per_group <= 0 || (grp.seq - grp.n_text) % grp.per_group == 0,
                 "orv_layernorm_modulate_bwd: video rows must be a whole number of groups");
     LnBwdArgs a;
     a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x; a.dres = (const bf16_t*)dres; a.dx = (bf16_t*)dx;
     a.gamma = (const bf16_t*)gamma; a.beta = (const bf16_t*)beta; a.scale = scale; a.dscale = dscale; a.dshift = dshift;
-    a.part = (dgamma || dbeta) ? scratch : nullptr;
+    a.part = scratch; a.want_gb = (dgamma || dbeta) ? 1 : 0;
     a.mod_b = mod_b; a.mod_g = mod_g; a.seq = grp.seq; a.n_text = grp.n_text; a.per_group = grp.per_group; a.D = D;
     a.eps = eps; a.xmap = xmap;
     ln_bwd_blocks(grp, a.bt, a.bg, a.bpb);
@@ -530,9 +566,14 @@ extern "C" int orv_layernorm_modulate_bwd(const void* dy, const void* x, orv_row
     hipStream_t st = (hipStream_t)stream;
     if (D <= 2048) hipLaunchKernelGGL(ln_mod_bwd_kernel<1>, dim3(nblk), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(ln_mod_bwd_kernel<2>, dim3(nblk), dim3(256), 0, st, a);
-    if (a.part)
+    if (a.want_gb)
         hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((D + 255) / 256, (nblk + 63) / 64), dim3(256), 0, st, scratch, nblk, D,
                            dgamma, dbeta);
+    if (scale) {
+        const int ngroups = a.bg > 0 ? (a.bpb - a.bt) / a.bg : 0;
+        hipLaunchKernelGGL(groups_reduce_kernel, dim3((D + 255) / 256, batch * (1 + ngroups)), dim3(256), 0, st, scratch, 4L * D, 2,
+                           3, D, dscale, dshift, mod_b, mod_g, a.bt, a.bg, a.bpb, ngroups);
+    }
     return orv_check_launch("orv_layernorm_modulate_bwd");
 }
 

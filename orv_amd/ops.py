@@ -242,15 +242,16 @@ def colsum(src, out, R, C, ld=None):
 
 
 def gated_residual_bwd(dout, y, gate, dgate, dy, mod_b, mod_g, grp, batch, D):
-    check(lib().orv_gated_residual_bwd(_p(dout), _p(y), _p(gate), _p(dgate), _p(dy), mod_b, mod_g, grp, batch, D, _stream()),
-          "orv_gated_residual_bwd")
+    scratch = torch.empty(lib().orv_gated_residual_bwd_scratch(grp, batch, D), dtype=torch.float32, device=dout.device)
+    check(lib().orv_gated_residual_bwd(_p(dout), _p(y), _p(gate), _p(dgate), _p(dy), _p(scratch), mod_b, mod_g, grp, batch, D,
+                                       _stream()), "orv_gated_residual_bwd")
     return dy
 
 
 def layernorm_modulate_bwd(dy, x, dres, dx, gamma, beta, scale, dscale, dshift, dgamma, dbeta, mod_b, mod_g, grp, batch, D,
                            eps, xmap: Optional[RowMap] = None):
     scratch = None
-    if dgamma is not None or dbeta is not None:
+    if dgamma is not None or dbeta is not None or scale is not None:
         scratch = torch.empty(lib().orv_layernorm_modulate_bwd_scratch(grp, batch, D), dtype=torch.float32, device=dy.device)
     check(lib().orv_layernorm_modulate_bwd(_p(dy), _p(x), xmap or RowMap(0, 0, 0), _p(dres), _p(dx), _p(gamma), _p(beta),
                                            _p(scale), _p(dscale), _p(dshift), _p(dgamma), _p(dbeta), _p(scratch), mod_b, mod_g,
