@@ -124,6 +124,11 @@ int orv_modulation_tables(const void* temb, const void* action_emb, const void* 
 int orv_qkv_prep(void* qkv, void* vT, const void* gq, const void* bq, const void* gk, const void* bk,
                  const float* rope_cos, const float* rope_sin, int B, int S, int H, int n_text, int s_pad,
                  float eps, float q_premul, void* stream);
+/* Out-of-place form (training keeps the raw QKV GEMM output for the qk-LayerNorm adjoint): reads `src`, writes the
+ * normalised q / k and the untouched v third to `qkv`.  src == qkv is the in-place call above. */
+int orv_qkv_prep_from(const void* src, void* qkv, void* vT, const void* gq, const void* bq, const void* gk, const void* bk,
+                      const float* rope_cos, const float* rope_sin, int B, int S, int H, int n_text, int s_pad, float eps,
+                      float q_premul, void* stream);
 
 /* -- GEMM ------------------------------------------------------------------------------------- */
 /* C = epilogue(A[M,K] . W[N,K]^T + bias[N]); bf16 operands, fp32 MFMA accumulation, bf16 output.

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const bf16_t* __restrict__ 
 __device__ __forceinline__ int vt_pos(int s) { return (s & ~12) | ((s & 4) << 1) | ((s & 8) >> 1); }
 
 // grid (ceil(S/64), H, B), 256 threads: 64 tokens of one head.
-__global__ __launch_bounds__(256) void qkv_prep_kernel(bf16_t* __restrict__ qkv, bf16_t* __restrict__ vT,
+__global__ __launch_bounds__(256) void qkv_prep_kernel(const bf16_t* src, bf16_t* qkv, bf16_t* __restrict__ vT,
                                                        const bf16_t* __restrict__ gq, const bf16_t* __restrict__ bq,
                                                        const bf16_t* __restrict__ gk, const bf16_t* __restrict__ bk,
                                                        const float* __restrict__ rcos, const float* __restrict__ rsin,
@@ -127,8 +127,9 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(bf16_t* __restrict__ qkv,
         for (int it = 0; it < 2; ++it) {
             const int s = s0 + wave * 16 + it * 8 + (lane >> 3);
             const bool ok = s < S;
-            bf16_t* ptr = qkv + ((long)b * S + (ok ? s : S - 1)) * ld + which * H * 64 + h * 64 + sub * 8;
-            const uint4 u = *(const uint4*)ptr;
+            const long eoff = ((long)b * S + (ok ? s : S - 1)) * ld + which * H * 64 + h * 64 + sub * 8;
+            bf16_t* ptr = qkv + eoff;
+            const uint4 u = *(const uint4*)(src + eoff);
             const uint32_t w[4] = {u.x, u.y, u.z, u.w};
             float v[8], sum = 0.f;
 #pragma unroll
@@ -173,7 +174,11 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(bf16_t* __restrict__ qkv,
         const int tl = wave * 16 + it * 8 + (lane >> 3);
         const int s = s0 + tl;
         uint4 u = make_uint4(0, 0, 0, 0);
-        if (s < S) u = *(const uint4*)(qkv + ((long)b * S + s) * ld + 2 * H * 64 + h * 64 + sub * 8);
+        if (s < S) {
+            const long voff = ((long)b * S + s) * ld + 2 * H * 64 + h * 64 + sub * 8;
+            u = *(const uint4*)(src + voff);
+            if (src != qkv) *(uint4*)(qkv + voff) = u;      // out-of-place form: the v third travels too (attention bwd reads it)
+        }
         uint32_t* dst = (uint32_t*)&vt_s[tl][sub * 8];
         dst[0] = u.x; dst[1] = u.y; dst[2] = u.z; dst[3] = u.w;
     }
@@ -222,16 +227,26 @@ extern "C" int orv_layernorm_modulate(const void* x, int ldx, orv_rowmap_t xmap,
     return orv_check_launch("orv_layernorm_modulate");
 }
 
+extern "C" int orv_qkv_prep_from(const void* src, void* qkv, void* vT, const void* gq, const void* bq, const void* gk,
+                                 const void* bk, const float* rope_cos, const float* rope_sin, int B, int S, int H, int n_text,
+                                 int s_pad, float eps, float q_premul, void* stream);
+
 extern "C" int orv_qkv_prep(void* qkv, void* vT, const void* gq, const void* bq, const void* gk, const void* bk,
                             const float* rope_cos, const float* rope_sin, int B, int S, int H, int n_text, int s_pad,
                             float eps, float q_premul, void* stream) {
-    ORV_REQUIRE(qkv && vT, "orv_qkv_prep: null operand");
+    return orv_qkv_prep_from(qkv, qkv, vT, gq, bq, gk, bk, rope_cos, rope_sin, B, S, H, n_text, s_pad, eps, q_premul, stream);
+}
+
+extern "C" int orv_qkv_prep_from(const void* src, void* qkv, void* vT, const void* gq, const void* bq, const void* gk,
+                                 const void* bk, const float* rope_cos, const float* rope_sin, int B, int S, int H, int n_text,
+                                 int s_pad, float eps, float q_premul, void* stream) {
+    ORV_REQUIRE(src && qkv && vT, "orv_qkv_prep: null operand");
     ORV_REQUIRE(B > 0 && S > 0 && H > 0, "orv_qkv_prep: empty problem");
     ORV_REQUIRE(s_pad % 64 == 0 && s_pad >= S && s_pad == ((S + 63) / 64) * 64,
                 "orv_qkv_prep: s_pad=%d must be S=%d rounded up to 64", s_pad, S);
     ORV_REQUIRE((rope_cos == nullptr) == (rope_sin == nullptr), "orv_qkv_prep: cos and sin go together");
     dim3 grid(s_pad / 64, H, B);
-    hipLaunchKernelGGL(qkv_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, (bf16_t*)qkv, (bf16_t*)vT,
+    hipLaunchKernelGGL(qkv_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)qkv, (bf16_t*)vT,
                        (const bf16_t*)gq, (const bf16_t*)bq, (const bf16_t*)gk, (const bf16_t*)bk, rope_cos, rope_sin, S,
                        H, n_text, s_pad, eps, q_premul);
     return orv_check_launch("orv_qkv_prep");

@@ -156,13 +156,14 @@ def modulation_tables(temb, action_emb, w_ptrs, b_ptrs, n_tab, B, T, E, width, t
 
 
 def qkv_prep(qkv, vT, gq, bq, gk, bk, rope: Optional[Tuple[torch.Tensor, torch.Tensor]], B, S, H, n_text, s_pad, eps,
-             q_premul: float = 1.0):
+             q_premul: float = 1.0, src=None):
+    """In place on ``qkv``, or (``src`` given) out of place: reads ``src``, writes q' / k' / v to ``qkv``."""
     _need(qkv, BF16, "qkv"), _need(vT, BF16, "vT")
     cos = sin = None
     if rope is not None:
         cos, sin = (_need(r.contiguous(), torch.float32, "rope") for r in rope)
-    check(lib().orv_qkv_prep(_p(qkv), _p(vT), _p(gq), _p(bq), _p(gk), _p(bk), _p(cos), _p(sin), B, S, H, n_text, s_pad,
-                             float(eps), float(q_premul), _stream()), "orv_qkv_prep")
+    check(lib().orv_qkv_prep_from(_p(qkv if src is None else src), _p(qkv), _p(vT), _p(gq), _p(bq), _p(gk), _p(bk), _p(cos),
+                                  _p(sin), B, S, H, n_text, s_pad, float(eps), float(q_premul), _stream()), "orv_qkv_prep")
 
 
 def gemm(A, W, bias, C, M, N, K, epilogue=0, R=None, r_mod=0, gate=None, gate_b=0, gate_g=0, grp: Optional[Groups] = None,

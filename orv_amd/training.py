@@ -43,11 +43,13 @@ def _acc_grad(store: Dict, p: torch.nn.Parameter) -> torch.Tensor:
     return g
 
 
-def _wgrad(dY2d, X2d, dW, M, N, K):
-    """dW[N,K] += dY[M,N]^T . X[M,K]  through two transposes and the NT GEMM (contraction over the M rows)."""
+def _wgrad(dY2d, X2d, dW, M, N, K, accumulate=True):
+    """dW[N,K] (+)= dY[M,N]^T . X[M,K]  through two transposes and the NT GEMM (contraction over the M rows)."""
     dYT = ops.transpose(dY2d, M, N)           # [N, M_pad]
     XT = ops.transpose(X2d, M, K)             # [K, M_pad]
-    if K % 64 == 0:
+    if K % 64 == 0 and not accumulate:
+        ops.gemm(dYT, XT, None, dW, N, K, dYT.shape[1])
+    elif K % 64 == 0:
         ops.gemm(dYT, XT, None, dW, N, K, dYT.shape[1], epilogue=2, R=dW, ldr=K)
     else:                                     # odd widths (tiny test configs only): pad the output columns
         kp = (K + 63) // 64 * 64
@@ -55,7 +57,10 @@ def _wgrad(dY2d, X2d, dW, M, N, K):
         XTp[:K] = XT
         tmp = torch.empty(N, kp, dtype=BF16, device=XT.device)
         ops.gemm(dYT, XTp, None, tmp, N, kp, dYT.shape[1])
-        dW.add_(tmp[:, :K])
+        if accumulate:
+            dW.add_(tmp[:, :K])
+        else:
+            dW.copy_(tmp[:, :K])
 
 
 def _pad_k(a, w):
@@ -95,9 +100,8 @@ def _attn_forward(at, xn, ly, bufs, B_, S_, n_text, heads, rope, scale):
     wqkv, bqkv = at.packed_qkv()
     ly.qkv_raw = torch.empty(M_, 3 * D, dtype=BF16, device=dev)
     ops.gemm(xn, wqkv, bqkv, ly.qkv_raw, M_, 3 * D, D)
-    bufs.work.copy_(ly.qkv_raw)
     ops.qkv_prep(bufs.work, bufs.vT, at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, rope, B_, S_, heads,
-                 n_text, bufs.s_pad, at.eps, q_premul=scale * LOG2E)
+                 n_text, bufs.s_pad, at.eps, q_premul=scale * LOG2E, src=ly.qkv_raw)
     ly.att = torch.empty(M_, D, dtype=BF16, device=dev)
     ly.lse = torch.empty(B_, heads, S_, dtype=torch.float32, device=dev)
     ops.attention_fwd(bufs.work, bufs.vT, ly.att, B_, S_, heads, bufs.s_pad, 1.0 / LOG2E, lse=ly.lse)
@@ -109,9 +113,8 @@ def _attn_backward(at, ly, xn, datt, bufs, B_, S_, n_text, heads, rope, scale, g
     M_ = B_ * S_
     dev = xn.device
     z32 = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
-    bufs.work.copy_(ly.qkv_raw)
     ops.qkv_prep(bufs.work, bufs.vT, at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, rope, B_, S_, heads,
-                 n_text, bufs.s_pad, at.eps, q_premul=scale * LOG2E)
+                 n_text, bufs.s_pad, at.eps, q_premul=scale * LOG2E, src=ly.qkv_raw)
     ops.head_transpose(bufs.work, 0, bufs.qT, B_, S_, heads, bufs.s_pad, ld=3 * D)
     ops.head_transpose(bufs.work, D, bufs.kT, B_, S_, heads, bufs.s_pad, ld=3 * D)
     ops.head_transpose(datt, 0, bufs.doT, B_, S_, heads, bufs.s_pad, ld=D)
@@ -126,8 +129,8 @@ def _attn_backward(at, ly, xn, datt, bufs, B_, S_, n_text, heads, rope, scale, g
     wqkv, _ = at.packed_qkv()
     lins = (at.to_q, at.to_k, at.to_v)
     if any(l.weight.requires_grad for l in lins):
-        dwqkv = torch.zeros(3 * D, D, dtype=BF16, device=dev)
-        _wgrad(dqkv, xn, dwqkv, M_, 3 * D, D)
+        dwqkv = torch.empty(3 * D, D, dtype=BF16, device=dev)
+        _wgrad(dqkv, xn, dwqkv, M_, 3 * D, D, accumulate=False)
         for j, lin in enumerate(lins):
             if lin.weight.requires_grad:
                 _acc_grad(grads, lin.weight).add_(dwqkv[j * D:(j + 1) * D])
@@ -422,8 +425,14 @@ def backward(model, sv, dout, drecon=None) -> Dict[int, torch.Tensor]:
         acc.add_(g32.to(BF16).view_as(acc))
 
     def wgrad_p(param, dY2d, X2d, M_, N_, K_):
-        if param.requires_grad:                 # frozen weights (e.g. everything but mv_blocks, :641-656) cost no GEMM
-            _wgrad(dY2d, X2d, _acc_grad(grads, param), M_, N_, K_)
+        if not param.requires_grad:             # frozen weights (e.g. everything but mv_blocks, :641-656) cost no GEMM
+            return
+        if id(param) in grads:
+            _wgrad(dY2d, X2d, grads[id(param)], M_, N_, K_)
+        else:                                   # first (normally only) contribution: plain store, no zero-fill + re-read
+            g = torch.empty_like(param, dtype=BF16)
+            grads[id(param)] = g
+            _wgrad(dY2d, X2d, g, M_, N_, K_, accumulate=False)
 
     def bias_p(param, dY2d, M_, N_):
         if param is not None and param.requires_grad:

@@ -148,3 +148,31 @@ def test_positional_tables_match_oracle():
         h, w = map(int, key.split("x"))
         got = utils.get_resize_crop_region_for_grid((h, w), 45, 30)
         assert [list(got[0]), list(got[1])] == [list(want[0]), list(want[1])]
+
+
+def test_c_abi_argument_validation_and_no_gpu_behaviour():
+    """Every entry point validates before touching the device: bad arguments come back as a non-zero code with a message
+    in orv_last_error() (no exception, no abort); without a GPU orv_device_check fails loudly instead of falling back."""
+    import ctypes
+    from orv_amd import _lib
+    h = _lib.lib()
+    err = lambda: h.orv_last_error().decode()
+    g = _lib.Gemm()
+    assert h.orv_gemm_bf16(ctypes.byref(g), None) != 0 and "null operand" in err()
+    buf = (ctypes.c_uint16 * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    g.A, g.W, g.C, g.M, g.N, g.K, g.lda, g.ldw, g.ldc = p, p, p, 8, 64, 100, 104, 104, 64
+    assert h.orv_gemm_bf16(ctypes.byref(g), None) != 0 and "K=100 must be a multiple of 64" in err()
+    assert h.orv_qkv_prep(p, p, None, None, None, None, None, None, 1, 100, 2, 0, 64, 1e-6, 1.0, None) != 0
+    assert "s_pad=64 must be S=100 rounded up to 64" in err()
+    assert h.orv_colsum(p, 12, p, 4, 12, None) != 0 and "multiples of 8" in err()
+    assert h.orv_adamw_flat(p, p, p, p, 1000, p, p, 1, 1e-3, 0.9, 0.95, 1e-8, 0.0, 1, None, None) != 0
+    assert "multiple of 2048" in err()
+    assert h.orv_gather_rows(p, 64, p, p, 64, 4, 60, None) != 0 and "bad arguments" in err()
+    if not torch.cuda.is_available():
+        assert h.orv_device_check(0) != 0 and err()
+        from orv_amd.cogvideox_control import CogVideoXTransformer3DModelTraj
+        cfg, _, ins, w, _ = load_golden("fwd_noactions")
+        m = CogVideoXTransformer3DModelTraj(**cfg)
+        with pytest.raises(RuntimeError, match="MI355X only"):
+            m(ins["hidden_states"], ins["encoder_hidden_states"], {}, ins["timestep"])
