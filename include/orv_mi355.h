@@ -173,6 +173,14 @@ int orv_layernorm_modulate_bwd(const void* dy, const void* x, orv_rowmap_t xmap,
                                const void* gamma, const void* beta, const float* scale, float* dscale, float* dshift,
                                float* dgamma, float* dbeta, float* scratch, long mod_b, long mod_g, orv_groups_t grp,
                                int batch, int D, float eps, void* stream);
+/* Adjoint of orv_modulation_tables for all n_tab AdaLN linears at once (cogvideox_control.py:117-130,:172 under autograd):
+ * dtab fp32 [n_tab, B, 1+T, width] (d out); cond_v bf16 [B*T, E] = SiLU(temb + action_emb) rows, cond_t bf16 [B, E] =
+ * SiLU(temb); W device array of n_tab weight pointers as in the forward.  Writes gW bf16 [n_tab, width*(1+text), E]
+ * and gb fp32 [n_tab, width*(1+text)] (overwritten), accumulates d_cond_v fp32 [B*T, E] / d_cond_t fp32 [B, E].
+ * B*T <= 32. */
+int orv_modulation_tables_bwd(const float* dtab, const void* cond_v, const void* cond_t, const void* const* W, void* gW,
+                              float* gb, float* d_cond_v, float* d_cond_t, int n_tab, int B, int T, int E, int width,
+                              int text, void* stream);
 /* Small-row (R <= 4096) linear adjoint for the conditioning MLPs / AdaLN linears: dW[N,K] (+)= dy^T x (bf16),
  * db[N] (+)= colsum(dy) (fp32), dx[R,K] += dy W (fp32 atomics).  dy fp32 [R, ldy].  Any of dW/dx may be NULL. */
 int orv_small_linear_bwd(const float* dy, int ldy, const void* x, int ldx, const void* W, void* dW, float* db, float* dx,

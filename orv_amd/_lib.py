@@ -62,6 +62,8 @@ SIGNATURES = {
     "orv_layernorm_modulate_bwd": (c_int, [c_void_p, c_void_p, RowMap, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, Groups, c_int,
                                            c_int, c_float, c_void_p]),
+    "orv_modulation_tables_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                          c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "orv_small_linear_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                      c_int, c_int, c_int, c_void_p]),
     "orv_adamw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float, c_float, c_int,

@@ -410,6 +410,95 @@ __global__ __launch_bounds__(256) void small_dgrad_kernel(const float* __restric
     }
 }
 
+// ---- adjoint of orv_modulation_tables: ALL AdaLN linears of a backward in two launches -------------------------------
+//      tab t, video rows:  out[t][b][1+f][n] = W_t[n,:] . cond_v[b*T+f,:] + bias      (n < width)
+//      tab t, text rows:   out[t][b][0][n]   = W_t[width+n,:] . cond_t[b,:] + bias    (if text)
+//      given dtab = d out (fp32, same layout):
+//        gW_t[n,k]  = sum_rows dtab * cond   (bf16, OVERWRITTEN: one flat [n_tab, width*(1+text), E] buffer)
+//        gb[t][n]   = sum_rows dtab          (fp32, overwritten)
+//        d_cond_v[r,k] += sum_{t,n} dtab_v[t][r][n] * W_t[n,k]     d_cond_t likewise from the text halves
+struct ModBwdArgs {
+    const float* dtab; const bf16_t* cond_v; const bf16_t* cond_t; const bf16_t* const* W;
+    bf16_t* gW; float* gb; float* d_cond_v; float* d_cond_t;
+    int n_tab, B, T, E, width, text;
+};
+
+// weight / bias gradient: thread -> (n, 8 consecutive k); rows <= 32 per half (checked by the host)
+__global__ __launch_bounds__(256) void mod_bwd_wgrad_kernel(const ModBwdArgs p) {
+    const int tab = blockIdx.y, E = p.E, kc = E >> 3;
+    const int ntot = p.width * (1 + p.text);
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)ntot * kc) return;
+    const int n = (int)(i / kc), k0 = (int)(i % kc) * 8;
+    const bool is_text = n >= p.width;
+    const int nn = is_text ? n - p.width : n;
+    const int rows = is_text ? p.B : p.B * p.T, G = 1 + p.T;
+    const bf16_t* cond = is_text ? p.cond_t : p.cond_v;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bs = 0.f;
+    for (int r = 0; r < rows; ++r) {
+        const int b = is_text ? r : r / p.T, g = is_text ? 0 : 1 + r % p.T;
+        const float d = p.dtab[(((long)tab * p.B + b) * G + g) * p.width + nn];
+        const uint4 u = *(const uint4*)(cond + (long)r * E + k0);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[2 * e] += d * bf2f(w[e] & 0xffff); acc[2 * e + 1] += d * bf2f(w[e] >> 16); }
+        bs += d;
+    }
+    *(uint4*)(p.gW + ((long)tab * ntot + n) * E + k0) =
+        make_uint4(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7]));
+    if (k0 == 0) p.gb[(long)tab * ntot + n] = bs;
+}
+
+// input gradient: block = (64-wide k slice, tab, half); 256 threads = 64 k x 4 n-phases; the dtab slab of 128 n x rows is
+// staged in LDS as [n][32 rows]; every thread streams its W column once (128-byte rows across the 64 k lanes).
+__global__ __launch_bounds__(256) void mod_bwd_dgrad_kernel(const ModBwdArgs p) {
+    __shared__ __attribute__((aligned(16))) float dys[128][32];
+    __shared__ float red[3][32][64];
+    const int tab = blockIdx.y, half = blockIdx.z;          // half 0 = video rows, 1 = text rows
+    const int E = p.E, G = 1 + p.T;
+    const int rows = half ? p.B : p.B * p.T;
+    const int kk = threadIdx.x & 63, ph = threadIdx.x >> 6, k = blockIdx.x * 64 + kk;
+    const bf16_t* W = p.W[tab] + (long)(half ? p.width : 0) * E;
+    float acc[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+    for (int n0 = 0; n0 < p.width; n0 += 128) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 128 * 32; i += 256) {
+            const int r = i >> 7, nl = i & 127;              // consecutive threads -> consecutive n (coalesced dtab rows)
+            float d = 0.f;
+            if (r < rows && n0 + nl < p.width) {
+                const int b = half ? r : r / p.T, g = half ? 0 : 1 + r % p.T;
+                d = p.dtab[(((long)tab * p.B + b) * G + g) * p.width + n0 + nl];
+            }
+            dys[nl][r] = d;
+        }
+        __syncthreads();
+        if (k < E) {
+            const int nend = min(128, p.width - n0);
+            for (int nl = ph; nl < nend; nl += 4) {
+                const float w = bf2f(W[(long)(n0 + nl) * E + k]);
+#pragma unroll
+                for (int j = 0; j < 32; j += 4) {
+                    const float4 d4 = *(const float4*)&dys[nl][j];
+                    acc[j] = fmaf(d4.x, w, acc[j]); acc[j + 1] = fmaf(d4.y, w, acc[j + 1]);
+                    acc[j + 2] = fmaf(d4.z, w, acc[j + 2]); acc[j + 3] = fmaf(d4.w, w, acc[j + 3]);
+                }
+            }
+        }
+    }
+    if (ph > 0)
+#pragma unroll
+        for (int j = 0; j < 32; ++j) red[ph - 1][j][kk] = acc[j];
+    __syncthreads();
+    if (ph == 0 && k < E) {
+        float* dx = half ? p.d_cond_t : p.d_cond_v;
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+            if (j < rows) atomicAdd(dx + (long)j * E + k, acc[j] + red[0][j][kk] + red[1][j][kk] + red[2][j][kk]);
+    }
+}
+
 // ---- fused AdamW on bf16 parameters / bf16 gradients with fp32 moments (torch.optim.AdamW semantics, decoupled decay):
 //      g *= clip ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p = p (1 - lr wd) - lr (m / bc1) / (sqrt(v / bc2) + eps)
 __global__ void adamw_kernel(bf16_t* __restrict__ p, const bf16_t* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
@@ -595,6 +684,22 @@ extern "C" int orv_small_linear_bwd(const float* dy, int ldy, const void* x, int
                            (long)lddx, R, N, K, nslab);
     }
     return orv_check_launch("orv_small_linear_bwd");
+}
+
+extern "C" int orv_modulation_tables_bwd(const float* dtab, const void* cond_v, const void* cond_t, const void* const* W,
+                                         void* gW, float* gb, float* d_cond_v, float* d_cond_t, int n_tab, int B, int T, int E,
+                                         int width, int text, void* stream) {
+    ORV_REQUIRE(dtab && cond_v && W && gW && gb && d_cond_v, "orv_modulation_tables_bwd: null operand");
+    ORV_REQUIRE(!text || (cond_t && d_cond_t), "orv_modulation_tables_bwd: text rows need cond_t / d_cond_t");
+    ORV_REQUIRE(n_tab > 0 && B > 0 && T > 0 && B * T <= 32 && E % 64 == 0 && width % 8 == 0,
+                "orv_modulation_tables_bwd: unsupported shape (B*T=%d must be <= 32, E=%d %% 64, width=%d %% 8)", B * T, E, width);
+    ModBwdArgs a{dtab, (const bf16_t*)cond_v, (const bf16_t*)cond_t, (const bf16_t* const*)W, (bf16_t*)gW, gb, d_cond_v, d_cond_t,
+                 n_tab, B, T, E, width, text ? 1 : 0};
+    hipStream_t st = (hipStream_t)stream;
+    const long per_tab = (long)width * (1 + a.text) * (E / 8);
+    hipLaunchKernelGGL(mod_bwd_wgrad_kernel, dim3((unsigned)((per_tab + 255) / 256), n_tab), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(mod_bwd_dgrad_kernel, dim3(E / 64, n_tab, 1 + a.text), dim3(256), 0, st, a);
+    return orv_check_launch("orv_modulation_tables_bwd");
 }
 
 extern "C" int orv_adamw(void* p, const void* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,

@@ -260,6 +260,18 @@ def layernorm_modulate_bwd(dy, x, dres, dx, gamma, beta, scale, dscale, dshift, 
     return dx
 
 
+def modulation_tables_bwd(dtab, cond_v, cond_t, w_ptrs, d_cond_v, d_cond_t, n_tab, B, T, E, width, text):
+    """Adjoint of ``modulation_tables``: returns (gW bf16 [n_tab, width*(1+text), E], gb fp32 [n_tab, width*(1+text)])."""
+    _need(dtab, torch.float32, "dtab"), _need(cond_v, BF16, "cond_v")
+    ntot = width * (2 if text else 1)
+    gW = torch.empty(n_tab, ntot, E, dtype=BF16, device=dtab.device)
+    gb = torch.empty(n_tab, ntot, dtype=torch.float32, device=dtab.device)
+    check(lib().orv_modulation_tables_bwd(_p(dtab), _p(cond_v), _p(cond_t), _p(w_ptrs), _p(gW), _p(gb), _p(d_cond_v),
+                                          _p(d_cond_t), n_tab, B, T, E, width, int(text), _stream()),
+          "orv_modulation_tables_bwd")
+    return gW, gb
+
+
 def small_linear_bwd(dy, x, W, dW, db, dx, R, N, K, accumulate=True, ldy=None, ldx=None, lddx=None):
     _need(dy, torch.float32, "dy")
     check(lib().orv_small_linear_bwd(_p(dy), ldy or N, _p(x), ldx or K, _p(W), _p(dW), _p(db), _p(dx), lddx or K, R, N, K,

@@ -613,13 +613,27 @@ def backward(model, sv, dout, drecon=None) -> Dict[int, torch.Tensor]:
             ops.small_linear_bwd(dt, cond_t, lin.weight[width:], gw[width:], gb32[width:], d_cond_t, B, width, E)
         f32_to_param_grad(lin.bias, gb32)
 
-    for i, blk in enumerate(model.transformer_blocks):
-        table_bwd(blk.norm1.linear, dmod[2 * i], 3 * D, mod_text)
-        table_bwd(blk.norm2.linear, dmod[2 * i + 1], 3 * D, mod_text)
-    table_bwd(model.norm_out.linear, dmodf, 2 * D, False)
+    def tables_bwd(lins, dtab, w_ptrs, width, text, cv, dcv, T_):
+        """Adjoint of one ``ops.modulation_tables`` call: all its AdaLN linears in two launches (B*T <= 32), else per table."""
+        if B * T_ > 32:
+            for i, lin in enumerate(lins):
+                table_bwd(lin, dtab[i], width, text, cv=cv, dcv=dcv, rows_v=B * T_)
+            return
+        gW, gb = ops.modulation_tables_bwd(dtab, cv, cond_t, w_ptrs, dcv, d_cond_t, len(lins), B, T_, E, width, text)
+        gb16 = gb.to(BF16)
+        for i, lin in enumerate(lins):
+            if lin.weight.requires_grad:
+                grads[id(lin.weight)] = gW[i]
+            if lin.bias is not None and lin.bias.requires_grad:
+                grads[id(lin.bias)] = gb16[i]
+
+    ptr = model._pointer_tables(dev)
+    tables_bwd([n.linear for blk in model.transformer_blocks for n in (blk.norm1, blk.norm2)], dmod, ptr["w_blk"], 3 * D,
+               mod_text, cond_v, d_cond_v, Ta)
+    tables_bwd([model.norm_out.linear], dmodf[None], ptr["w_out"], 2 * D, False, cond_v, d_cond_v, Ta)
     if mv is not None:                         # MVBlock.norm1 has no action term: both row groups see silu(temb)
-        for i, mblk in enumerate(model.mv_blocks):
-            table_bwd(mblk.norm1.linear, dmv[i], 3 * D, mod_text, cv=cond_t, dcv=d_cond_t, rows_v=B)
+        wmv, _ = model._mv_pointer_tables(dev)
+        tables_bwd([mblk.norm1.linear for mblk in model.mv_blocks], dmv, wmv, 3 * D, mod_text, cond_t, d_cond_t, 1)
 
     def dsilu(x):
         s = torch.sigmoid(x)
