@@ -84,11 +84,8 @@ class FusedAdamW:
             f["active"].copy_(torch.tensor(live, dtype=torch.uint8))
             f["active_host"] = live
         if average_over and average_over > 1:
-            import torch.distributed as dist
-            g = f["g"]
-            for s in range(0, g.numel(), _AR_CHUNK):
-                dist.all_reduce(g[s:s + _AR_CHUNK])
-            g.mul_(1.0 / average_over)
+            from .sharding import allreduce_flat_
+            allreduce_flat_(f["g"], _AR_CHUNK)
         dev = f["p"].device
         ss = torch.zeros(1, dtype=torch.float32, device=dev)
         ops.sumsq(f["g"], ss)

@@ -76,3 +76,20 @@ def allreduce_gradients(params, bucket_bytes: int = 256 << 20, group=None, avera
         size += nb
     flush()
     return n_coll
+
+
+def allreduce_flat_(flat: torch.Tensor, chunk_elems: int = 128 * 1024 * 1024, group=None, average: bool = True) -> int:
+    """In-place sum / average of ONE flat gradient buffer (``FusedAdamW``'s) over the data-parallel group, ``chunk_elems``
+    elements per collective (256 MB of bf16: ring all-reduce over xGMI is per-link bound, so few large messages).
+    A parameter without a gradient on some rank holds zeros in its segment.  Returns the number of collectives issued."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    world = dist.get_world_size(group)
+    n = 0
+    for s0 in range(0, flat.numel(), chunk_elems):
+        piece = flat[s0:s0 + chunk_elems]
+        dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=group)
+        n += 1
+    if average:
+        flat.mul_(1.0 / world)
+    return n

@@ -60,8 +60,12 @@ def _dp_worker(rank, world, port, out):
         p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
     params[1].grad = None if rank == 1 else params[1].grad            # an "unused" parameter on one rank
     n = allreduce_gradients(params + [frozen], bucket_bytes=1 << 20)
+    # the flat-buffer form used by FusedAdamW: one buffer, several collectives, averaged in place
+    from orv_amd.sharding import allreduce_flat_
+    flat = torch.arange(10000, dtype=torch.float32) * (rank + 1)
+    nf = allreduce_flat_(flat, chunk_elems=4096)
     if rank == 0:
-        out.put((n, [p.grad.clone() for p in params], frozen.grad))
+        out.put((n, [p.grad.clone() for p in params], frozen.grad, nf, flat))
     dist.destroy_process_group()
 
 
@@ -72,10 +76,11 @@ def test_two_rank_gradient_allreduce():
     port = _free_port()
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     [p.start() for p in procs]
-    n, grads, frozen_grad = q.get(timeout=120)
+    n, grads, frozen_grad, nf, flat = q.get(timeout=120)
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     assert n >= 2 and frozen_grad is None                               # 300000 floats alone exceed the 1 MiB bucket
     want = [1.5 * 1, 0.5 * 2, 1.5 * 3, 1.5 * 4]                          # mean over ranks; missing grad counts as zero
     for g, w in zip(grads, want):
         assert torch.allclose(g, torch.full_like(g, w))
+    assert nf == 3 and torch.allclose(flat, torch.arange(10000, dtype=torch.float32) * 1.5)
