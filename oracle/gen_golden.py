@@ -154,8 +154,39 @@ def misc_case(cc, comp, utils):
     _save("misc_actions", {}, tensors, dict(crops=crops))
 
 
+def collate_case():
+    """orv/dataset/dataset.py:2053-2142 ``CollateFunctionControl`` on cached-latent samples (what the SFT loop consumes at
+    :864-886), singleview and 2-view."""
+    Collate = ref_harness.load_reference_class("orv/dataset/dataset.py", "CollateFunctionControl")
+    g = torch.Generator().manual_seed(1234)
+    for name, v in (("collate_single", 1), ("collate_mv2", 2)):
+        data = []
+        for i in range(3):
+            data.append({"prompt": f"p{i}", "prompt_embeds": _q(torch.randn(8, 96, generator=g)),
+                         "actions": _q(torch.randn(8, 7, generator=g)),
+                         "latents": _q(torch.randn(v * 3, 32, 8, 12, generator=g)),
+                         "image": _q(torch.randn(v * 1, 32, 8, 12, generator=g)),
+                         "latents_depth": _q(torch.randn(v * 3, 32, 8, 12, generator=g)),
+                         "latents_label": _q(torch.randn(v * 3, 32, 8, 12, generator=g)),
+                         "metainfo": {"num_view": v, "num_frame": 9, "episode": i}})
+        out = Collate(weight_dtype=torch.bfloat16, load_tensors=True)(data)
+        tensors = {}
+        for i, d in enumerate(data):
+            for k in ("prompt_embeds", "actions", "latents", "image", "latents_depth", "latents_label"):
+                tensors[f"in.{i}.{k}"] = d[k]
+        for k in ("prompt_embeds", "latents", "images"):
+            tensors["out." + k] = out[k].float()
+        for k, val in out["controls"].items():
+            tensors["out.controls." + k] = val.float()
+        _save(name, {}, tensors, dict(num_views=out["num_views"], num_frames=out["num_frames"], image_width=out["image_width"],
+                                      image_height=out["image_height"], prompts=out["prompts"], n=len(data),
+                                      metainfos=[d["metainfo"] for d in data]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "collate":      # add the data-format fixtures without touching the others
+        return collate_case()
     cc, comp, utils = ref_harness.load_reference()
     forward_case(cc, utils, "fwd_actions", {})
     forward_case(cc, utils, "fwd_actions_masked", {}, mask=(True, False))
@@ -175,6 +206,7 @@ def main():
     pipeline_case(cc, "pipe_ddim_cfg", __import__("oracle.leaf", fromlist=["x"]).CogVideoXDDIMScheduler, guidance=3.0,
                   with_actions=False)
     misc_case(cc, comp, utils)
+    collate_case()
 
 
 if __name__ == "__main__":

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import contextlib
 import importlib
+import os
 import importlib.machinery
 import inspect
 import sys
@@ -24,6 +25,8 @@ from typing import Any, Dict
 
 import numpy as np
 import torch
+
+REF = REFERENCE_ROOT if "REFERENCE_ROOT" in globals() else "/root/reference"
 from torch import nn
 
 from . import leaf
@@ -251,3 +254,20 @@ def make_pipeline(cc, transformer, scheduler, scaling_factor=1.15258426):
     return cc.CogVideoXImageToVideoPipelineTraj(tokenizer=None, text_encoder=None,
                                                 vae=_FakeVAE(scaling_factor=scaling_factor),
                                                 transformer=transformer, scheduler=scheduler)
+
+
+def load_reference_class(rel_path: str, class_name: str, extra_globals=None):
+    """Exec ONE pure-torch class of the reference in isolation (its module imports decord / torchvision / PIL, absent
+    here): the class definition is AST-sliced out of the file and compiled with the few names it needs (SURVEY §8c,
+    "AST-extract pure-torch classes").  Build-container use only (golden-vector generation)."""
+    import ast
+    import itertools
+    import typing
+    src = open(os.path.join(REF, rel_path)).read()
+    tree = ast.parse(src)
+    node = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == class_name)
+    mod = ast.Module(body=[node], type_ignores=[])
+    glb = {"torch": torch, "Any": typing.Any, "Optional": typing.Optional, "chain": itertools.chain, "Tensor": torch.Tensor}
+    glb.update(extra_globals or {})
+    exec(compile(mod, os.path.join(REF, rel_path), "exec"), glb)
+    return glb[class_name]

@@ -176,3 +176,40 @@ def test_c_abi_argument_validation_and_no_gpu_behaviour():
         m = CogVideoXTransformer3DModelTraj(**cfg)
         with pytest.raises(RuntimeError, match="MI355X only"):
             m(ins["hidden_states"], ins["encoder_hidden_states"], {}, ins["timestep"])
+
+
+@pytest.mark.parametrize("name", ["collate_single", "collate_mv2"])
+def test_collate_matches_reference_golden(name, tmp_path):
+    """orv_amd.data.CollateFunctionControl against the reference's class run on the same samples (fixture generated by
+    oracle/gen_golden.py from orv/dataset/dataset.py:2053-2142), and the cached-latent file readers on files written in the
+    reference's on-disk layout ([2C, F, h, w] moments)."""
+    from orv_amd import data
+    _, extra, ins, _, outs = load_golden(name)
+    n = extra["n"]
+    samples = []
+    for i in range(n):
+        d = {k.split(".", 1)[1]: v for k, v in ins.items() if k.startswith(f"{i}.")}
+        samples.append({**d, "prompt": extra["prompts"][i], "metainfo": extra["metainfos"][i]})
+    got = data.CollateFunctionControl(torch.bfloat16, True)(samples)
+    for k in ("prompt_embeds", "latents", "images"):
+        assert got[k].dtype == torch.bfloat16 and torch.equal(got[k].float(), outs[k]), k
+    for k in ("actions", "latents_depth", "latents_label"):
+        assert torch.equal(got["controls"][k].float(), outs["controls." + k]), k
+    for k in ("num_views", "num_frames", "image_width", "image_height", "prompts"):
+        assert got[k] == extra[k], k
+    # file readers: one clip + per-view controls round-trip through the .pt layout
+    v = extra["num_views"]
+    lat = samples[0]["latents"]                                    # [v*F, 2C, h, w]
+    F = lat.shape[0] // v
+    torch.save(lat[:F].permute(1, 0, 2, 3).contiguous(), tmp_path / "clip.pt")
+    torch.save(samples[0]["image"][:1].permute(1, 0, 2, 3).contiguous(), tmp_path / "ref.pt")
+    clip = data.load_latent_clip(str(tmp_path), "clip.pt", "ref.pt", frame_ids=list(range(4 * F)))
+    assert torch.equal(clip["latents"], lat[:F]) and clip["image"].shape == (1, *lat.shape[1:])
+    with pytest.raises(RuntimeError, match="mismatched latent video"):
+        data.load_latent_clip(str(tmp_path), "clip.pt", "ref.pt", frame_ids=[4 * F + 3], is_sliced=False)
+    paths = []
+    for vi in range(v):
+        torch.save(samples[0]["latents_depth"][vi * F:(vi + 1) * F].permute(1, 0, 2, 3).contiguous(), tmp_path / f"d{vi}.pt")
+        paths.append(f"d{vi}.pt")
+    ctl = data.load_latent_controls(str(tmp_path), ["depth"], latent_depth_paths=paths)
+    assert torch.equal(ctl["latents_depth"], samples[0]["latents_depth"]) and "latents_label" not in ctl
