@@ -255,7 +255,10 @@ def main():
                 # kernel symbol as orv_gemm_bf16 dispatches it (gemm.hip: tile choice) so it matches the rocprofv3 name
                 bn = 192 if N % 192 == 0 else (128 if N % 128 == 0 else 64)
                 big = ((M + 255) // 256) * (N // bn) >= 224
-                sym = f"gemm_pp_kernel<{bn}, 5, {epi}>" if (big and bn != 64) else f"gemm_kernel<{256 if big else 128}, {bn}, {epi}>"
+                if big and N % 256 == 0 and ((M + 255) // 256) * (N // 256) >= 4 * 256:
+                    sym = f"gemm_pp_kernel<256, 5, {epi}>"
+                else:
+                    sym = f"gemm_pp_kernel<{bn}, 5, {epi}>" if (big and bn != 64) else f"gemm_kernel<{256 if big else 128}, {bn}, {epi}>"
                 flop, name = 2.0 * M * N * K, f"{sym} M={M} N={N} K={K}"
             else:
                 _, b, s, h = key

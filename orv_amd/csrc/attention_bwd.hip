@@ -89,8 +89,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const BwdArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 256 + wave * 32;
+    const int nqt = (p.S + 255) / 256;                      // head-major items per XCD, as in the forward
+    const int item = orv_xcd_item(blockIdx.x, gridDim.x);
+    const int bh = item / nqt, h = bh % p.H, b = bh / p.H;
+    const int q0 = (item % nqt) * 256 + wave * 32;
     const int D = p.H * 64;
     const long row0 = (long)b * p.S;
     const int qr = min(q0 + l31, p.S - 1);
@@ -194,8 +196,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const BwdArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int k0 = blockIdx.x * 256 + wave * 32;
+    const int nkt = (p.S + 255) / 256;
+    const int item = orv_xcd_item(blockIdx.x, gridDim.x);
+    const int bh = item / nkt, h = bh % p.H, b = bh / p.H;
+    const int k0 = (item % nkt) * 256 + wave * 32;
     const int D = p.H * 64;
     const long row0 = (long)b * p.S;
     const int kr = min(k0 + l31, p.S - 1);
@@ -442,7 +446,7 @@ extern "C" int orv_attention_bwd(const void* qkv, int ld_qkv, const void* qT, co
     a.qkv = (const bf16_t*)qkv; a.ld = ld_qkv; a.qT = (const bf16_t*)qT; a.kT = (const bf16_t*)kT; a.doT = (const bf16_t*)doT;
     a.dout = (const bf16_t*)dout; a.ld_do = ld_out; a.neg_lse2 = neg_lse2; a.neg_delta = neg_delta;
     a.dqkv = (bf16_t*)dqkv; a.ld_dqkv = ld_dqkv; a.B = B; a.S = S; a.H = H; a.s_pad = s_pad; a.scale = scale;
-    dim3 grid((S + 255) / 256, H, B);
+    dim3 grid(((S + 255) / 256) * H * B);   // 1-D: orv_xcd_item hands head-major items to the XCDs
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(512), 0, st, a);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(512), 0, st, a);
     return orv_check_launch("orv_attention_bwd");

@@ -60,6 +60,14 @@ __device__ __forceinline__ float silu(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 
+// XCD-aware work-item order for 1-D grids: workgroup L runs on XCD L % 8 (round-robin dispatch); XCD x takes the x-th
+// contiguous chunk of the `total` work items, so items that share operands (the query tiles of one attention head, the
+// tiles of one GEMM panel group) meet in ONE 4 MB L2 instead of being fetched by all eight.  Bijective for any total.
+__device__ __forceinline__ int orv_xcd_item(int L, int total) {
+    const int q = total >> 3, r = total & 7, x = L & 7, j = L >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
