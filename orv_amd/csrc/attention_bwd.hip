@@ -158,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const BwdArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float pv = __builtin_amdgcn_exp2f(sT[kb][r]);
-                if (tail && t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.S) pv = 0.f;
+                if (tail) pv = (t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.S) ? 0.f : pv;
                 sT[kb][r] = pv * dP[kb][r];      // dS^T = P (dP - delta)
             }
 #pragma unroll
@@ -224,10 +224,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const BwdArgs p) {
         glds16(dobase + (row0 + qrow) * p.ld_do, base + TILE + wave * 1024);
         glds16(qtsrc + q0, base + 2 * TILE + wave * 1024);
         glds16(dotsrc + q0, base + 3 * TILE + wave * 1024);
-        if (wave == 0 && lane < 32) {     // 64 + 64 floats = 32 lanes x 16 B
-            const float* src = (lane < 16 ? p.neg_lse2 : p.neg_delta) + hb * p.s_pad + q0 + (lane & 15) * 4;
-            *(float4*)(base + 4 * TILE + lane * 16) = *(const float4*)src;
-        }
+        // the two 64-float vectors also travel by LDS-DMA (a register round trip here would put a vmcnt(0) wait right
+        // behind the tile loads just issued: wave 0 then stalls a full memory latency per tile and everyone meets it at
+        // the barrier - measured as 50 % of all wave cycles parked)
+        if (wave == 0) glds4(p.neg_lse2 + hb * p.s_pad + q0 + lane, base + 4 * TILE);
+        if (wave == 1) glds4(p.neg_delta + hb * p.s_pad + q0 + lane, base + 4 * TILE + 256);
     };
     f32x16 dk[2], dv[2];
 #pragma unroll
@@ -236,7 +237,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const BwdArgs p) {
         for (int e = 0; e < 16; ++e) { dk[i][e] = 0.f; dv[i][e] = 0.f; }
     const int row_off = l31 * 128;
     const int nt = (p.S + 63) / 64;
-    const bool key_valid = (k0 + l31) < p.S;
     stage_load(0, 0);
     for (int t = 0; t < nt; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -276,8 +276,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const BwdArgs p) {
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                // (rows of keys >= S compute garbage that is never stored; only query rows >= S must not contribute)
                 float pv = __builtin_amdgcn_exp2f(sS[qb][r]);
-                if (!key_valid || (tail && t * 64 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.S)) pv = 0.f;
+                if (tail) pv = (t * 64 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.S) ? 0.f : pv;   // uniform branch + select
                 sS[qb][r] = pv;                 // P
                 dP[qb][r] = pv * dP[qb][r];     // dS
             }
