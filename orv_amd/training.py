@@ -421,8 +421,11 @@ def backward(model, sv, dout, drecon=None) -> Dict[int, torch.Tensor]:
     def f32_to_param_grad(param, g32):
         if param is None or not param.requires_grad:
             return
-        acc = _acc_grad(grads, param)
-        acc.add_(g32.to(BF16).view_as(acc))
+        g = g32.to(BF16).view(param.shape)
+        if id(param) in grads:
+            grads[id(param)].add_(g)
+        else:                                   # first (normally only) contribution: no zero-fill + add
+            grads[id(param)] = g
 
     def wgrad_p(param, dY2d, X2d, M_, N_, K_):
         if not param.requires_grad:             # frozen weights (e.g. everything but mv_blocks, :641-656) cost no GEMM
