@@ -584,8 +584,8 @@ int launch(const GemmArgs& a, int epi, hipStream_t st) {
 
 }  // namespace
 
-// Tile choice.  BN must divide N: 192 divides 1920/5760/7680 (the 2B model) exactly, 128 covers 3072-wide (5B) and
-// the tiny test widths, 64 the 64-wide proj_out.  BM = 256 unless the grid would leave most CUs idle.
+// BN must divide N: 192 divides 1920/5760/7680 (the 2B model) exactly, 128/256 cover 3072-wide (5B) and the tiny test
+// widths, 64 the 64-wide proj_out.
 extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
     ORV_REQUIRE(g && g->A && g->W && g->C, "orv_gemm_bf16: null operand");
     ORV_REQUIRE(g->M > 0 && g->N > 0 && g->K > 0, "orv_gemm_bf16: empty problem M=%d N=%d K=%d", g->M, g->N, g->K);
@@ -608,27 +608,53 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
     a.Y = (bf16_t*)g->Y; a.ldy = g->ldy;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("ORV_GEMM_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     hipStream_t st = (hipStream_t)stream;
-    const int bn = (g->N % 192 == 0) ? 192 : (g->N % 128 == 0 ? 128 : 64);
-    a.tiles_n = g->N / bn;
-    const int tiles256 = ((g->M + 255) / 256) * a.tiles_n;
-    const bool big = tiles256 >= 224;  // ~one full wave of workgroups over the 256 CUs
-    a.tiles_m = big ? (g->M + 255) / 256 : (g->M + 127) / 128;
-    static int algo = -1;   // ORV_GEMM_ALGO=0 forces the simple double-buffered kernel (A/B testing)
-    if (algo < 0) { const char* e = getenv("ORV_GEMM_ALGO"); algo = e ? atoi(e) : 1; }
-    static int wide = -1;   // ORV_GEMM_BN256=0 keeps 192-wide tiles where N divides by both (A/B testing)
-    if (wide < 0) { const char* e = getenv("ORV_GEMM_BN256"); wide = e ? atoi(e) : 1; }
-    if (big && algo == 1 && wide && g->N % 256 == 0 && ((g->M + 255) / 256) * (g->N / 256) >= 4 * 256) {
-        // 256 x 256 tile: 7.8 instead of 9.1 B/kFLOP through the LDS-DMA path and 10 % fewer LDS fragment reads per MFMA -
-        // energy per FLOP is what a power-capped GEMM is bound by.  Only with >= 4 rounds of tiles (tail quantisation).
-        a.tiles_n = g->N / 256;
-        a.tiles_m = (g->M + 255) / 256;
-        return launch_pp<256, 5>(a, g->epilogue, st);
+    // Tile / kernel choice: every candidate whose BN divides N is priced as
+    //     rounds(tiles over the CUs) x BM x BN / relative_rate(candidate)
+    // and the cheapest wins.  The rates are measured on MI355X at M = 12904 (tools/kbench_gemm tile sweep); the
+    // rounds term is what matters at small batch, where a "better" tile that needs one more, nearly empty, round loses to a
+    // smaller one that fills the chip (B = 1: N = 1920 GEMMs take 195 tiles of 256x128 instead of 260 of 128x192).
+    struct Cand { int ring, bm, bn; float rate; };
+    static const Cand cands[] = {
+        {1, 256, 256, 1.060f}, {1, 256, 192, 1.000f}, {1, 256, 128, 0.885f},
+        {0, 256, 192, 0.975f}, {0, 256, 128, 0.935f}, {0, 256, 64, 0.855f},
+        {0, 128, 192, 0.965f}, {0, 128, 128, 0.855f}, {0, 128, 64, 0.760f},
+    };
+    static int force_ring = -1, force_bm = 0, force_bn = 0;   // ORV_GEMM_TILE="ring,bm,bn" pins one candidate (sweeps / A-B)
+    if (force_ring < 0) {
+        force_ring = 2;
+        if (const char* e = getenv("ORV_GEMM_TILE")) sscanf(e, "%d,%d,%d", &force_ring, &force_bm, &force_bn);
+        if (const char* e = getenv("ORV_GEMM_ALGO")) { if (atoi(e) == 0) force_ring = 0; }   // legacy switch: simple kernel only
     }
-    if (big && algo == 1) {
-        if (bn == 192) return launch_pp<192, 5>(a, g->epilogue, st);
-        if (bn == 128) return launch_pp<128, 5>(a, g->epilogue, st);
+    const int ncu = orv_num_cus();
+    const Cand* best = nullptr;
+    double best_cost = 0;
+    for (const Cand& c : cands) {
+        if (g->N % c.bn) continue;
+        if (force_bm && (c.ring != force_ring || c.bm != force_bm || c.bn != force_bn)) continue;
+        if (!force_bm && force_ring == 0 && c.ring) continue;
+        const long tiles = (long)((g->M + c.bm - 1) / c.bm) * (g->N / c.bn);
+        // full rounds cost 1 each; the last, partial round runs faster than a full one because the chip is power-capped
+        // (fewer active CUs clock higher): 0.62 (= 1.5 GHz / 2.4 GHz) + 0.38 x the fraction of CUs it occupies.
+        // Rows of the last M tile that do not exist still cost their MFMAs (tiles are counted whole).
+        const long full = tiles / ncu, rem = tiles % ncu;
+        const double rounds = (double)full + (rem ? 0.62 + 0.38 * (double)rem / ncu : 0.0);
+        const double cost = rounds * c.bm * c.bn / c.rate;
+        if (!best || cost < best_cost) { best = &c; best_cost = cost; }
     }
-    if (bn == 192) return big ? launch<256, 192>(a, g->epilogue, st) : launch<128, 192>(a, g->epilogue, st);
-    if (bn == 128) return big ? launch<256, 128>(a, g->epilogue, st) : launch<128, 128>(a, g->epilogue, st);
-    return big ? launch<256, 64>(a, g->epilogue, st) : launch<128, 64>(a, g->epilogue, st);
+    ORV_REQUIRE(best, "orv_gemm_bf16: no tile configuration for N=%d (ORV_GEMM_TILE override?)", g->N);
+    a.tiles_n = g->N / best->bn;
+    a.tiles_m = (g->M + best->bm - 1) / best->bm;
+    if (best->ring) {
+        if (best->bn == 256) return launch_pp<256, 5>(a, g->epilogue, st);
+        if (best->bn == 192) return launch_pp<192, 5>(a, g->epilogue, st);
+        return launch_pp<128, 5>(a, g->epilogue, st);
+    }
+    if (best->bm == 256) {
+        if (best->bn == 192) return launch<256, 192>(a, g->epilogue, st);
+        if (best->bn == 128) return launch<256, 128>(a, g->epilogue, st);
+        return launch<256, 64>(a, g->epilogue, st);
+    }
+    if (best->bn == 192) return launch<128, 192>(a, g->epilogue, st);
+    if (best->bn == 128) return launch<128, 128>(a, g->epilogue, st);
+    return launch<128, 64>(a, g->epilogue, st);
 }
