@@ -252,13 +252,11 @@ def main():
         for key, ms in timeline.items():
             if key[0] == "gemm":
                 _, M, N, K, epi = key
-                # kernel symbol as orv_gemm_bf16 dispatches it (gemm.hip: tile choice) so it matches the rocprofv3 name
-                bn = 192 if N % 192 == 0 else (128 if N % 128 == 0 else 64)
-                big = ((M + 255) // 256) * (N // bn) >= 224
-                if big and N % 256 == 0 and ((M + 255) // 256) * (N // 256) >= 4 * 256:
-                    sym = f"gemm_pp_kernel<256, 5, {epi}>"
-                else:
-                    sym = f"gemm_pp_kernel<{bn}, 5, {epi}>" if (big and bn != 64) else f"gemm_kernel<{256 if big else 128}, {bn}, {epi}>"
+                # kernel symbol as orv_gemm_bf16 dispatches it (cost-model tile choice), so it matches the rocprofv3 name
+                import ctypes
+                buf = ctypes.create_string_buffer(64)
+                check(lib().orv_gemm_kernel_name(M, N, K, epi, buf, 64), "orv_gemm_kernel_name")
+                sym = buf.value.decode()
                 flop, name = 2.0 * M * N * K, f"{sym} M={M} N={N} K={K}"
             else:
                 _, b, s, h = key
@@ -267,13 +265,26 @@ def main():
             kernels.append({"kernel": name, "launches": len(ms), "avg_ms": round(avg, 4), "total_ms": round(sum(ms), 2),
                             "tflops": round(flop / avg / 1e9, 1)})
         kernels.sort(key=lambda k: -k["total_ms"])
-        dom = kernels[0] if kernels else None
+        # roofline of the dominant KERNEL SYMBOL (all its shapes together), so that launches / average duration are the
+        # same quantities rocprofv3 --stats prints for that name (profiles/r1_bench_kernel_stats_summary.txt)
+        by_sym = {}
+        for k in kernels:
+            sym = k["kernel"].split(" M=")[0].split(" B=")[0]
+            e = by_sym.setdefault(sym, {"kernel": sym, "launches": 0, "total_ms": 0.0, "flop": 0.0, "shapes": []})
+            e["launches"] += k["launches"]
+            e["total_ms"] += k["total_ms"]
+            e["flop"] += k["tflops"] * 1e9 * k["avg_ms"] * k["launches"]
+            e["shapes"].append(k["kernel"][len(sym):].strip())
+        dom = max(by_sym.values(), key=lambda e: e["total_ms"]) if by_sym else None
+        if dom:
+            dom["avg_ms"] = round(dom["total_ms"] / dom["launches"], 4)
+            dom["tflops"] = round(dom["flop"] / dom["total_ms"] / 1e9, 1)
         traffic = None
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if dom and os.path.exists(prof):
             try:
-                ent = json.load(open(prof)).get(dom["kernel"].split(" M=")[0].split(" B=")[0])
-                traffic = None if ent is None else ent.get("total_bytes")
+                ent = json.load(open(prof)).get(dom["kernel"])
+                traffic = None if ent is None else int(ent.get("total_bytes"))
             except Exception:
                 traffic = None
         line = {
@@ -288,7 +299,8 @@ def main():
                        "batch_per_gpu": B, "num_layers": args.layers, "parallelism": f"replica x{world} (no collective)",
                        "valid": args.layers == 30},
             "roofline": None if dom is None else {
-                "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": MFMA_PEAK_TFLOPS,
+                "bound": "mfma", "kernel": dom["kernel"], "shapes": dom["shapes"], "achieved": dom["tflops"],
+                "peak": MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "launches": dom["launches"], "avg_ms": dom["avg_ms"]},
             "kernels": kernels[:8],

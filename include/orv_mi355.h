@@ -153,6 +153,9 @@ typedef struct {
     void* Y; int ldy;   /* optional: also store acc + bias (before GELU / gate) at the same rows - saved for backward */
 } orv_gemm_t;
 int orv_gemm_bf16(const orv_gemm_t* g, void* stream);
+/* Kernel symbol (as rocprofv3 prints it, e.g. "gemm_pp_kernel<192, 5, 1>") that orv_gemm_bf16 launches for this shape on this
+ * device: the tile is chosen by a cost model over all candidates, so callers that label timings ask. */
+int orv_gemm_kernel_name(int M, int N, int K, int epilogue, char* buf, int len);
 
 /* -- backward (training) ------------------------------------------------------------------------------ */
 /* dst[c, r] = src[r, c] ([R, C] bf16 -> [C, ld_dst], columns [R, ld_dst) zero-filled).  Feeds the NT GEMM with the

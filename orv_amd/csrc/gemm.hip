@@ -584,6 +584,55 @@ int launch(const GemmArgs& a, int epi, hipStream_t st) {
 
 }  // namespace
 
+struct GemmCand { int ring, bm, bn; float rate; };
+
+// Tile / kernel choice: every candidate whose BN divides N is priced as
+//     rounds(tiles over the CUs) x BM x BN / relative_rate(candidate)
+// and the cheapest wins.  The rates are measured on MI355X at M = 12904 (tools/tile_sweep.sh rates); the rounds term is
+// what matters at small batch, where a "better" tile that needs one more, nearly empty, round loses to a smaller one that
+// fills the chip (B = 1: N = 1920 GEMMs take 195 tiles of 256x128 instead of 260 of 128x192).
+static const GemmCand* choose_tile(int M, int N) {
+    static const GemmCand cands[] = {
+        {1, 256, 256, 1.060f}, {1, 256, 192, 1.000f}, {1, 256, 128, 0.885f},
+        {0, 256, 192, 0.975f}, {0, 256, 128, 0.935f}, {0, 256, 64, 0.855f},
+        {0, 128, 192, 0.965f}, {0, 128, 128, 0.855f}, {0, 128, 64, 0.760f},
+    };
+    static int force_ring = -1, force_bm = 0, force_bn = 0;   // ORV_GEMM_TILE="ring,bm,bn" pins one candidate (sweeps / A-B)
+    if (force_ring < 0) {
+        force_ring = 2;
+        if (const char* e = getenv("ORV_GEMM_TILE")) sscanf(e, "%d,%d,%d", &force_ring, &force_bm, &force_bn);
+        if (const char* e = getenv("ORV_GEMM_ALGO")) { if (atoi(e) == 0) force_ring = 0; }   // legacy switch: simple kernel only
+    }
+    const int ncu = orv_num_cus();
+    const GemmCand* best = nullptr;
+    double best_cost = 0;
+    for (const GemmCand& c : cands) {
+        if (N % c.bn) continue;
+        if (force_bm && (c.ring != force_ring || c.bm != force_bm || c.bn != force_bn)) continue;
+        if (!force_bm && force_ring == 0 && c.ring) continue;
+        const long tiles = (long)((M + c.bm - 1) / c.bm) * (N / c.bn);
+        // full rounds cost 1 each; the last, partial round runs faster than a full one because the chip is power-capped
+        // (fewer active CUs clock higher): 0.62 (= 1.5 GHz / 2.4 GHz) + 0.38 x the fraction of CUs it occupies.
+        // Rows of the last M tile that do not exist still cost their MFMAs (tiles are counted whole).
+        const long full = tiles / ncu, rem = tiles % ncu;
+        const double rounds = (double)full + (rem ? 0.62 + 0.38 * (double)rem / ncu : 0.0);
+        const double cost = rounds * c.bm * c.bn / c.rate;
+        if (!best || cost < best_cost) { best = &c; best_cost = cost; }
+    }
+    return best;
+}
+
+// the kernel symbol orv_gemm_bf16 launches for a shape, as rocprofv3 prints it (bench.py labels its timings with it)
+extern "C" int orv_gemm_kernel_name(int M, int N, int K, int epilogue, char* buf, int len) {
+    (void)K;
+    ORV_REQUIRE(buf && len > 0 && M > 0 && N > 0 && N % 64 == 0, "orv_gemm_kernel_name: bad arguments");
+    const GemmCand* c = choose_tile(M, N);
+    ORV_REQUIRE(c, "orv_gemm_kernel_name: no tile configuration for N=%d", N);
+    if (c->ring) snprintf(buf, len, "gemm_pp_kernel<%d, 5, %d>", c->bn, epilogue);
+    else snprintf(buf, len, "gemm_kernel<%d, %d, %d>", c->bm, c->bn, epilogue);
+    return ORV_OK;
+}
+
 // BN must divide N: 192 divides 1920/5760/7680 (the 2B model) exactly, 128/256 cover 3072-wide (5B) and the tiny test
 // widths, 64 the 64-wide proj_out.
 extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
@@ -608,39 +657,7 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
     a.Y = (bf16_t*)g->Y; a.ldy = g->ldy;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("ORV_GEMM_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     hipStream_t st = (hipStream_t)stream;
-    // Tile / kernel choice: every candidate whose BN divides N is priced as
-    //     rounds(tiles over the CUs) x BM x BN / relative_rate(candidate)
-    // and the cheapest wins.  The rates are measured on MI355X at M = 12904 (tools/kbench_gemm tile sweep); the
-    // rounds term is what matters at small batch, where a "better" tile that needs one more, nearly empty, round loses to a
-    // smaller one that fills the chip (B = 1: N = 1920 GEMMs take 195 tiles of 256x128 instead of 260 of 128x192).
-    struct Cand { int ring, bm, bn; float rate; };
-    static const Cand cands[] = {
-        {1, 256, 256, 1.060f}, {1, 256, 192, 1.000f}, {1, 256, 128, 0.885f},
-        {0, 256, 192, 0.975f}, {0, 256, 128, 0.935f}, {0, 256, 64, 0.855f},
-        {0, 128, 192, 0.965f}, {0, 128, 128, 0.855f}, {0, 128, 64, 0.760f},
-    };
-    static int force_ring = -1, force_bm = 0, force_bn = 0;   // ORV_GEMM_TILE="ring,bm,bn" pins one candidate (sweeps / A-B)
-    if (force_ring < 0) {
-        force_ring = 2;
-        if (const char* e = getenv("ORV_GEMM_TILE")) sscanf(e, "%d,%d,%d", &force_ring, &force_bm, &force_bn);
-        if (const char* e = getenv("ORV_GEMM_ALGO")) { if (atoi(e) == 0) force_ring = 0; }   // legacy switch: simple kernel only
-    }
-    const int ncu = orv_num_cus();
-    const Cand* best = nullptr;
-    double best_cost = 0;
-    for (const Cand& c : cands) {
-        if (g->N % c.bn) continue;
-        if (force_bm && (c.ring != force_ring || c.bm != force_bm || c.bn != force_bn)) continue;
-        if (!force_bm && force_ring == 0 && c.ring) continue;
-        const long tiles = (long)((g->M + c.bm - 1) / c.bm) * (g->N / c.bn);
-        // full rounds cost 1 each; the last, partial round runs faster than a full one because the chip is power-capped
-        // (fewer active CUs clock higher): 0.62 (= 1.5 GHz / 2.4 GHz) + 0.38 x the fraction of CUs it occupies.
-        // Rows of the last M tile that do not exist still cost their MFMAs (tiles are counted whole).
-        const long full = tiles / ncu, rem = tiles % ncu;
-        const double rounds = (double)full + (rem ? 0.62 + 0.38 * (double)rem / ncu : 0.0);
-        const double cost = rounds * c.bm * c.bn / c.rate;
-        if (!best || cost < best_cost) { best = &c; best_cost = cost; }
-    }
+    const GemmCand* best = choose_tile(g->M, g->N);
     ORV_REQUIRE(best, "orv_gemm_bf16: no tile configuration for N=%d (ORV_GEMM_TILE override?)", g->N);
     a.tiles_n = g->N / best->bn;
     a.tiles_m = (g->M + best->bm - 1) / best->bm;
