@@ -178,6 +178,8 @@ def main():
     ap.add_argument("--mode", choices=["denoise", "train"], default="denoise",
                     help="denoise (headline, BASELINE configs[1]) or train (configs[2]: one SFT step = fwd+bwd+all-reduce+AdamW)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the transformer forward from a HIP graph (B=1 latency); "
+                                                         "the per-kernel roofline needs the eager path and is omitted")
     ap.add_argument("--cpu-baseline-layers", type=int, default=6)
     args = ap.parse_args()
 
@@ -206,13 +208,18 @@ def main():
     ts = sched.timesteps.tolist()
     controls = {"actions": actions}
 
+    fwd = model
+    if args.graph:                      # transformer forward replayed from a HIP graph (per-kernel timeline unavailable)
+        from orv_amd.cogvideox_control import GraphedTransformer
+        fwd = GraphedTransformer(model)
+
     @torch.no_grad()                    # the reference sampler runs under torch.no_grad (cogvideox_control.py:1228)
     def step(i, lat):
         t = ts[i % len(ts)]
         model_in = torch.cat([lat, image_latents], dim=2)                   # cogvideox_control.py:1409-1413
         tvec = torch.full((B,), t, device=dev, dtype=torch.int64)
-        v = model(hidden_states=model_in, encoder_hidden_states=prompt, timestep=tvec,
-                  controls_or_guidances=controls, return_dict=False)[0]
+        v = fwd(hidden_states=model_in, encoder_hidden_states=prompt, timestep=tvec,
+                controls_or_guidances=controls, return_dict=False)[0]
         return sched.step(v, t, lat, return_dict=False)[0]
 
     if args.mode == "train":

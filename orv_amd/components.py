@@ -57,7 +57,9 @@ class ActionEmbed(nn.Module):
         h = ops.skinny_linear(x.reshape(B * frames, -1).to(torch.bfloat16), w0.weight, w0.bias, act_out="gelu_tanh")
         emb = ops.skinny_linear(h, w3.weight, w3.bias).view(B, frames, -1)
         if self.forced_mask is not None:
-            is_mask = self.forced_mask.to(device=x.device, dtype=torch.bool)
+            if self.forced_mask.device != x.device or self.forced_mask.dtype != torch.bool:
+                self.forced_mask = self.forced_mask.to(device=x.device, dtype=torch.bool)   # once: no H2D copy per call
+            is_mask = self.forced_mask
         else:
             is_mask = torch.rand(B, device=x.device) < 0.1
         if self.mask:

@@ -64,6 +64,9 @@ __global__ __launch_bounds__((WM*WN+NP)*64) void k(const char* G, float* out, in
   // fill LDS with something non-trivial
   for(int i=threadIdx.x;i<NSLOT*SLOT/4;i+=blockDim.x) ((uint32_t*)smem)[i]=0x3f803f80u ^ ((i*2654435761u)&0x007f007fu);
   __syncthreads();
+#ifdef PROBE_PRIO
+  __builtin_amdgcn_s_setprio(PROBE_PRIO);
+#endif
   f16v acc[MI][NI];
   for(int i=0;i<MI;i++) for(int j=0;j<NI;j++) for(int e=0;e<16;e++) acc[i][j][e]=0.f;
   const int r=lane&31, c=lane>>5;
@@ -130,14 +133,11 @@ int main(){
   { std::vector<uint16_t> h((gspan+(4<<20))/2); for(size_t i=0;i<h.size();i++) h[i]=0x3f80 ^ (uint16_t)((i*2654435761u)>>25); CK(hipMemcpy(G,h.data(),h.size()*2,hipMemcpyHostToDevice)); }
   float* out; CK(hipMalloc(&out,8192));
   for(size_t span : {(size_t)16<<20}){
+    run<2,3,4,2,5,0>(G,out,span,"cur 256x192 8w no-glds");
     run<2,3,4,2,5,1>(G,out,span,"cur 256x192 8w glds+barrier");
-    run<4,3,2,2,2,0>(G,out,span,"2WG/CU 256x192 4w(128x96) no-glds");
-    run<4,3,2,2,2,1>(G,out,span,"2WG/CU 256x192 4w(128x96) glds 2slot");
-    run<2,5,4,1,3,0>(G,out,span,"2WG/CU 256x160 4w(64x160) no-glds");
-    run<2,5,4,1,3,1>(G,out,span,"2WG/CU 256x160 4w(64x160) glds 3slot");
-    run<2,5,4,1,3,3>(G,out,span,"2WG/CU 256x160 4w glds 3slot nobarrier");
-    run<4,2,2,2,3,1>(G,out,span,"2WG/CU 256x128 4w(128x64) glds 3slot");
-    run<2,4,4,1,3,1>(G,out,span,"2WG/CU 256x128 4w(64x128) glds 3slot");
+    run<2,3,4,2,5,0,4>(G,out,span,"256x192 8 cons + 4 prod");
+    run<2,4,4,2,4,0,4>(G,out,span,"256x256 8 cons + 4 prod");
+    run<2,4,4,2,4,1>(G,out,span,"256x256 8w glds+barrier");
   }
   return 0;
 }
