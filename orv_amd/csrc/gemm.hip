@@ -85,41 +85,45 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[N
         // Every vector load issued here queues BEHIND the DMA pieces already in flight for the next tile (vmcnt retires in
         // order), i.e. costs a full loaded-memory-pipeline latency: so the bias comes through the scalar cache (uniform
         // address, s_load), and the per-row operands (residual, gate) of a row block are all requested up front.
-        uint32_t rq[NB][2][2][2];   // [block][u][quad t][dword]: residual / pre-activation operand, this lane's 4 columns
+        constexpr int IB = NB <= 4 ? NB : 2;   // blocks whose row operands are requested together (register budget)
         bool g_uniform = false;     // all rows of this 32-row block share one gate row -> gate through the scalar cache too
         const float* g_srow = nullptr;
+        if (EPI == 2 && p.gate) {
+            const int mf = __builtin_amdgcn_readfirstlane(mbase + j * 32), ml = min(mf + 31, p.M - 1);
+            long of = mf, ol = ml;
+            if (p.c_rows > 0) {
+                of = (long)(mf / p.c_rows) * p.c_bstride + p.c_off + mf % p.c_rows;
+                ol = (long)(ml / p.c_rows) * p.c_bstride + p.c_off + ml % p.c_rows;
+            }
+            const int bf_ = (int)(of / p.seq), bl_ = (int)(ol / p.seq);
+            const int gf_ = orv_group_of((int)(of % p.seq), p.n_text, p.per_group);
+            const int gl_ = orv_group_of((int)(ol % p.seq), p.n_text, p.per_group);
+            g_uniform = (bf_ == bl_) && (gf_ == gl_);
+            g_srow = p.gate + bf_ * p.gate_b + gf_ * p.gate_g;
+        }
+#pragma unroll
+        for (int i0 = 0; i0 < NB; i0 += IB) {
+        uint32_t rq[IB][2][2][2];   // [block][u][quad t][dword]: residual / pre-activation operand, this lane's 4 columns
         if (EPI == 2 || EPI == 3) {
 #pragma unroll
-            for (int i = 0; i < NB; ++i)
+            for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const uint4 rr = *(const uint4*)(rrow + nbase + i * 32 + (2 * u + hi) * 8);
-                    rq[i][u][0][0] = rr.x; rq[i][u][0][1] = rr.y; rq[i][u][1][0] = rr.z; rq[i][u][1][1] = rr.w;
+                    const uint4 rr = *(const uint4*)(rrow + nbase + (i0 + ii) * 32 + (2 * u + hi) * 8);
+                    rq[ii][u][0][0] = rr.x; rq[ii][u][0][1] = rr.y; rq[ii][u][1][0] = rr.z; rq[ii][u][1][1] = rr.w;
                 }
-            if (EPI == 2 && p.gate) {
-                const int mf = __builtin_amdgcn_readfirstlane(mbase + j * 32), ml = min(mf + 31, p.M - 1);
-                long of = mf, ol = ml;
-                if (p.c_rows > 0) {
-                    of = (long)(mf / p.c_rows) * p.c_bstride + p.c_off + mf % p.c_rows;
-                    ol = (long)(ml / p.c_rows) * p.c_bstride + p.c_off + ml % p.c_rows;
-                }
-                const int bf_ = (int)(of / p.seq), bl_ = (int)(ol / p.seq);
-                const int gf_ = orv_group_of((int)(of % p.seq), p.n_text, p.per_group);
-                const int gl_ = orv_group_of((int)(ol % p.seq), p.n_text, p.per_group);
-                g_uniform = (bf_ == bl_) && (gf_ == gl_);
-                g_srow = p.gate + bf_ * p.gate_b + gf_ * p.gate_g;
-            }
 #pragma unroll
-            for (int i = 0; i < NB; ++i)
+            for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     // loaded: lower = group 2u cols 0-7, upper = group 2u+1 cols 0-7  ->  (quad 2u | quad 2u+1) own 4 columns
-                    swap_halves(rq[i][u][0][0], rq[i][u][1][0]);
-                    swap_halves(rq[i][u][0][1], rq[i][u][1][1]);
+                    swap_halves(rq[ii][u][0][0], rq[ii][u][1][0]);
+                    swap_halves(rq[ii][u][0][1], rq[ii][u][1][1]);
                 }
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
+        for (int ii = 0; ii < IB; ++ii) {
+            const int i = i0 + ii;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 // this lane's 16-byte piece: column group 2u + hi of the 32-column block
@@ -161,12 +165,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[N
                                 g[0] = gg.x; g[1] = gg.y; g[2] = gg.z; g[3] = gg.w;
                             }
                         }
-                        v[0] = bf2f(rq[i][u][t][0] & 0xffff) + g[0] * v[0]; v[1] = bf2f(rq[i][u][t][0] >> 16) + g[1] * v[1];
-                        v[2] = bf2f(rq[i][u][t][1] & 0xffff) + g[2] * v[2]; v[3] = bf2f(rq[i][u][t][1] >> 16) + g[3] * v[3];
+                        v[0] = bf2f(rq[ii][u][t][0] & 0xffff) + g[0] * v[0]; v[1] = bf2f(rq[ii][u][t][0] >> 16) + g[1] * v[1];
+                        v[2] = bf2f(rq[ii][u][t][1] & 0xffff) + g[2] * v[2]; v[3] = bf2f(rq[ii][u][t][1] >> 16) + g[3] * v[3];
                     }
                     if (EPI == 3) {   // backward through GELU(tanh): C = acc * gelu'(U), U = saved pre-activation
-                        v[0] *= gelu_tanh_grad(bf2f(rq[i][u][t][0] & 0xffff)); v[1] *= gelu_tanh_grad(bf2f(rq[i][u][t][0] >> 16));
-                        v[2] *= gelu_tanh_grad(bf2f(rq[i][u][t][1] & 0xffff)); v[3] *= gelu_tanh_grad(bf2f(rq[i][u][t][1] >> 16));
+                        v[0] *= gelu_tanh_grad(bf2f(rq[ii][u][t][0] & 0xffff)); v[1] *= gelu_tanh_grad(bf2f(rq[ii][u][t][0] >> 16));
+                        v[2] *= gelu_tanh_grad(bf2f(rq[ii][u][t][1] & 0xffff)); v[3] *= gelu_tanh_grad(bf2f(rq[ii][u][t][1] >> 16));
                     }
                     oc[t][0] = pack2bf(v[0], v[1]); oc[t][1] = pack2bf(v[2], v[3]);
                 }
@@ -182,6 +186,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[N
 #endif
                 *(uint4*)(crow + n16) = make_uint4(oc[0][0], oc[0][1], oc[1][0], oc[1][1]);
             }
+        }
         }
     }
 }
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs p) {
 //     per phase) both stall the matrix pipe ~45 % of the time - the first on lock-step LDS latency + DMA issue bursts,
 //     the second on the barrier itself (only one wave per SIMD ever has MFMAs to issue).
 // ---------------------------------------------------------------------------------------------------------------
-template <int BN, int NSLOT, int EPI, int NPC>
+template <int BN, int NSLOT, int EPI, int NPC, bool ONESET = false>
 __device__ __forceinline__ void gemm_ring_body(const GemmArgs& p, char* smem, const int wave, const int lane) {
     constexpr int BM = 256;
     constexpr int MB = 2, NB = BN / 64;            // wave sub-tile: 64 rows x BN/2 cols as 32x32 blocks
@@ -390,10 +395,11 @@ __device__ __forceinline__ void gemm_ring_body(const GemmArgs& p, char* smem, co
     const int a_off = (wq * 64 + l31) * 64;
     const int b_off = (BM + grp * (BN / 2) + l31) * 64;
     const int coff0 = ((0 * 2 + hi) ^ sw) * 16, coff1 = ((1 * 2 + hi) ^ sw) * 16;
-    bf16x8 fa0[2][MB], fb0[2][NB], fa1[2][MB], fb1[2][NB];   // two fragment sets [k-step][block]
+    // two fragment sets [k-step][block]; ONESET (BN = 384: 192 accumulator registers) keeps ONE k-step's fragments only
+    bf16x8 fa0[ONESET ? 1 : 2][MB], fb0[ONESET ? 1 : 2][NB], fa1[ONESET ? 1 : 2][ONESET ? 1 : MB], fb1[ONESET ? 1 : 2][ONESET ? 1 : NB];
     int rd_slot = 0;               // ring slot of the next sub-stage to read
 #define ORV_READ_FRAGS(FA, FB)                                                                                       \
-    {                                                                                                                \
+    if constexpr (!ONESET) {                                                                                         \
         const char* sb_ = smem + rd_slot * SLOT;                                                                     \
         _Pragma("unroll") for (int j = 0; j < MB; ++j) {                                                             \
             FA[0][j] = *(const bf16x8*)(sb_ + a_off + j * 32 * 64 + coff0);                                          \
@@ -414,7 +420,8 @@ __device__ __forceinline__ void gemm_ring_body(const GemmArgs& p, char* smem, co
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     constexpr int NSTORE = NB * MB * 2;   // 16-byte C stores one wave issues per full tile (no Y output)
-    static_assert((NSLOT - 3) * NPC + NSTORE <= 63, "vmcnt immediate is 6 bits");
+    constexpr int AHEAD = ONESET ? NSLOT - 2 : NSLOT - 3;   // sub-stages that may still be in flight at the top of a sub-stage
+    static_assert(AHEAD * NPC + NSTORE <= 63, "vmcnt immediate is 6 bits");
     int st_pending = 0;                   // sub-stages whose DMA pieces were issued before the last epilogue's stores
 
 #ifdef ORV_GEMM_ABLATE_NOMFMA
@@ -455,14 +462,57 @@ __device__ __forceinline__ void gemm_ring_body(const GemmArgs& p, char* smem, co
         ORV_ADVANCE()                                                                                                \
     }
 
+    // single-fragment-set form (ONESET): the wave reads the fragments of ITS OWN current sub-stage, one k-step at a time,
+    // and leaves the LDS latency to the other wave of the SIMD; sub-stage g must have landed at the top of sub-stage g,
+    // so one more sub-stage may stay in flight for the same ring depth.
+#define ORV_READ_K(KK)                                                                                               \
+    {                                                                                                                \
+        _Pragma("unroll") for (int j = 0; j < MB; ++j)                                                               \
+            fa0[0][j] = *(const bf16x8*)(sb1_ + a_off + j * 32 * 64 + ((KK) ? coff1 : coff0));                       \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                               \
+            fb0[0][i] = *(const bf16x8*)(sb1_ + b_off + i * 32 * 64 + ((KK) ? coff1 : coff0));                       \
+    }
+#define ORV_SUBSTAGE1()                                                                                              \
+    {                                                                                                                \
+        if (st_pending > 0) {                                                                                        \
+            --st_pending;                                                                                            \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * NPC + NSTORE) : "memory");                              \
+        } else {                                                                                                     \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * NPC) : "memory");                                       \
+        }                                                                                                            \
+        __builtin_amdgcn_s_barrier();                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        const char* sb1_ = smem + rd_slot * SLOT;                                                                    \
+        rd_slot = (rd_slot + 1 == NSLOT) ? 0 : rd_slot + 1;                                                          \
+        ORV_READ_K(0)                                                                                                \
+        ORV_ISSUE_MAIN()                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                               \
+            _Pragma("unroll") for (int j = 0; j < MB; ++j) { ORV_MFMA(fa0, fb0, 0, i, j) }                           \
+        __builtin_amdgcn_sched_group_barrier(0x100, MB + NB, 0);                                                     \
+        if constexpr (NPC >= 1) { __builtin_amdgcn_sched_group_barrier(0x8, 2, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); } \
+        if constexpr (NPC >= 2) { __builtin_amdgcn_sched_group_barrier(0x8, 2, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); } \
+        if constexpr (NPC >= 3) { __builtin_amdgcn_sched_group_barrier(0x8, 2, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); } \
+        if constexpr (NPC >= 4) { __builtin_amdgcn_sched_group_barrier(0x8, 2, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); } \
+        if constexpr (NPC >= 5) { __builtin_amdgcn_sched_group_barrier(0x8, 2, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); } \
+        __builtin_amdgcn_sched_group_barrier(0x8, NB * MB - 2 * NPC, 0);                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        ORV_READ_K(1)                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                               \
+            _Pragma("unroll") for (int j = 0; j < MB; ++j) { ORV_MFMA(fa0, fb0, 0, i, j) }                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        ORV_ADVANCE()                                                                                                \
+    }
+
     // prologue: stream sub-stages 0 .. NSLOT-2, then fragments of sub-stage 0
 #pragma unroll
     for (int s2 = 0; s2 < NSLOT - 1; ++s2) {
         ORV_ISSUE_PIECES()
         ORV_ADVANCE()
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 2) * NPC) : "memory");
-    __builtin_amdgcn_s_barrier();
+    if constexpr (!ONESET) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 2) * NPC) : "memory");
+        __builtin_amdgcn_s_barrier();
+    }
     ORV_READ_FRAGS(fa0, fb0)
 #ifdef ORV_GEMM_TRACE   // tools/trace_gemm.cpp: s_memtime stamps of workgroup 0 / wave 0 (R doubles as the trace buffer, EPI 0/1 only)
     int trace_i = 0;
@@ -473,8 +523,13 @@ __device__ __forceinline__ void gemm_ring_body(const GemmArgs& p, char* smem, co
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         ORV_TRACE(0)
         for (int j = 0; j < nsub; j += 2) {            // K % 64 == 0, so nsub is even: static fragment-set names
-            ORV_SUBSTAGE(fa0, fb0, fa1, fb1)
-            ORV_SUBSTAGE(fa1, fb1, fa0, fb0)
+            if constexpr (ONESET) {
+                ORV_SUBSTAGE1()
+                ORV_SUBSTAGE1()
+            } else {
+                ORV_SUBSTAGE(fa0, fb0, fa1, fb1)
+                ORV_SUBSTAGE(fa1, fb1, fa0, fb0)
+            }
         }
         // finished tile -> memory.  vmcnt counts the epilogue's stores too and retires in issue order (loads and stores
         // share the counter on gfx9-class hardware), so the counted DMA waits of the next NSLOT-2 sub-stages - whose pieces
@@ -493,7 +548,7 @@ __device__ __forceinline__ void gemm_ring_body(const GemmArgs& p, char* smem, co
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j2][e] = 0.f;
         if (tm * BM + BM <= p.M && !p.Y && p.dbg != 7) {
-            st_pending = NSLOT - 2;
+            st_pending = ONESET ? NSLOT - 1 : NSLOT - 2;
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -510,6 +565,8 @@ __device__ __forceinline__ void gemm_ring_body(const GemmArgs& p, char* smem, co
 #undef ORV_MFMA
 #undef ORV_ISSUE_MAIN
 #undef ORV_SUBSTAGE
+#undef ORV_SUBSTAGE1
+#undef ORV_READ_K
 #undef ORV_TRACE
 }
 
@@ -526,8 +583,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave < 4) gemm_ring_body<BN, NSLOT, EPI, NP_G0>(p, smem, wave, lane);
-    else gemm_ring_body<BN, NSLOT, EPI, NP_G1>(p, smem, wave, lane);
+    if (wave < 4) gemm_ring_body<BN, NSLOT, EPI, NP_G0, (BN > 256)>(p, smem, wave, lane);
+    else gemm_ring_body<BN, NSLOT, EPI, NP_G1, (BN > 256)>(p, smem, wave, lane);
 }
 
 template <int BN, int NSLOT>
@@ -584,7 +641,7 @@ int launch(const GemmArgs& a, int epi, hipStream_t st) {
 
 }  // namespace
 
-struct GemmCand { int ring, bm, bn; float rate; };
+struct GemmCand { int ring, bm, bn; float rate; int min_rounds; };
 
 // Tile / kernel choice: every candidate whose BN divides N is priced as
 //     rounds(tiles over the CUs) x BM x BN / relative_rate(candidate)
@@ -593,9 +650,11 @@ struct GemmCand { int ring, bm, bn; float rate; };
 // fills the chip (B = 1: N = 1920 GEMMs take 195 tiles of 256x128 instead of 260 of 128x192).
 static const GemmCand* choose_tile(int M, int N) {
     static const GemmCand cands[] = {
-        {1, 256, 256, 1.060f}, {1, 256, 192, 1.000f}, {1, 256, 128, 0.885f},
-        {0, 256, 192, 0.975f}, {0, 256, 128, 0.935f}, {0, 256, 64, 0.855f},
-        {0, 128, 192, 0.965f}, {0, 128, 128, 0.855f}, {0, 128, 64, 0.760f},
+        // 256x384 keeps ONE fragment set (192 accumulator registers) and leans on its neighbour tiles to hide the exposed
+        // prologue / epilogue: measured +8 % on QKV (765 tiles), a loss when every CU gets a single tile (N = 1920: 255)
+        {1, 256, 384, 1.075f, 2}, {1, 256, 256, 1.060f, 0}, {1, 256, 192, 1.000f, 0}, {1, 256, 128, 0.885f, 0},
+        {0, 256, 192, 0.975f, 0}, {0, 256, 128, 0.935f, 0}, {0, 256, 64, 0.855f, 0},
+        {0, 128, 192, 0.965f, 0}, {0, 128, 128, 0.855f, 0}, {0, 128, 64, 0.760f, 0},
     };
     static int force_ring = -1, force_bm = 0, force_bn = 0;   // ORV_GEMM_TILE="ring,bm,bn" pins one candidate (sweeps / A-B)
     if (force_ring < 0) {
@@ -603,6 +662,8 @@ static const GemmCand* choose_tile(int M, int N) {
         if (const char* e = getenv("ORV_GEMM_TILE")) sscanf(e, "%d,%d,%d", &force_ring, &force_bm, &force_bn);
         if (const char* e = getenv("ORV_GEMM_ALGO")) { if (atoi(e) == 0) force_ring = 0; }   // legacy switch: simple kernel only
     }
+    static int no384 = -1;   // ORV_GEMM_BN384=0: A/B switch for the 384-wide variant
+    if (no384 < 0) { const char* e = getenv("ORV_GEMM_BN384"); no384 = (e && atoi(e) == 0) ? 1 : 0; }
     const int ncu = orv_num_cus();
     const GemmCand* best = nullptr;
     double best_cost = 0;
@@ -611,6 +672,8 @@ static const GemmCand* choose_tile(int M, int N) {
         if (force_bm && (c.ring != force_ring || c.bm != force_bm || c.bn != force_bn)) continue;
         if (!force_bm && force_ring == 0 && c.ring) continue;
         const long tiles = (long)((M + c.bm - 1) / c.bm) * (N / c.bn);
+        if (!force_bm && tiles < (long)c.min_rounds * ncu) continue;
+        if (!force_bm && c.bn == 384 && no384) continue;
         // full rounds cost 1 each; the last, partial round runs faster than a full one because the chip is power-capped
         // (fewer active CUs clock higher): 0.62 (= 1.5 GHz / 2.4 GHz) + 0.38 x the fraction of CUs it occupies.
         // Rows of the last M tile that do not exist still cost their MFMAs (tiles are counted whole).
@@ -628,7 +691,7 @@ extern "C" int orv_gemm_kernel_name(int M, int N, int K, int epilogue, char* buf
     ORV_REQUIRE(buf && len > 0 && M > 0 && N > 0 && N % 64 == 0, "orv_gemm_kernel_name: bad arguments");
     const GemmCand* c = choose_tile(M, N);
     ORV_REQUIRE(c, "orv_gemm_kernel_name: no tile configuration for N=%d", N);
-    if (c->ring) snprintf(buf, len, "gemm_pp_kernel<%d, 5, %d>", c->bn, epilogue);
+    if (c->ring) snprintf(buf, len, "gemm_pp_kernel<%d, %d, %d>", c->bn, c->bn == 384 ? 4 : 5, epilogue);
     else snprintf(buf, len, "gemm_kernel<%d, %d, %d>", c->bm, c->bn, epilogue);
     return ORV_OK;
 }
@@ -662,6 +725,7 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
     a.tiles_n = g->N / best->bn;
     a.tiles_m = (g->M + best->bm - 1) / best->bm;
     if (best->ring) {
+        if (best->bn == 384) return launch_pp<384, 4>(a, g->epilogue, st);
         if (best->bn == 256) return launch_pp<256, 5>(a, g->epilogue, st);
         if (best->bn == 192) return launch_pp<192, 5>(a, g->epilogue, st);
         return launch_pp<128, 5>(a, g->epilogue, st);

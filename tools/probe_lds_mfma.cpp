@@ -128,16 +128,78 @@ template<int MI,int NI,int WM,int WN,int NSLOT,int GLDS,int NP=0,int CM=0,int PM
   double fl=(double)grid*iters*2.0*BM*BN*32; 
   printf("%-34s NP=%d tile %3dx%3d waves %d (wave tile %3dx%3d) slots %d smem %3dKB glds %d : %.3f ms  %.0f TF  clk %.0f MHz\n",name,NP,BM,BN,WM*WN,MI*32,NI*32,NSLOT,smem/1024,GLDS,ms,fl/ms/1e9,(double)hc[0]/((double)hc[1]/100.0));
 }
+
+typedef __attribute__((ext_vector_type(4))) float f4v;
+// same loop with v_mfma_f32_16x16x32_bf16: wave tile (MI*32) x (NI*32) as 16x16 blocks, one K=32 step per sub-stage
+template<int MI,int NI,int WM,int WN,int NSLOT,int GLDS,int DEPTH=NSLOT-2>
+__global__ __launch_bounds__(WM*WN*64) void k16(const char* G, float* out, int iters, size_t gspan){
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const long long c0=clock64(), w0=wall_clock64();
+  constexpr int BM=MI*32*WM, BN=NI*32*WN, ROWS=BM+BN, SLOT=ROWS*64, NW=WM*WN;
+  constexpr int PIECES=ROWS/16, PPW=PIECES/NW;
+  constexpr int MB=MI*2, NB=NI*2;   // 16-row blocks
+  const int lane=threadIdx.x&63, wave=__builtin_amdgcn_readfirstlane(threadIdx.x>>6);
+  const int wm=wave%WM, wn=wave/WM;
+  for(int i=threadIdx.x;i<NSLOT*SLOT/4;i+=blockDim.x) ((uint32_t*)smem)[i]=0x3f803f80u ^ ((i*2654435761u)&0x007f007fu);
+  __syncthreads();
+  f4v acc[MB][NB];
+  for(int i=0;i<MB;i++) for(int j=0;j<NB;j++) for(int e=0;e<4;e++) acc[i][j][e]=0.f;
+  const int r=lane&15, c=lane>>4;
+  int aoff[MB], boff[NB];
+  for(int i=0;i<MB;i++){ int row=wm*MI*32+i*16+r; aoff[i]=row*64+((c^((row>>2)&3))*16); }
+  for(int j=0;j<NB;j++){ int row=BM+wn*NI*32+j*16+r; boff[j]=row*64+((c^((row>>2)&3))*16); }
+  const char* gsrc=G+((size_t)blockIdx.x*ROWS*64)%gspan + (size_t)wave*PPW*1024 + lane*16;
+  for(int it=0;it<iters;it++){
+    char* base=smem+(it%NSLOT)*SLOT;
+    if(GLDS){
+      char* dst=smem+((it+NSLOT-1)%NSLOT)*SLOT+wave*PPW*1024;
+      #pragma unroll
+      for(int p=0;p<PPW;p++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc+((size_t)it*SLOT+p*1024)%gspan),
+                                         (__attribute__((address_space(3))) void*)(dst+p*1024),16,0,0);
+    }
+    bf8 a[MB], b[NB];
+    #pragma unroll
+    for(int i=0;i<MB;i++) a[i]=*(const bf8*)(base+aoff[i]);
+    #pragma unroll
+    for(int j=0;j<NB;j++) b[j]=*(const bf8*)(base+boff[j]);
+    #pragma unroll
+    for(int i=0;i<MB;i++)
+      #pragma unroll
+      for(int j=0;j<NB;j++) acc[i][j]=__builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i],b[j],acc[i][j],0,0,0);
+    if(GLDS){ asm volatile("s_waitcnt vmcnt(%0)"::"n"(PPW*DEPTH>63?63:PPW*DEPTH):"memory"); __builtin_amdgcn_s_barrier(); }
+  }
+  asm volatile("s_waitcnt vmcnt(0)":::"memory");
+  if(blockIdx.x==0 && threadIdx.x==0){ ((long long*)(out+1024))[0]=clock64()-c0; ((long long*)(out+1024))[1]=wall_clock64()-w0; }
+  float s=0; for(int i=0;i<MB;i++) for(int j=0;j<NB;j++) for(int e=0;e<4;e++) s+=acc[i][j][e];
+  if(s==123.456f) out[threadIdx.x]=s;
+}
+template<int MI,int NI,int WM,int WN,int NSLOT,int GLDS,int DEPTH=NSLOT-2> void run16(const char* G,float* out,size_t gspan,const char* name){
+  constexpr int BM=MI*32*WM, BN=NI*32*WN; int smem=NSLOT*(BM+BN)*64; int iters=600;
+  CK(hipFuncSetAttribute((const void*)k16<MI,NI,WM,WN,NSLOT,GLDS,DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  int grid=256*4;
+  hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for(int i=0;i<2;i++) k16<MI,NI,WM,WN,NSLOT,GLDS,DEPTH><<<grid,WM*WN*64,smem>>>(G,out,iters,gspan);
+  hipEventRecord(e0); for(int i=0;i<5;i++) k16<MI,NI,WM,WN,NSLOT,GLDS,DEPTH><<<grid,WM*WN*64,smem>>>(G,out,iters,gspan); hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms,e0,e1); ms/=5; CK(hipGetLastError());
+  long long hc[2]; CK(hipMemcpy(hc,out+1024,16,hipMemcpyDeviceToHost));
+  double fl=(double)grid*iters*2.0*BM*BN*32;
+  printf("%-34s [16x16x32] depth %d tile %3dx%3d waves %d glds %d : %.3f ms  %.0f TF  clk %.0f MHz\n",name,DEPTH,BM,BN,WM*WN,GLDS,ms,fl/ms/1e9,(double)hc[0]/((double)hc[1]/100.0));
+}
+
 int main(){
   size_t gspan=(size_t)256<<20; char* G; CK(hipMalloc(&G,gspan+(4<<20))); 
   { std::vector<uint16_t> h((gspan+(4<<20))/2); for(size_t i=0;i<h.size();i++) h[i]=0x3f80 ^ (uint16_t)((i*2654435761u)>>25); CK(hipMemcpy(G,h.data(),h.size()*2,hipMemcpyHostToDevice)); }
   float* out; CK(hipMalloc(&out,8192));
-  for(size_t span : {(size_t)16<<20}){
-    run<2,3,4,2,5,0>(G,out,span,"cur 256x192 8w no-glds");
-    run<2,3,4,2,5,1>(G,out,span,"cur 256x192 8w glds+barrier");
-    run<2,3,4,2,5,0,4>(G,out,span,"256x192 8 cons + 4 prod");
-    run<2,4,4,2,4,0,4>(G,out,span,"256x256 8 cons + 4 prod");
-    run<2,4,4,2,4,1>(G,out,span,"256x256 8w glds+barrier");
+  for(size_t span : {(size_t)2<<20, (size_t)64<<20}){
+    printf("--- span %zu MB\n", span>>20);
+    run16<2,3,4,2,5,1,0>(G,out,span,"256x192 depth0");
+    run16<2,3,4,2,5,1,1>(G,out,span,"256x192 depth1");
+    run16<2,3,4,2,5,1,2>(G,out,span,"256x192 depth2");
+    run16<2,3,4,2,5,1,3>(G,out,span,"256x192 depth3");
+    run16<2,2,4,2,5,1,3>(G,out,span,"256x128 depth3");
+    run16<2,2,4,2,6,1,4>(G,out,span,"256x128 6 slots depth4");
+    run16<2,2,4,2,6,1,2>(G,out,span,"256x128 6 slots depth2");
   }
   return 0;
 }
