@@ -23,7 +23,6 @@ namespace {
 constexpr int KV = 64;            // keys per tile
 constexpr int TILE_BYTES = 8192;  // 64 rows x 128 B (K tile, and V^T tile)
 constexpr int SLOT_BYTES = 2 * TILE_BYTES;
-constexpr int NSLOT = 4;          // K/V ring depth (64 KiB of LDS)
 constexpr float RESCALE_THR = 8.f;  // defer the running-max update while exp2 arguments stay <= 8 (P <= 256)
 
 struct AttnArgs {
@@ -49,204 +48,10 @@ __device__ __forceinline__ float sum_with_partner_half(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// Per KV tile each wave does: S^T(t+1) = K(t+1).Q^T (8 MFMA, issued first so the matrix pipe works under the softmax),
-// online softmax of S^T(t) (VALU), O^T += V^T(t).P^T(t) (8 MFMA).  K/V tiles stream through a 4-slot LDS ring filled by
-// global_load_lds two tiles ahead with counted vmcnt waits; one s_barrier per tile.
-template <bool LAZY, bool AHEAD, bool FUSED, int MINW = 2>
-__global__ __launch_bounds__(512, MINW) void attn_fwd_kernel(const AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[NSLOT * SLOT_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
-    // 1-D grid, head-major items (all query tiles of a (b, h) consecutive) handed out per XCD: K / V^T of a head are
-    // streamed into one L2, not eight (PMC: 863 MB fetched per launch against 149 MB of operands before)
-    const int nqt = (p.S + 255) / 256;
-    const int item = orv_xcd_item(blockIdx.x, gridDim.x);
-    const int bh = item / nqt, h = bh % p.H, b = bh / p.H;
-    const int q0 = (item % nqt) * 256 + wave * 32;
-    const int D = p.H * 64;
-    const long row0 = (long)b * p.S;
-
-    // ---- Q fragments (B operand of S^T = K.Q^T): lane holds q row (q0+l31), d = ks*16 + hi*8 .. +8 ----
-    bf16x8 qf[4];
-    {
-        const int qr = min(q0 + l31, p.S - 1);
-        const bf16_t* qp = p.qkv + (row0 + qr) * p.ld + h * 64 + hi * 8;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
-    }
-
-    // ---- DMA: wave w moves K rows 8w..8w+7 and V^T rows (d) 8w..8w+7 of each tile ----
-    const int srow = wave * 8 + (lane >> 3), slot16 = lane & 7;
-    const int schunk = slot16 ^ ((srow >> 1) & 7);
-    const bf16_t* kbase = p.qkv + D + h * 64 + schunk * 8;                                   // + key row * ld
-    const bf16_t* vsrc = p.vT + ((long)(b * p.H + h) * 64 + srow) * p.s_pad + schunk * 8;  // + kv0
-    const int nt = (p.S + KV - 1) / KV;
-    int dma_tile = 0, dma_slot = 0;
-#define ATTN_ISSUE_TILE()                                                                              \
-    {                                                                                                  \
-        const int kv0_ = min(dma_tile, nt - 1) * KV; /* past the end: harmless re-fetch of the last tile */ \
-        const int krow_ = min(kv0_ + srow, p.S - 1);                                                   \
-        glds16(kbase + (row0 + krow_) * p.ld, smem + dma_slot * SLOT_BYTES + wave * 1024);             \
-        glds16(vsrc + kv0_, smem + dma_slot * SLOT_BYTES + TILE_BYTES + wave * 1024);                  \
-        ++dma_tile;                                                                                    \
-        dma_slot = (dma_slot + 1) & (NSLOT - 1);                                                       \
-    }
-
-    f32x16 oT[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) oT[i][e] = 0.f;
-    // running max and this lane's partial row sum.  FUSED (q pre-multiplied by scale*log2e in orv_qkv_prep): m_run is in
-    // log2 units and lives in the S^T accumulator init (S' = q.k - m_run comes straight out of the MFMA), so the softmax
-    // needs no per-score VALU op besides v_exp_f32; otherwise m_run is in raw score units.
-    float m_run = FUSED ? 0.f : -INFINITY, l_run = 0.f;
-    const float c = p.scale_log2;
-    const int row_off = l31 * 128;
-    const int coff[4] = {((0 * 2 + hi) ^ sw) * 16, ((1 * 2 + hi) ^ sw) * 16, ((2 * 2 + hi) ^ sw) * 16, ((3 * 2 + hi) ^ sw) * 16};
-
-    // fragments of one tile: K rows (A operand of S^T = K.Q^T) / V^T rows (A operand of O^T += V^T.P^T), [32-row block][k-step]
-#define ATTN_READ_FRAGS(F, base)                                                                       \
-    _Pragma("unroll") for (int blk = 0; blk < 2; ++blk)                                                \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                               \
-            F[blk][ks] = *(const bf16x8*)((base) + blk * 4096 + row_off + coff[ks]);
-    // iteration t: tile t+1 landed (counted wait + barrier); all LDS fragment reads of the iteration are issued up front
-    // (K of tile t+1, V^T of tile t), then S^T(t+1) = K.Q^T on the matrix pipe, the online softmax of S^T(t) on the
-    // VALU, and O^T += V^T(t).P^T(t).  The slot of tile t-1 is refilled by DMA.  Past the last tile S^T(t+1) is
-    // computed on a dummy slot and never used (no branch in the MFMA stream).
-#define ATTN_ITER(S_CUR, S_NXT, t)                                                                     \
-    {                                                                                                  \
-        if constexpr (AHEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 3) * 2) : "memory");    \
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 2) * 2) : "memory");                    \
-        __builtin_amdgcn_s_barrier();                                                                  \
-        bf16x8 kf_[2][4], vf_[2][4];                                                                   \
-        ATTN_READ_FRAGS(kf_, smem + (((t) + (AHEAD ? 1 : 0)) & (NSLOT - 1)) * SLOT_BYTES)              \
-        ATTN_READ_FRAGS(vf_, smem + ((t) & (NSLOT - 1)) * SLOT_BYTES + TILE_BYTES)                     \
-        ATTN_ISSUE_TILE()                                                                              \
-        /* the first k-step takes its C operand from cinit (all lanes' registers = -m_run, or 0): no per-tile init movs */ \
-        _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                               \
-            S_NXT[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf_[kb][0], qf[0], cinit, 0, 0, 0);    \
-        _Pragma("unroll") for (int ks = 1; ks < 4; ++ks)                                               \
-            _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                           \
-                S_NXT[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf_[kb][ks], qf[ks], S_NXT[kb], 0, 0, 0); \
-        if ((t) == nt - 1 && (p.S & (KV - 1)) != 0) { /* tail tile: keys >= S contribute nothing */    \
-            const int kv0_ = (t) * KV;                                                                 \
-            _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                           \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                       \
-                    const int key_ = kv0_ + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;                 \
-                    if (key_ >= p.S) S_CUR[kb][r] = -INFINITY;                                         \
-                }                                                                                      \
-        }                                                                                              \
-        float tmax_ = S_CUR[0][0];                                                                     \
-        _Pragma("unroll") for (int r = 1; r < 16; ++r) tmax_ = fmaxf(tmax_, S_CUR[0][r]);              \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) tmax_ = fmaxf(tmax_, S_CUR[1][r]);              \
-        tmax_ = max_with_partner_half(tmax_);                                                          \
-        float psum_ = 0.f;                                                                             \
-        if constexpr (FUSED) {                                                                         \
-            /* S_CUR already holds q.k - m_run (log2 units).  Move the max only when it grew past the threshold */ \
-            /* (always on the first tile): wave-uniform, and everything at the old max is rescaled exactly once. */ \
-            if ((t) == 0 || !__all(tmax_ <= RESCALE_THR)) {                                            \
-                const float d_ = (t) == 0 ? tmax_ : fmaxf(tmax_, 0.f);                                 \
-                const float alpha_ = fast_exp2(-d_);                                                   \
-                m_run += d_;                                                                           \
-                l_run *= alpha_;                                                                       \
-                _Pragma("unroll") for (int e = 0; e < 16; ++e) cinit[e] = -m_run;                      \
-                _Pragma("unroll") for (int i = 0; i < 2; ++i)                                          \
-                    _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                   \
-                        oT[i][e] *= alpha_;                                                            \
-                        S_CUR[i][e] -= d_;                                                             \
-                        if (AHEAD) S_NXT[i][e] -= d_;                                                  \
-                    }                                                                                  \
-            }                                                                                          \
-            _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                           \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                       \
-                    const float pv_ = fast_exp2(S_CUR[kb][r]);                                         \
-                    S_CUR[kb][r] = pv_;                                                                \
-                    psum_ += pv_;                                                                      \
-                }                                                                                      \
-        } else {                                                                                       \
-            if (!LAZY || !__all((tmax_ - m_run) * c <= RESCALE_THR)) {                                 \
-                const float m_new_ = fmaxf(m_run, tmax_);                                              \
-                const float alpha_ = fast_exp2((m_run - m_new_) * c);                                  \
-                m_run = m_new_;                                                                        \
-                l_run *= alpha_;                                                                       \
-                _Pragma("unroll") for (int i = 0; i < 2; ++i)                                          \
-                    _Pragma("unroll") for (int e = 0; e < 16; ++e) oT[i][e] *= alpha_;                 \
-            }                                                                                          \
-            const float mc_ = m_run * c;                                                               \
-            _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                           \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                       \
-                    const float pv_ = fast_exp2(fmaf(S_CUR[kb][r], c, -mc_));                          \
-                    S_CUR[kb][r] = pv_;                                                                \
-                    psum_ += pv_;                                                                      \
-                }                                                                                      \
-        }                                                                                              \
-        l_run += psum_;                                                                                \
-        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) { /* 16 keys per k-step; P frag = 8 consecutive acc regs */ \
-            union { bf16x8 v; uint32_t u[4]; } pf_;                                                    \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
-                pf_.u[i] = pack2bf(S_CUR[kk >> 1][(kk & 1) * 8 + 2 * i], S_CUR[kk >> 1][(kk & 1) * 8 + 2 * i + 1]); \
-            _Pragma("unroll") for (int db = 0; db < 2; ++db)                                           \
-                oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf_[db][kk], pf_.v, oT[db], 0, 0, 0); \
-        }                                                                                              \
-    }
-
-    f32x16 sA[2], sB[2];
-    f32x16 cinit;                  // C operand of each tile's first QK^T MFMA: -m_run (FUSED) or 0
-#pragma unroll
-    for (int e = 0; e < 16; ++e) cinit[e] = 0.f;
-#pragma unroll
-    for (int i = 0; i < NSLOT - 1; ++i) ATTN_ISSUE_TILE()
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 2) * 2) : "memory");
-    __builtin_amdgcn_s_barrier();
-    if constexpr (AHEAD) {
-        bf16x8 kf0[2][4];
-        ATTN_READ_FRAGS(kf0, smem)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) sA[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[kb][0], qf[0], cinit, 0, 0, 0);
-#pragma unroll
-        for (int ks = 1; ks < 4; ++ks)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-                sA[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[kb][ks], qf[ks], sA[kb], 0, 0, 0);
-    }
-    if constexpr (AHEAD) {
-        for (int t = 0; t < nt; t += 2) {
-            ATTN_ITER(sA, sB, t)
-            if (t + 1 < nt) ATTN_ITER(sB, sA, t + 1)
-        }
-    } else {
-        for (int t = 0; t < nt; ++t) ATTN_ITER(sA, sA, t)
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#undef ATTN_ISSUE_TILE
-#undef ATTN_READ_FRAGS
-#undef ATTN_ITER
-
-    // ---- epilogue: normalise, store O[q, h*64 + d] with d = db*32 + (r&3) + 8*(r>>2) + 4*hi ----
-    const float l_tot = sum_with_partner_half(l_run);
-    const float inv = 1.0f / l_tot;
-    const int q = q0 + l31;
-    if (q < p.S) {
-        bf16_t* op = p.out + (row0 + q) * p.ld_out + h * 64 + hi * 4;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                uint2 o;
-                o.x = pack2bf(oT[db][qd * 4 + 0] * inv, oT[db][qd * 4 + 1] * inv);
-                o.y = pack2bf(oT[db][qd * 4 + 2] * inv, oT[db][qd * 4 + 3] * inv);
-                *(uint2*)(op + db * 32 + qd * 8) = o;
-            }
-        if (p.lse && hi == 0)
-            p.lse[((long)b * p.H + h) * p.S + q] = FUSED ? (m_run + __log2f(l_tot)) * 0.6931471805599453f : m_run * p.scale + __logf(l_tot);
-    }
-}
-
-// Occupancy-first variant: 2-stage K/V buffer (32 KiB), fragments read just in time, <= 128 VGPRs so that TWO workgroups
-// (4 waves per SIMD) share a CU: with head_dim 64 the loop is VALU-issue bound (one v_exp/add/max/cvt per score against
-// 16 MFMAs per 2048 scores), and four waves per SIMD hide that better than deeper per-wave software pipelining.
+// 2-stage K/V buffer (32 KiB), fragments read just in time, <= 128 VGPRs so that TWO workgroups (4 waves per SIMD) share a
+// CU: with head_dim 64 the loop is VALU-issue bound (one v_exp/add/max/cvt per score against 16 MFMAs per 2048 scores), and
+// four waves per SIMD hide that better than deeper per-wave software pipelining (a 4-slot ring with QK one tile ahead and
+// all fragments up front measured 5-10 % slower and was removed).
 template <bool LAZY, bool FUSED>
 __global__ __launch_bounds__(512, 4) void attn_fwd_v1_kernel(const AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * SLOT_BYTES];
@@ -403,23 +208,8 @@ extern "C" int orv_attention_fwd(const void* qkv, int ld_qkv, const void* vT, vo
     dim3 grid(((S + 255) / 256) * H * B);
     // q pre-multiplied by scale*log2(e) in orv_qkv_prep (q_premul) arrives here as scale == 1/log2(e): fused fast path
     const bool fused = fabsf(a.scale_log2 - 1.0f) < 1e-6f;
-    static int variant = -1;   // ORV_ATTN_VARIANT: bit0 = lazy rescale, bit1 = QK one tile ahead (generic path A/B testing)
-    if (variant < 0) { const char* e = getenv("ORV_ATTN_VARIANT"); variant = e ? atoi(e) : 8; }
     hipStream_t st = (hipStream_t)stream;
-    if (variant & 8) {   // occupancy-first kernel (default)
-        if (fused) hipLaunchKernelGGL((attn_fwd_v1_kernel<true, true>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((attn_fwd_v1_kernel<true, false>), grid, dim3(512), 0, st, a);
-    } else if (fused) {
-        if (variant & 4) hipLaunchKernelGGL((attn_fwd_kernel<true, false, true, 4>), grid, dim3(512), 0, st, a);
-        else if (variant & 2) hipLaunchKernelGGL((attn_fwd_kernel<true, true, true>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((attn_fwd_kernel<true, false, true>), grid, dim3(512), 0, st, a);
-    } else {
-        switch (variant & 3) {
-            case 0: hipLaunchKernelGGL((attn_fwd_kernel<false, false, false>), grid, dim3(512), 0, st, a); break;
-            case 1: hipLaunchKernelGGL((attn_fwd_kernel<true, false, false>), grid, dim3(512), 0, st, a); break;
-            case 2: hipLaunchKernelGGL((attn_fwd_kernel<false, true, false>), grid, dim3(512), 0, st, a); break;
-            default: hipLaunchKernelGGL((attn_fwd_kernel<true, true, false>), grid, dim3(512), 0, st, a); break;
-        }
-    }
+    if (fused) hipLaunchKernelGGL((attn_fwd_v1_kernel<true, true>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((attn_fwd_v1_kernel<true, false>), grid, dim3(512), 0, st, a);
     return orv_check_launch("orv_attention_fwd");
 }

@@ -13,5 +13,5 @@ int main(int argc,char**argv){ int B=argc>1?atoi(argv[1]):4, S=3226, H=30; int s
   hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for(int i=0;i<3;i++) orv_attention_fwd(qkv,3*H*64,vT,out,H*64,nullptr,B,S,H,s_pad,sc,nullptr);
   hipEventRecord(e0); for(int i=0;i<20;i++) orv_attention_fwd(qkv,3*H*64,vT,out,H*64,nullptr,B,S,H,s_pad,sc,nullptr); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms,e0,e1); ms/=20;
-  printf("attention B=%d S=%d H=%d: %.4f ms  %.1f TFLOP/s (variant %s)\n",B,S,H,ms,4.0*B*H*(double)S*S*64/ms/1e9, getenv("ORV_ATTN_VARIANT")?getenv("ORV_ATTN_VARIANT"):"default");
+  printf("attention B=%d S=%d H=%d: %.4f ms  %.1f TFLOP/s\n",B,S,H,ms,4.0*B*H*(double)S*S*64/ms/1e9);
   return 0; }
