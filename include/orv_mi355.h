@@ -139,6 +139,7 @@ int orv_qkv_prep_from(const void* src, void* qkv, void* vT, const void* gq, cons
  * [n,D] table broadcast over the batch - the sincos pos-embedding - uses r_mod = n).
  * epilogue 3 (backward): C = acc * GELU'(R[out_row]) - the dgrad of FeedForward net.2 fused with the GELU adjoint
  * (R = saved pre-activation).  Epilogue 2 with gate NULL and R == C accumulates gradients in place.
+ * epilogue 4: the packed QKV projection with the qk LayerNorm fused (see the qn_* fields).
  * Output row remap: out_row = cmap(m) (scatter into the joint [B,S,D] sequence).  Constraints: K % 64 == 0, N % 64 == 0, 16-byte aligned rows. */
 typedef struct {
     const void* A; int lda;
@@ -151,6 +152,11 @@ typedef struct {
     const float* gate; long gate_b, gate_g; orv_groups_t grp;
     orv_rowmap_t cmap;
     void* Y; int ldy;   /* optional: also store acc + bias (before GELU / gate) at the same rows - saved for backward */
+    /* epilogue 4 only - the packed QKV projection [M, 3*heads*64] with the per-head LayerNorm(64, eps) of the q and k
+     * thirds (affine [64] bf16 or NULL) fused, q additionally multiplied by qn_premul, v stored as is; Y (if given)
+     * receives the raw projection.  Equivalent to epilogue 0 followed by orv_qkv_prep without RoPE, minus the V^T copy
+     * (use orv_head_transpose for that). */
+    const void *qn_gamma_q, *qn_beta_q, *qn_gamma_k, *qn_beta_k; float qn_eps, qn_premul; int qn_heads;
 } orv_gemm_t;
 int orv_gemm_bf16(const orv_gemm_t* g, void* stream);
 /* Kernel symbol (as rocprofv3 prints it, e.g. "gemm_pp_kernel<192, 5, 1>") that orv_gemm_bf16 launches for this shape on this

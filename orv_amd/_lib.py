@@ -24,7 +24,9 @@ class Gemm(Structure):
     _fields_ = [("A", c_void_p), ("lda", c_int), ("W", c_void_p), ("ldw", c_int), ("bias", c_void_p),
                 ("C", c_void_p), ("ldc", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("epilogue", c_int),
                 ("R", c_void_p), ("ldr", c_int), ("r_mod", c_int), ("gate", c_void_p), ("gate_b", c_long),
-                ("gate_g", c_long), ("grp", Groups), ("cmap", RowMap), ("Y", c_void_p), ("ldy", c_int)]
+                ("gate_g", c_long), ("grp", Groups), ("cmap", RowMap), ("Y", c_void_p), ("ldy", c_int),
+                ("qn_gamma_q", c_void_p), ("qn_beta_q", c_void_p), ("qn_gamma_k", c_void_p), ("qn_beta_k", c_void_p),
+                ("qn_eps", c_float), ("qn_premul", c_float), ("qn_heads", c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/orv_mi355.h declares

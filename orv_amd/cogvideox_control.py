@@ -525,6 +525,26 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             self._mv_ptr_tables = (key, arr([l.weight for l in lins]), arr([l.bias for l in lins]))
         return self._mv_ptr_tables[1:]
 
+    @staticmethod
+    def _qkv_projection(at, xn, qkv, vT, rope, B, S, heads, n_text, s_pad, scale, raw=None):
+        """to_q / to_k / to_v + norm_q / norm_k (+ RoPE) + V^T (:232-254): q', k', v into ``qkv``, V^T per head into ``vT``.
+        Without RoPE the qk LayerNorm and the softmax pre-multiplier (scale * log2 e, one rounding) ride in the GEMM epilogue
+        and only V is touched again (transpose); with RoPE the projection is followed by ``orv_qkv_prep``.  ``raw`` (training)
+        receives the un-normalised projection for the LayerNorm adjoint."""
+        D = heads * 64
+        M = B * S
+        wqkv, bqkv = at.packed_qkv()
+        nq, nk = at.norm_q, at.norm_k
+        if rope is None and _FUSE_QKNORM:
+            ops.gemm(xn, wqkv, bqkv, qkv, M, 3 * D, D, epilogue=4, Y=raw,
+                     qknorm=(nq.weight, nq.bias, nk.weight, nk.bias, at.eps, scale * LOG2E, heads))
+            ops.head_transpose(qkv, 2 * D, vT, B, S, heads, s_pad, ld=3 * D)
+        else:
+            dst = qkv if raw is None else raw
+            ops.gemm(xn, wqkv, bqkv, dst, M, 3 * D, D)
+            ops.qkv_prep(qkv, vT, nq.weight, nq.bias, nk.weight, nk.bias, rope, B, S, heads, n_text, s_pad, at.eps,
+                         q_premul=scale * LOG2E, src=raw)
+
     def _mv_block(self, blk, mv, m, x, xn, grp0, Bv, S, Nt, n_view, n_frame, rope_view=None):
         """MVBlock.forward (:313-348): AdaLN (no action term) -> tokens of all views of one frame attend jointly ->
         to_out, proj_out -> rearranged back and added with gate_msa.  m: this block's fp32 table [Bv, 2, 3D]."""
@@ -535,11 +555,8 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
                                2 * 3 * D, 3 * D, grp0, Bv, D, c.norm_eps)
         R, Sm, s_pad = mv["R"], mv["Sm"], mv["s_pad"]
         ops.gather_rows(xn, mv["idx"], mv["xm"], R, D)
-        wqkv, bqkv = at.packed_qkv()
-        ops.gemm(mv["xm"], wqkv, bqkv, mv["qkv"], R, 3 * D, D)
         scale = 1.0 / math.sqrt(c.attention_head_dim)
-        ops.qkv_prep(mv["qkv"], mv["vT"], at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, rope_view,
-                     R // Sm, Sm, heads, n_view * Nt, s_pad, at.eps, q_premul=scale * LOG2E)
+        self._qkv_projection(at, mv["xm"], mv["qkv"], mv["vT"], rope_view, R // Sm, Sm, heads, n_view * Nt, s_pad, scale)
         ops.attention_fwd(mv["qkv"], mv["vT"], mv["att"], R // Sm, Sm, heads, s_pad, 1.0 / LOG2E)
         ops.gemm(mv["att"], at.to_out[0].weight, at.to_out[0].bias, mv["xm"], R, D, D)
         ops.gemm(mv["xm"], blk.proj_out.weight, blk.proj_out.bias, mv["att"], R, D, D)
@@ -683,12 +700,7 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             at = blk.attn1
             ops.layernorm_modulate(x, xn, blk.norm1.norm.weight, blk.norm1.norm.bias, m1[..., D:2 * D], m1[..., :D],
                                    mb, mg, grp, B, D, c.norm_eps)
-            wqkv, bqkv = at.packed_qkv()
-            ops.gemm(xn, wqkv, bqkv, qkv, M, 3 * D, D)
-            nq, nk = at.norm_q, at.norm_k
-            # softmax scale and log2(e) are folded into q (one rounding) so the attention kernel's exp2 needs no multiply
-            ops.qkv_prep(qkv, vT, nq.weight, nq.bias, nk.weight, nk.bias, rope, B, S, heads, Nt, s_pad, at.eps,
-                         q_premul=scale * LOG2E)
+            self._qkv_projection(at, xn, qkv, vT, rope, B, S, heads, Nt, s_pad, scale)
             ops.attention_fwd(qkv, vT, att, B, S, heads, s_pad, 1.0 / LOG2E)
             ops.gemm(att, at.to_out[0].weight, at.to_out[0].bias, x, M, D, D, epilogue=2, R=x, ldr=D,
                      gate=m1[..., 2 * D:], gate_b=mb, gate_g=mg, grp=grp)
@@ -730,6 +742,9 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
 # ------------------------------------------------------------------------------------------------------------------
 # sampler pipeline (:1090-1489)
 # ------------------------------------------------------------------------------------------------------------------
+_FUSE_QKNORM = os.environ.get("ORV_FUSED_QKNORM", "1") != "0"      # A/B switch: 0 = projection + orv_qkv_prep
+
+
 class GraphedTransformer:
     """One denoise step's transformer forward replayed from a HIP graph (``torch.cuda.CUDAGraph`` over the library's
     launches on the capture stream): ~330 kernel launches become one submission, which matters when the step is short

@@ -42,6 +42,8 @@ struct GemmArgs {
     int seq, n_text, per_group;
     int c_rows, c_bstride, c_off;
     bf16_t* Y; long ldy;   // optional second output: the pre-epilogue value acc + bias (saved for backward)
+    // epilogue 4 (fused qk LayerNorm of the QKV projection): norm_q / norm_k affine [64], eps, q pre-multiplier, heads
+    const bf16_t *qn_gq, *qn_bq, *qn_gk, *qn_bk; float qn_eps, qn_premul; int qn_heads;
     int tiles_m, tiles_n;
     int dbg;  // ORV_GEMM_DBG: 1 = skip main-loop loads, 2 = skip MFMAs (ablation only)
 };
@@ -61,8 +63,122 @@ __device__ __forceinline__ void swap_halves(uint32_t& a, uint32_t& b) {
     a = r[0]; b = r[1];
 }
 
+__device__ __forceinline__ float sum_with_partner_half(float v) {   // v(lane) + v(lane ^ 32)
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// two register quads (this lane's 4 columns of column groups 2u and 2u+1) -> one aligned 16-byte piece per lane
+__device__ __forceinline__ void store_quads16(bf16_t* row, int n16, const float (&a)[4], const float (&b)[4]) {
+    uint32_t a0 = pack2bf(a[0], a[1]), a1 = pack2bf(a[2], a[3]), b0 = pack2bf(b[0], b[1]), b1 = pack2bf(b[2], b[3]);
+    swap_halves(a0, b0);
+    swap_halves(a1, b1);
+    *(uint4*)(row + n16) = make_uint4(a0, a1, b0, b1);
+}
+
+// Epilogue 4: the QKV projection with the per-head LayerNorm(64) of q and k (diffusers Attention.norm_q / norm_k as called
+// at cogvideox_control.py:243-247) and the softmax pre-multiplier of q applied in registers; the v third is stored as is.
+// A wave's BN/2 columns are whole heads of ONE of q | k | v (host-checked), a head is two adjacent 32-column blocks, and
+// a row's 64 values sit in this lane (32) and lane ^ 32 (32): the statistics are lane-local sums plus one half-wave swap.
+// Optional Y keeps acc + bias (the raw projection) for the LayerNorm adjoint.
+template <int NB, int MB>
+__device__ __forceinline__ void gemm_epilogue_qknorm(const GemmArgs& p, f32x16 (&acc)[NB][MB], int mbase, int nbase, int lane) {
+    static_assert(NB % 2 == 0, "a wave must cover whole 64-wide heads");
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int region = __builtin_amdgcn_readfirstlane(nbase / (p.qn_heads * 64));   // 0 = q, 1 = k, 2 = v
+    const bf16_t* gam = region == 0 ? p.qn_gq : p.qn_gk;
+    const bf16_t* bet = region == 0 ? p.qn_bq : p.qn_bk;
+    const float post = region == 0 ? p.qn_premul : 1.f;
+    // One head (two 32-column blocks of one row block) at a time, fenced with sched_barrier: the 192 accumulator registers
+    // leave no room for the scheduler to overlap heads (it did, and spilled ~700 registers).
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+        const int m = mbase + j * 32 + l31;
+        const bool valid = m < p.M;               // lane and lane ^ 32 hold the same row
+        bf16_t* crow = p.C + (long)min(m, p.M - 1) * p.ldc;
+        bf16_t* yrow = p.Y ? p.Y + (long)min(m, p.M - 1) * p.ldy : nullptr;
+#pragma unroll
+        for (int hh = 0; hh < NB / 2; ++hh) {
+            __builtin_amdgcn_sched_barrier(0);
+            float v[2][16];
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float bb[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (p.bias) {
+                        const int nq = __builtin_amdgcn_readfirstlane(nbase + (2 * hh + ii) * 32 + q * 8);
+                        const u32x4 b8 = *(const __attribute__((address_space(4))) u32x4*)(uintptr_t)(p.bias + nq);
+                        const uint32_t bx = hi ? b8[2] : b8[0], by = hi ? b8[3] : b8[1];
+                        bb[0] = bf2f(bx & 0xffff); bb[1] = bf2f(bx >> 16); bb[2] = bf2f(by & 0xffff); bb[3] = bf2f(by >> 16);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[ii][q * 4 + e] = acc[2 * hh + ii][j][q * 4 + e] + bb[e];
+                }
+            if (yrow) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        float a[4], b[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { a[e] = v[ii][(2 * u) * 4 + e]; b[e] = v[ii][(2 * u + 1) * 4 + e]; }
+                        if (valid) store_quads16(yrow, nbase + (2 * hh + ii) * 32 + (2 * u + hi) * 8, a, b);
+                    }
+            }
+            if (region < 2) {
+                float s = 0.f;
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s += v[ii][r];
+                const float mean = sum_with_partner_half(s) * (1.f / 64.f);
+                float sq = 0.f;
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { v[ii][r] -= mean; sq += v[ii][r] * v[ii][r]; }
+                const float rstd = rsqrtf(sum_with_partner_half(sq) * (1.f / 64.f) + p.qn_eps);
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float g[4] = {1.f, 1.f, 1.f, 1.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (gam) {
+                            const u32x4 g8 = *(const __attribute__((address_space(4))) u32x4*)(uintptr_t)(gam + ii * 32 + q * 8);
+                            const uint32_t gx = hi ? g8[2] : g8[0], gy = hi ? g8[3] : g8[1];
+                            g[0] = bf2f(gx & 0xffff); g[1] = bf2f(gx >> 16); g[2] = bf2f(gy & 0xffff); g[3] = bf2f(gy >> 16);
+                        }
+                        if (bet) {
+                            const u32x4 b8 = *(const __attribute__((address_space(4))) u32x4*)(uintptr_t)(bet + ii * 32 + q * 8);
+                            const uint32_t bx = hi ? b8[2] : b8[0], by = hi ? b8[3] : b8[1];
+                            bb[0] = bf2f(bx & 0xffff); bb[1] = bf2f(bx >> 16); bb[2] = bf2f(by & 0xffff); bb[3] = bf2f(by >> 16);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[ii][q * 4 + e] = (v[ii][q * 4 + e] * rstd * g[e] + bb[e]) * post;
+                    }
+            }
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float a[4], b[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { a[e] = v[ii][(2 * u) * 4 + e]; b[e] = v[ii][(2 * u + 1) * 4 + e]; }
+                    if (valid) store_quads16(crow, nbase + (2 * hh + ii) * 32 + (2 * u + hi) * 8, a, b);
+                }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int NB, int MB, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[NB][MB], int mbase, int nbase, int lane) {
+    if constexpr (EPI == 4) {
+        gemm_epilogue_qknorm<NB, MB>(p, acc, mbase, nbase, lane);
+        return;
+    }
     const int l31 = lane & 31, hi = lane >> 5;
 #pragma unroll
     for (int j = 0; j < MB; ++j) {
@@ -607,6 +723,17 @@ int launch_pp(const GemmArgs& a, int epi, hipStream_t st) {
         ORV_GEMM_CASE(1)
         ORV_GEMM_CASE(2)
         ORV_GEMM_CASE(3)
+        case 4:
+            if constexpr ((BN / 2) % 64 == 0) {
+                static bool attr_done4 = false;
+                if (!attr_done4) {
+                    (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<BN, NSLOT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+                    attr_done4 = true;
+                }
+                hipLaunchKernelGGL((gemm_pp_kernel<BN, NSLOT, 4>), dim3(grid), dim3(512), smem, st, a);
+                break;
+            }
+            [[fallthrough]];
         default: orv_set_error("orv_gemm_bf16: bad epilogue %d", epi); return ORV_EINVAL;
     }
 #undef ORV_GEMM_CASE
@@ -633,6 +760,17 @@ int launch(const GemmArgs& a, int epi, hipStream_t st) {
         ORV_GEMM_CASE(1)
         ORV_GEMM_CASE(2)
         ORV_GEMM_CASE(3)
+        case 4:
+            if constexpr ((BN / 2) % 64 == 0) {
+                static bool attr_done4 = false;
+                if (!attr_done4) {
+                    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+                    attr_done4 = true;
+                }
+                hipLaunchKernelGGL((gemm_kernel<BM, BN, 4>), dim3(grid), dim3(512), smem, st, a);
+                break;
+            }
+            [[fallthrough]];
         default: orv_set_error("orv_gemm_bf16: bad epilogue %d", epi); return ORV_EINVAL;
     }
 #undef ORV_GEMM_CASE
@@ -648,7 +786,7 @@ struct GemmCand { int ring, bm, bn; float rate; int min_rounds; };
 // and the cheapest wins.  The rates are measured on MI355X at M = 12904 (tools/tile_sweep.sh rates); the rounds term is
 // what matters at small batch, where a "better" tile that needs one more, nearly empty, round loses to a smaller one that
 // fills the chip (B = 1: N = 1920 GEMMs take 195 tiles of 256x128 instead of 260 of 128x192).
-static const GemmCand* choose_tile(int M, int N) {
+static const GemmCand* choose_tile(int M, int N, int epilogue = 0, int heads = 0) {
     static const GemmCand cands[] = {
         // 256x384 keeps ONE fragment set (192 accumulator registers) and leans on its neighbour tiles to hide the exposed
         // prologue / epilogue: measured +8 % on QKV (765 tiles), a loss when every CU gets a single tile (N = 1920: 255)
@@ -669,6 +807,8 @@ static const GemmCand* choose_tile(int M, int N) {
     double best_cost = 0;
     for (const GemmCand& c : cands) {
         if (N % c.bn) continue;
+        // epilogue 4 normalises whole 64-wide heads inside a wave (BN / 2 columns) that must not straddle q | k | v
+        if (epilogue == 4 && ((c.bn / 2) % 64 != 0 || (heads * 64) % (c.bn / 2) != 0)) continue;
         if (force_bm && (c.ring != force_ring || c.bm != force_bm || c.bn != force_bn)) continue;
         if (!force_bm && force_ring == 0 && c.ring) continue;
         const long tiles = (long)((M + c.bm - 1) / c.bm) * (N / c.bn);
@@ -689,7 +829,7 @@ static const GemmCand* choose_tile(int M, int N) {
 extern "C" int orv_gemm_kernel_name(int M, int N, int K, int epilogue, char* buf, int len) {
     (void)K;
     ORV_REQUIRE(buf && len > 0 && M > 0 && N > 0 && N % 64 == 0, "orv_gemm_kernel_name: bad arguments");
-    const GemmCand* c = choose_tile(M, N);
+    const GemmCand* c = choose_tile(M, N, epilogue, epilogue == 4 ? N / 192 : 0);
     ORV_REQUIRE(c, "orv_gemm_kernel_name: no tile configuration for N=%d", N);
     if (c->ring) snprintf(buf, len, "gemm_pp_kernel<%d, %d, %d>", c->bn, c->bn == 384 ? 4 : 5, epilogue);
     else snprintf(buf, len, "gemm_kernel<%d, %d, %d>", c->bm, c->bn, epilogue);
@@ -718,9 +858,15 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
     a.seq = g->grp.seq; a.n_text = g->grp.n_text; a.per_group = g->grp.per_group;
     a.c_rows = g->cmap.rows; a.c_bstride = g->cmap.bstride; a.c_off = g->cmap.off;
     a.Y = (bf16_t*)g->Y; a.ldy = g->ldy;
+    a.qn_gq = (const bf16_t*)g->qn_gamma_q; a.qn_bq = (const bf16_t*)g->qn_beta_q; a.qn_gk = (const bf16_t*)g->qn_gamma_k;
+    a.qn_bk = (const bf16_t*)g->qn_beta_k; a.qn_eps = g->qn_eps; a.qn_premul = g->qn_premul; a.qn_heads = g->qn_heads;
+    if (g->epilogue == 4) {
+        ORV_REQUIRE(g->qn_heads > 0 && g->N == 3 * g->qn_heads * 64, "orv_gemm_bf16: epilogue 4 needs N = 3 * heads * 64 (N=%d heads=%d)", g->N, g->qn_heads);
+        ORV_REQUIRE(g->cmap.rows == 0, "orv_gemm_bf16: epilogue 4 writes rows in place (no cmap)");
+    }
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("ORV_GEMM_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     hipStream_t st = (hipStream_t)stream;
-    const GemmCand* best = choose_tile(g->M, g->N);
+    const GemmCand* best = choose_tile(g->M, g->N, g->epilogue, g->qn_heads);
     ORV_REQUIRE(best, "orv_gemm_bf16: no tile configuration for N=%d (ORV_GEMM_TILE override?)", g->N);
     a.tiles_n = g->N / best->bn;
     a.tiles_m = (g->M + best->bm - 1) / best->bm;

@@ -167,9 +167,15 @@ def qkv_prep(qkv, vT, gq, bq, gk, bk, rope: Optional[Tuple[torch.Tensor, torch.T
 
 
 def gemm(A, W, bias, C, M, N, K, epilogue=0, R=None, r_mod=0, gate=None, gate_b=0, gate_g=0, grp: Optional[Groups] = None,
-         cmap: Optional[RowMap] = None, lda=None, ldw=None, ldc=None, ldr=None, Y=None, ldy=None):
+         cmap: Optional[RowMap] = None, lda=None, ldw=None, ldc=None, ldr=None, Y=None, ldy=None, qknorm=None):
+    """``qknorm`` = (gamma_q, beta_q, gamma_k, beta_k, eps, q_premul, heads) with ``epilogue=4``: the QKV projection with the
+    per-head qk LayerNorm fused (no RoPE)."""
     _need(A, BF16, "A"), _need(W, BF16, "W"), _need(C, BF16, "C")
     g = Gemm()
+    if qknorm is not None:
+        gq, bq, gk, bk, eps, premul, heads = qknorm
+        g.qn_gamma_q, g.qn_beta_q, g.qn_gamma_k, g.qn_beta_k = _p(gq), _p(bq), _p(gk), _p(bk)
+        g.qn_eps, g.qn_premul, g.qn_heads = float(eps), float(premul), int(heads)
     g.A, g.lda, g.W, g.ldw, g.bias = _p(A), lda or K, _p(W), ldw or K, _p(bias)
     g.C, g.ldc, g.M, g.N, g.K, g.epilogue = _p(C), ldc or N, M, N, K, epilogue
     g.R, g.ldr, g.r_mod = _p(R), ldr or N, r_mod

@@ -97,11 +97,9 @@ def _attn_forward(at, xn, ly, bufs, B_, S_, n_text, heads, rope, scale):
     D = heads * 64
     M_ = B_ * S_
     dev = xn.device
-    wqkv, bqkv = at.packed_qkv()
+    from .cogvideox_control import CogVideoXTransformer3DModelTraj as _M
     ly.qkv_raw = torch.empty(M_, 3 * D, dtype=BF16, device=dev)
-    ops.gemm(xn, wqkv, bqkv, ly.qkv_raw, M_, 3 * D, D)
-    ops.qkv_prep(bufs.work, bufs.vT, at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, rope, B_, S_, heads,
-                 n_text, bufs.s_pad, at.eps, q_premul=scale * LOG2E, src=ly.qkv_raw)
+    _M._qkv_projection(at, xn, bufs.work, bufs.vT, rope, B_, S_, heads, n_text, bufs.s_pad, scale, raw=ly.qkv_raw)
     ly.att = torch.empty(M_, D, dtype=BF16, device=dev)
     ly.lse = torch.empty(B_, heads, S_, dtype=torch.float32, device=dev)
     ops.attention_fwd(bufs.work, bufs.vT, ly.att, B_, S_, heads, bufs.s_pad, 1.0 / LOG2E, lse=ly.lse)

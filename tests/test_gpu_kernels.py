@@ -323,3 +323,35 @@ def test_gather_and_gated_scatter_rows():
     d = (x2.float() - ref.to(torch.bfloat16).float()).abs()
     assert (d > 0).float().mean().item() < 1e-3 and d.max().item() <= 2 ** -5
     assert torch.equal(x2[il[~vid]], x[il[~vid]])
+
+
+@pytest.mark.parametrize("M,H", [(300, 2), (3226, 30)])
+def test_qkv_gemm_with_fused_qk_layernorm(M, H):
+    """GEMM epilogue 4 (+ orv_head_transpose for V^T) against the unfused pair it replaces: epilogue 0 + orv_qkv_prep."""
+    from orv_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(M)
+    D = H * 64
+    B, S = 1, M
+    s_pad = (S + 63) // 64 * 64
+    x = torch.randn(M, D, generator=g).to(dev, torch.bfloat16)
+    W = (torch.randn(3 * D, D, generator=g) * 0.03).to(dev, torch.bfloat16)
+    bias = (torch.randn(3 * D, generator=g) * 0.1).to(dev, torch.bfloat16)
+    gq, bq, gk, bk = ((torch.randn(64, generator=g) * 0.2 + (1.0 if i % 2 == 0 else 0.0)).to(dev, torch.bfloat16) for i in range(4))
+    premul = 0.125 * 1.4426950408889634
+    ref = torch.empty(M, 3 * D, dtype=torch.bfloat16, device=dev)
+    ops.gemm(x, W, bias, ref, M, 3 * D, D)
+    raw = ref.clone()
+    vT_ref = torch.zeros(B, H, 64, s_pad, dtype=torch.bfloat16, device=dev)
+    ops.qkv_prep(ref, vT_ref, gq, bq, gk, bk, None, B, S, H, 0, s_pad, 1e-6, q_premul=premul)
+    out = torch.empty_like(ref)
+    y = torch.empty_like(ref)
+    ops.gemm(x, W, bias, out, M, 3 * D, D, epilogue=4, Y=y, qknorm=(gq, bq, gk, bk, 1e-6, premul, H))
+    vT = torch.zeros_like(vT_ref)
+    ops.head_transpose(out, 2 * D, vT, B, S, H, s_pad, ld=3 * D)
+    assert torch.equal(y, raw)                                   # Y = the raw projection, bit for bit
+    assert torch.equal(out[:, 2 * D:], ref[:, 2 * D:]) and torch.equal(vT, vT_ref)
+    # q / k: same arithmetic from the fp32 accumulator instead of the bf16-rounded projection -> bf16-level differences
+    d = (out[:, :2 * D].float() - ref[:, :2 * D].float()).abs()
+    scale = ref[:, :2 * D].float().abs().max().item()
+    assert d.max().item() <= 2e-2 * scale and d.mean().item() <= 2e-3 * scale
