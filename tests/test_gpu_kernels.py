@@ -355,3 +355,34 @@ def test_qkv_gemm_with_fused_qk_layernorm(M, H):
     d = (out[:, :2 * D].float() - ref[:, :2 * D].float()).abs()
     scale = ref[:, :2 * D].float().abs().max().item()
     assert d.max().item() <= 2e-2 * scale and d.mean().item() <= 2e-3 * scale
+
+
+@pytest.mark.parametrize("N,K,epi", [(5760, 1920, 0), (7680, 1920, 1), (1920, 7680, 2), (5760, 1920, 4)])
+def test_ring_gemm_is_deterministic_under_repetition(N, K, epi):
+    """Race screen for the persistent ring GEMM (counted vmcnt waits, DMA stream running across tile boundaries, epilogue
+    stores draining under the next tile): 25 back-to-back launches of the B=4 shapes must agree bit for bit, and with a
+    launch whose stores are forced to drain (ORV_GEMM_DBG=7 path is exercised separately by the partial last M tile)."""
+    from orv_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(N + K)
+    M = 12904
+    x = torch.randn(M, K, generator=g).to(dev, torch.bfloat16)
+    W = (torch.randn(N, K, generator=g) * 0.03).to(dev, torch.bfloat16)
+    bias = (torch.randn(N, generator=g) * 0.1).to(dev, torch.bfloat16)
+    R = torch.randn(M, N, generator=g).to(dev, torch.bfloat16) if epi == 2 else None
+    gate = torch.randn(4, 6, N, generator=g).to(dev) if epi == 2 else None
+    kw = {}
+    if epi == 2:
+        kw = dict(R=R, ldr=N, gate=gate, gate_b=6 * N, gate_g=N, grp=ops.groups(3226, 226, 600))
+    if epi == 4:
+        one = torch.ones(64, dtype=torch.bfloat16, device=dev)
+        kw = dict(qknorm=(one, None, one, None, 1e-6, 0.18, N // 192))
+    outs = []
+    for _ in range(25):
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        ops.gemm(x, W, bias, out, M, N, K, epilogue=epi, **kw)
+        outs.append(out)
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    assert torch.isfinite(outs[0].float()).all()
