@@ -57,6 +57,35 @@ class FusedAdamW:
             seg_start=torch.tensor(offs + [total], dtype=torch.int64, device=dev),
             active=torch.zeros(len(self.params), dtype=torch.uint8, device=dev), active_host=[False] * len(self.params))
 
+    # ---- data parallel: exchange overlapped with the backward ----
+    def begin_overlapped_allreduce(self):
+        """Returns ``hook(params, grads)`` for ``training.backward``: called whenever the gradients of a group of parameters
+        are final, it copies them into the flat buffer and lets a ``FlatGradReducer`` start summing every contiguous final
+        run over the process group while the backward continues.  ``step(average_over=world)`` then only sends the rest."""
+        from .sharding import FlatGradReducer
+        if self._flat is None:
+            self._build()
+        f = self._flat
+        index = {id(p): i for i, p in enumerate(self.params)}
+        red = FlatGradReducer(f["g"], f["seg_start"].tolist())
+        filled = set()
+
+        def hook(params, grads):
+            idx, srcs, dsts = [], [], []
+            for p in params:
+                i, g = index.get(id(p)), grads.get(id(p))
+                if i is None or g is None or i in filled:
+                    continue
+                idx.append(i); srcs.append(g); dsts.append(f["views_g"][i])
+            if not idx:
+                return
+            torch._foreach_copy_(dsts, srcs)
+            filled.update(idx)
+            red.ready(idx)
+
+        self._overlap = (red, filled)
+        return hook
+
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
             p.grad = None
@@ -74,16 +103,22 @@ class FusedAdamW:
         live = [p.grad is not None for p in self.params]
         if not any(live):
             return 0.0
-        srcs = [p.grad for p, a in zip(self.params, live) if a]
-        dsts = [v for v, a in zip(f["views_g"], live) if a]
-        torch._foreach_copy_(dsts, srcs)
+        overlap = getattr(self, "_overlap", None)
+        self._overlap = None
+        done = overlap[1] if overlap else ()
+        srcs = [p.grad for i, (p, a) in enumerate(zip(self.params, live)) if a and i not in done]
+        dsts = [v for i, (v, a) in enumerate(zip(f["views_g"], live)) if a and i not in done]
+        if srcs:
+            torch._foreach_copy_(dsts, srcs)
         if live != f["active_host"]:
             for v, was, now in zip(f["views_g"], f["active_host"], live):
                 if was and not now:
                     v.zero_()                            # stale gradient of a parameter that got none this step
             f["active"].copy_(torch.tensor(live, dtype=torch.uint8))
             f["active_host"] = live
-        if average_over and average_over > 1:
+        if overlap is not None:
+            overlap[0].finish()                          # the rest of the buffer, wait, average
+        elif average_over and average_over > 1:
             from .sharding import allreduce_flat_
             allreduce_flat_(f["g"], _AR_CHUNK)
         dev = f["p"].device

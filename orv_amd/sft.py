@@ -147,12 +147,17 @@ def sft_step(transformer, scheduler, optimizer, b: Batch, generator: Optional[to
     timesteps = torch.randint(0, scheduler.config.num_train_timesteps, (b.video_latents.shape[0],), dtype=torch.int64,
                               device=dev, generator=generator)                          # :1013-1019
     loss, parts = sft_loss(transformer, scheduler, b, noise, timesteps, use_rope, is_ofs_embed)
-    loss.backward()
     world = 1
     if data_parallel:
         import torch.distributed as dist
         world = dist.get_world_size()
-    grad_norm = optimizer.step(average_over=world)       # gradients are averaged inside, on the flat buffer
+    if world > 1:        # the exchange starts inside the backward, block by block (sharding.FlatGradReducer)
+        transformer._dp_grad_hook = optimizer.begin_overlapped_allreduce()
+    try:
+        loss.backward()
+    finally:
+        transformer._dp_grad_hook = None
+    grad_norm = optimizer.step(average_over=world)       # finishes the exchange, averages, clips, updates
     optimizer.zero_grad()
     parts["grad_norm"] = grad_norm
     return loss.detach(), parts

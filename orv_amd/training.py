@@ -396,8 +396,10 @@ def _gelu_tanh_grad(u):
     return 0.5 * (1 + th) + 0.5 * u * (1 - th * th) * a_ * (1 + 3 * b_ * u * u)
 
 
-def backward(model, sv, dout, drecon=None) -> Dict[int, torch.Tensor]:
-    """Gradients of every trainable parameter (bf16, keyed by id(param)) given dL/d(sample) (and dL/d(actions_recon))."""
+def backward(model, sv, dout, drecon=None, grad_hook=None) -> Dict[int, torch.Tensor]:
+    """Gradients of every trainable parameter (bf16, keyed by id(param)) given dL/d(sample) (and dL/d(actions_recon)).
+    ``grad_hook(params, grads)`` is called as soon as the gradients of a group of parameters are final (data-parallel
+    exchange overlapped with the rest of the backward, ``FusedAdamW.begin_overlapped_allreduce``)."""
     c = model.config
     d = sv.dims
     B, T, Hh, Ww, D, heads, E = d["B"], d["T"], d["Hh"], d["Ww"], d["D"], d["heads"], d["E"]
@@ -516,6 +518,9 @@ def backward(model, sv, dout, drecon=None) -> Dict[int, torch.Tensor]:
                                    dm1[..., D:2 * D], dm1[..., :D], dg, db_, mb, mg, grp, B, D, c.norm_eps)
         f32_to_param_grad(blk.norm1.norm.weight, dg), f32_to_param_grad(blk.norm1.norm.bias, db_)
         dx = dx0
+        if grad_hook is not None:       # everything of this block but its two AdaLN linears (their tables close at the end)
+            grad_hook(list(at.parameters()) + list(blk.ff.parameters()) + list(blk.norm1.norm.parameters())
+                      + list(blk.norm2.norm.parameters()), grads)
         if mv is not None:
             # MVBlock adjoint: x_out[idx[r]] = x_in[idx[r]] + gate[view] * y[r] on the video rows (text output dropped)
             mblk, mly, m = model.mv_blocks[i], mv.layers[i], mv.mod[i]
@@ -732,7 +737,8 @@ class DiTFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _dmask, drecon):
         with torch.no_grad():
-            grads = backward(ctx.model, ctx.sv, dout.contiguous(), drecon if ctx.sv.has_recon else None)
+            grads = backward(ctx.model, ctx.sv, dout.contiguous(), drecon if ctx.sv.has_recon else None,
+                             grad_hook=getattr(ctx.model, "_dp_grad_hook", None))
         ctx.sv = None
         outs = []
         for p_ in ctx.params:

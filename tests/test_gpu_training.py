@@ -225,3 +225,34 @@ def test_sft_batch_and_loss_match_oracle():
         assert abs(got.item() - ref.item()) <= 3e-2 * abs(ref.item()) + 1e-3
     loss.backward()
     assert m.action_recon.mlp[2].weight.grad is not None and m.transformer_blocks[0].ff.net[2].weight.grad is not None
+
+
+def test_overlapped_gradient_exchange_hook_changes_nothing():
+    """The data-parallel overlap path (gradients copied into the flat buffer block by block from inside the backward,
+    FlatGradReducer bookkeeping; world size 1 here, the collectives themselves are covered by the gloo test) must leave the
+    optimizer step bit-identical to the plain path."""
+    from orv_amd.cogvideox_control import CogVideoXTransformer3DModelTraj
+    from orv_amd.optim import FusedAdamW
+    dev = torch.device("cuda:0")
+    cfg, extra, ins, w, outs = load_golden("fwd_actions")
+    wout = torch.randn(outs["sample"].shape, generator=torch.Generator().manual_seed(1)).to(dev)
+    results = []
+    for use_hook in (False, True):
+        m = CogVideoXTransformer3DModelTraj(**cfg)
+        m.load_state_dict(w)
+        m = m.to(dev, BF).train()
+        m.action_embed.forced_mask = torch.tensor(extra["mask"])
+        opt = FusedAdamW(m.parameters(), lr=1e-2, betas=(0.9, 0.95), weight_decay=1e-3, max_grad_norm=1.0)
+        out = m(ins["hidden_states"].to(dev, BF), ins["encoder_hidden_states"].to(dev, BF), {"actions": ins["actions"].to(dev)},
+                ins["timestep"].to(dev), return_dict=False)[0]
+        if use_hook:
+            m._dp_grad_hook = opt.begin_overlapped_allreduce()
+        (out.float() * wout).sum().backward()
+        m._dp_grad_hook = None
+        if use_hook:
+            red, filled = opt._overlap
+            assert len(filled) > 20 and all(red.ready_flag[i] for i in filled)
+        opt.step(average_over=1)
+        results.append({k: v.detach().clone() for k, v in m.state_dict().items()})
+    for k in results[0]:
+        assert torch.equal(results[0][k], results[1][k]), k

@@ -64,8 +64,18 @@ def _dp_worker(rank, world, port, out):
     from orv_amd.sharding import allreduce_flat_
     flat = torch.arange(10000, dtype=torch.float32) * (rank + 1)
     nf = allreduce_flat_(flat, chunk_elems=4096)
+    # overlap form: segments become final out of order (as the backward walks the layers), runs are coalesced
+    from orv_amd.sharding import FlatGradReducer
+    starts = [0, 100, 1000, 1300, 5000, 5004, 9000, 10000]
+    buf = torch.arange(10000, dtype=torch.float32) * (rank + 1)
+    red = FlatGradReducer(buf, starts, min_elems=900, max_elems=3000)
+    red.ready([5])                 # 3996 elements: sent at once (2 pieces)
+    red.ready([1])                 # exactly 900: sent
+    red.ready([3])                 # 3700 elements: sent (2 pieces)
+    red.ready([2])                 # 300 < min and its neighbours are already sent: waits for finish
+    nr = red.finish()
     if rank == 0:
-        out.put((n, [p.grad.clone() for p in params], frozen.grad, nf, flat))
+        out.put((n, [p.grad.clone() for p in params], frozen.grad, nf, flat, nr, buf))
     dist.destroy_process_group()
 
 
@@ -76,7 +86,7 @@ def test_two_rank_gradient_allreduce():
     port = _free_port()
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     [p.start() for p in procs]
-    n, grads, frozen_grad, nf, flat = q.get(timeout=120)
+    n, grads, frozen_grad, nf, flat, nr, buf = q.get(timeout=120)
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     assert n >= 2 and frozen_grad is None                               # 300000 floats alone exceed the 1 MiB bucket
@@ -84,3 +94,4 @@ def test_two_rank_gradient_allreduce():
     for g, w in zip(grads, want):
         assert torch.allclose(g, torch.full_like(g, w))
     assert nf == 3 and torch.allclose(flat, torch.arange(10000, dtype=torch.float32) * 1.5)
+    assert nr == 2 + 1 + 2 + 4 and torch.allclose(buf, torch.arange(10000, dtype=torch.float32) * 1.5)
