@@ -5,6 +5,8 @@ Tolerances: bit-exact for index work (patchify/unpatchify); bf1
 """
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -128,7 +130,8 @@ LOG2E = 1.4426950408889634
 
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("B,S,H,nt,use_rope", [(2, 200, 2, 8, False), (1, 3226, 3, 226, False), (2, 333, 2, 13, True),
-                                                (1, 64, 1, 0, False), (1, 257, 2, 1, True)])
+                                                (1, 64, 1, 0, False), (1, 257, 2, 1, True), (3, 100, 5, 4, False),
+                                                (1, 17, 1, 0, False), (2, 700, 7, 30, True)])
 def test_qkv_prep_and_attention(B, S, H, nt, use_rope, fused):
     """fused: softmax scale * log2(e) folded into q by orv_qkv_prep (q_premul) -> the attention kernel's exp2 fast path."""
     from orv_amd import ops
@@ -386,3 +389,35 @@ def test_ring_gemm_is_deterministic_under_repetition(N, K, epi):
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
     assert torch.isfinite(outs[0].float()).all()
+
+
+def test_gemm_shape_fuzz_against_torch():
+    """Random (M, N, K, epilogue) over everything the tile chooser can pick (ring 384/256/192/128, simple kernel, one tile to many
+    rounds, K = 64 ... 4096, ragged M) against torch fp32 on the GPU; tolerance = bf16 output rounding + K-length accumulation."""
+    from orv_amd import ops
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(7)
+    g = torch.Generator(device=dev).manual_seed(7)
+    cases = [(1, 64, 64, 0), (255, 192, 64, 1), (257, 384, 128, 2), (4097, 768, 64, 0), (12904, 384, 64, 0), (70000, 64, 192, 1)]
+    for _ in range(34):
+        M = int(rng.choice([1, 7, 63, 64, 65, 127, 129, 300, 511, 1000, 2049, 3226, 5000, 9999, 12904, 20000]))
+        N = int(rng.choice([64, 128, 192, 256, 320, 384, 640, 768, 1152, 1536, 1920, 3072, 5760]))
+        K = int(rng.choice([64, 128, 192, 320, 512, 1024, 1920, 4096]))
+        cases.append((M, N, K, int(rng.integers(0, 3))))
+    for M, N, K, epi in cases:
+        A = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
+        W = (torch.randn(N, K, device=dev, generator=g) * (1.0 / K ** 0.5)).to(torch.bfloat16)
+        bias = torch.randn(N, device=dev, generator=g).to(torch.bfloat16)
+        ref = A.float() @ W.float().t() + bias.float()
+        kw = {}
+        if epi == 1:
+            ref = torch.nn.functional.gelu(ref, approximate="tanh")
+        if epi == 2:
+            R = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16)
+            ref = R.float() + ref
+            kw = dict(R=R, ldr=N)
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.gemm(A, W, bias, out, M, N, K, epilogue=epi, **kw)
+        err = (out.float() - ref).abs()
+        tol = 1.6e-2 * ref.abs() + 2e-2
+        assert bool((err <= tol).all()), (M, N, K, epi, err.max().item())
