@@ -208,7 +208,8 @@ int orv_adamw_flat(void* p, const void* g, float* m, float* v, long n, const lon
 int orv_sumsq(const void* g, long n, float* out, void* stream);
 
 /* src[B*S, ld] columns [col0 + h*64, +64) -> dst[b,h,d,pos(s)] per head (pos = s with bits 2<->3 exchanged, zero for
- * s >= S): the sequence-contiguous copies (q'^T, k^T, dO^T) the attention backward contracts over. */
+ * s >= S): the forward's V^T when the qk LayerNorm rides in the QKV GEMM (epilogue 4), and the sequence-contiguous copies
+ * (q'^T, k^T, dO^T) the attention backward contracts over. */
 int orv_head_transpose(const void* src, int ld, int col0, void* dst, int B, int S, int H, int s_pad, void* stream);
 /* Adjoint of orv_attention_fwd on the fused path (q pre-multiplied by scale*log2 e in orv_qkv_prep): given out, dout and
  * the saved lse, writes dqkv[B*S, ld_dqkv] = (dq | dk | dv) w.r.t. the normalised, un-premultiplied q, k and v.
@@ -225,7 +226,7 @@ int orv_qkv_prep_bwd(const void* qkv_raw, void* dqkv, const void* gq, const void
 /* -- attention -------------------------------------------------------------------------------- */
 /* Non-causal, unmasked softmax(q k^T * scale) v over the joint text+video sequence, head_dim 64
  * (F.scaled_dot_product_attention at cogvideox_control.py:256-258).  q,k are read in place from the packed qkv
- * buffer [B*S, ld_qkv] (q at column h*64, k at column H*64 + h*64); vT [B,H,64,s_pad] from orv_qkv_prep;
+ * buffer [B*S, ld_qkv] (q at column h*64, k at column H*64 + h*64); vT [B,H,64,s_pad] from orv_qkv_prep / orv_head_transpose;
  * out [B*S, H*64] bf16 (heads merged as :260); lse fp32 [B,H,S] or NULL (log-sum-exp, natural log, for backward). */
 int orv_attention_fwd(const void* qkv, int ld_qkv, const void* vT, void* out, int ld_out, float* lse, int B, int S,
                       int H, int s_pad, float scale, void* stream);
