@@ -801,10 +801,22 @@ class CogVideoXImageToVideoPipelineTraj:
         self.invert_scale_latents = bool(getattr(vcfg, "invert_scale_latents", False)) if vcfg is not None else False
         self._guidance_scale, self._interrupt, self._num_timesteps = 1.0, False, 0
         self._graphed: Optional[GraphedTransformer] = None
+        self.video_processor = None        # a caller with diffusers may attach VideoProcessor(vae_scale_factor=...) here
 
     guidance_scale = property(lambda self: self._guidance_scale)
     interrupt = property(lambda self: self._interrupt)
     num_timesteps = property(lambda self: self._num_timesteps)
+
+    def decode_latents(self, latents: torch.Tensor) -> torch.Tensor:
+        """Hands the latents to the CALLER-SUPPLIED VAE exactly as the base diffusers pipeline does (``[B,F,C,h,w] ->
+        [B,C,F,h,w]``, divided by the VAE scaling factor, ``vae.decode(...).sample``; the arithmetic of the decode itself is
+        the VAE object's, SURVEY §8f rank 1, out of scope here)."""
+        if self.vae is None:
+            raise NotImplementedError("VAE decode is a SURVEY §8(f) next row: pass a `vae` object (e.g. diffusers' "
+                                      "AutoencoderKLCogVideoX) or use output_type='latent'")
+        z = latents.permute(0, 2, 1, 3, 4) / self.vae_scaling_factor_image
+        out = self.vae.decode(z)
+        return getattr(out, "sample", out)
 
     def enable_hip_graph(self, enabled: bool = True):
         """Replay the transformer forward of each denoise step from a HIP graph (see ``GraphedTransformer``)."""
@@ -961,11 +973,14 @@ class CogVideoXImageToVideoPipelineTraj:
                 prompt_embeds = cb.pop("prompt_embeds", prompt_embeds)
         b, vf = latents.shape[:2]
         latents = latents.reshape(b * num_views, vf // num_views, *latents.shape[2:])
-        if output_type != "latent":
-            raise NotImplementedError("VAE decode is a SURVEY §8(f) next row: use output_type='latent'")
+        video = latents
+        if output_type != "latent":                                                  # :1477-1479
+            video = self.decode_latents(latents)
+            if self.video_processor is not None:
+                video = self.video_processor.postprocess_video(video=video, output_type=output_type)
         if not return_dict:
-            return (latents,)
-        return CogVideoXPipelineOutput(frames=latents)
+            return (video,)
+        return CogVideoXPipelineOutput(frames=video)
 
 
 def _randn(shape, generator, device, dtype):

@@ -181,3 +181,39 @@ def test_hip_graph_replay_is_bit_identical():
                    controls_or_guidances={"actions": ins["actions"].to(dev)})
         res.append(out.frames.clone())
     assert torch.equal(res[0], res[1])
+
+
+def test_pipeline_hands_latents_to_a_caller_supplied_vae():
+    """output_type != 'latent': the latents go to the caller's VAE object in the base pipeline's layout / scaling; without one
+    the call fails loudly (no decode is implemented here)."""
+    from orv_amd import schedulers
+    from orv_amd.cogvideox_control import CogVideoXImageToVideoPipelineTraj
+    dev = torch.device("cuda:0")
+    cfg, extra, ins, w, outs = load_golden("pipe_ddim")
+    m = build(cfg, w, dev)
+    b = ins["image"].shape[0]
+    m.action_embed.forced_mask = torch.zeros(b, dtype=torch.bool)
+
+    class FakeVAE:
+        config = type("C", (), {"block_out_channels": [1, 2, 3, 4], "temporal_compression_ratio": 4, "scaling_factor": 2.0})()
+        seen = None
+
+        def decode(self, z):
+            FakeVAE.seen = z
+            return type("O", (), {"sample": z * 3})()
+
+    kw = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+              prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=3.0, timestep_spacing="trailing")
+    g = torch.Generator().manual_seed(3)
+    image_lat = torch.randn(b, 16, 1, 8, 12, generator=g).to(dev, BF)
+    lat0 = torch.randn(b, 3, 16, 8, 12, generator=g).to(dev, BF)
+    args = dict(image=image_lat, height=64, width=96, num_frames=9, num_inference_steps=2, guidance_scale=1.0,
+                prompt_embeds=ins["prompt_embeds"].to(dev, BF), controls_or_guidances={"actions": ins["actions"].to(dev)})
+    pipe = CogVideoXImageToVideoPipelineTraj(transformer=m, scheduler=schedulers.CogVideoXDDIMScheduler(**kw), vae=FakeVAE())
+    lat = pipe(latents=lat0.clone(), output_type="latent", **args).frames
+    vid = pipe(latents=lat0.clone(), output_type="pt", **args).frames
+    assert FakeVAE.seen.shape == (b, 16, 3, 8, 12)
+    assert torch.allclose(vid.float(), lat.permute(0, 2, 1, 3, 4).float() / 2.0 * 3, atol=1e-2)
+    bare = CogVideoXImageToVideoPipelineTraj(transformer=m, scheduler=schedulers.CogVideoXDDIMScheduler(**kw))
+    with pytest.raises(NotImplementedError, match="VAE decode"):
+        bare(latents=lat0.clone(), output_type="pt", **args)

@@ -75,7 +75,9 @@ def _dp_worker(rank, world, port, out):
     red.ready([2])                 # 300 < min and its neighbours are already sent: waits for finish
     nr = red.finish()
     if rank == 0:
-        out.put((n, [p.grad.clone() for p in params], frozen.grad, nf, flat, nr, buf))
+        # numpy copies, not tensors: a tensor travels as a shared-memory fd that dies with this process (flaky FileNotFoundError)
+        out.put((n, [p.grad.numpy().copy() for p in params], None if frozen.grad is None else 1, nf, flat.numpy().copy(), nr,
+                 buf.numpy().copy()))
     dist.destroy_process_group()
 
 
@@ -87,6 +89,7 @@ def test_two_rank_gradient_allreduce():
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     [p.start() for p in procs]
     n, grads, frozen_grad, nf, flat, nr, buf = q.get(timeout=120)
+    grads, flat, buf = [torch.from_numpy(g) for g in grads], torch.from_numpy(flat), torch.from_numpy(buf)
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     assert n >= 2 and frozen_grad is None                               # 300000 floats alone exceed the 1 MiB bucket
