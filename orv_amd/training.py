@@ -86,7 +86,6 @@ class _AttnBufs:
     def __init__(self, B_, S_, heads, dev):
         self.s_pad = (S_ + 63) // 64 * 64
         z = lambda: torch.zeros(B_, heads, 64, self.s_pad, dtype=BF16, device=dev)
-        self.work = torch.empty(B_ * S_, 3 * heads * 64, dtype=BF16, device=dev)
         self.vT, self.qT, self.kT, self.doT = z(), z(), z(), z()
         self.nl = torch.empty(B_, heads, self.s_pad, dtype=torch.float32, device=dev)
         self.nd = torch.empty(B_, heads, self.s_pad, dtype=torch.float32, device=dev)
@@ -98,11 +97,12 @@ def _attn_forward(at, xn, ly, bufs, B_, S_, n_text, heads, rope, scale):
     M_ = B_ * S_
     dev = xn.device
     from .cogvideox_control import CogVideoXTransformer3DModelTraj as _M
-    ly.qkv_raw = torch.empty(M_, 3 * D, dtype=BF16, device=dev)
-    _M._qkv_projection(at, xn, bufs.work, bufs.vT, rope, B_, S_, heads, n_text, bufs.s_pad, scale, raw=ly.qkv_raw)
+    ly.qkv_raw = torch.empty(M_, 3 * D, dtype=BF16, device=dev)       # raw projection: input of the qk-LayerNorm adjoint
+    ly.qkvn = torch.empty(M_, 3 * D, dtype=BF16, device=dev)          # q' | k' | v as the attention kernels read them (kept:
+    _M._qkv_projection(at, xn, ly.qkvn, bufs.vT, rope, B_, S_, heads, n_text, bufs.s_pad, scale, raw=ly.qkv_raw)   # 148 MB/layer)
     ly.att = torch.empty(M_, D, dtype=BF16, device=dev)
     ly.lse = torch.empty(B_, heads, S_, dtype=torch.float32, device=dev)
-    ops.attention_fwd(bufs.work, bufs.vT, ly.att, B_, S_, heads, bufs.s_pad, 1.0 / LOG2E, lse=ly.lse)
+    ops.attention_fwd(ly.qkvn, bufs.vT, ly.att, B_, S_, heads, bufs.s_pad, 1.0 / LOG2E, lse=ly.lse)
 
 
 def _attn_backward(at, ly, xn, datt, bufs, B_, S_, n_text, heads, rope, scale, grads, f32_to_param_grad):
@@ -111,13 +111,11 @@ def _attn_backward(at, ly, xn, datt, bufs, B_, S_, n_text, heads, rope, scale, g
     M_ = B_ * S_
     dev = xn.device
     z32 = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
-    ops.qkv_prep(bufs.work, bufs.vT, at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, rope, B_, S_, heads,
-                 n_text, bufs.s_pad, at.eps, q_premul=scale * LOG2E, src=ly.qkv_raw)
-    ops.head_transpose(bufs.work, 0, bufs.qT, B_, S_, heads, bufs.s_pad, ld=3 * D)
-    ops.head_transpose(bufs.work, D, bufs.kT, B_, S_, heads, bufs.s_pad, ld=3 * D)
+    ops.head_transpose(ly.qkvn, 0, bufs.qT, B_, S_, heads, bufs.s_pad, ld=3 * D)
+    ops.head_transpose(ly.qkvn, D, bufs.kT, B_, S_, heads, bufs.s_pad, ld=3 * D)
     ops.head_transpose(datt, 0, bufs.doT, B_, S_, heads, bufs.s_pad, ld=D)
     dqkv = torch.empty(M_, 3 * D, dtype=BF16, device=dev)
-    ops.attention_bwd(bufs.work, bufs.qT, bufs.kT, ly.att, datt, bufs.doT, ly.lse, bufs.nl, bufs.nd, dqkv, B_, S_, heads,
+    ops.attention_bwd(ly.qkvn, bufs.qT, bufs.kT, ly.att, datt, bufs.doT, ly.lse, bufs.nl, bufs.nd, dqkv, B_, S_, heads,
                       bufs.s_pad, scale)
     dgq, dbq, dgk, dbk = z32(64), z32(64), z32(64), z32(64)
     ops.qkv_prep_bwd(ly.qkv_raw, dqkv, at.norm_q.weight, at.norm_k.weight, rope, dgq, dbq, dgk, dbk, B_, S_, heads, n_text,
