@@ -105,12 +105,11 @@ def _attn_forward(at, xn, ly, bufs, B_, S_, n_text, heads, rope, scale):
     ops.attention_fwd(ly.qkvn, bufs.vT, ly.att, B_, S_, heads, bufs.s_pad, 1.0 / LOG2E, lse=ly.lse)
 
 
-def _attn_backward(at, ly, xn, datt, bufs, B_, S_, n_text, heads, rope, scale, grads, f32_to_param_grad):
+def _attn_backward(at, ly, xn, datt, bufs, B_, S_, n_text, heads, rope, scale, grads, f32_to_param_grad, z32):
     """Adjoint of ``_attn_forward``: datt [M, D] -> gradient w.r.t. xn [M, D]; parameter gradients into ``grads``."""
     D = heads * 64
     M_ = B_ * S_
     dev = xn.device
-    z32 = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
     ops.head_transpose(ly.qkvn, 0, bufs.qT, B_, S_, heads, bufs.s_pad, ld=3 * D)
     ops.head_transpose(ly.qkvn, D, bufs.kT, B_, S_, heads, bufs.s_pad, ld=3 * D)
     ops.head_transpose(datt, 0, bufs.doT, B_, S_, heads, bufs.s_pad, ld=D)
@@ -407,8 +406,23 @@ def backward(model, sv, dout, drecon=None, grad_hook=None) -> Dict[int, torch.Te
     p, pt = c.patch_size, c.patch_size_t
     grads: Dict[int, torch.Tensor] = {}
     e = lambda *shape, dt=BF16: torch.empty(*shape, dtype=dt, device=dev)
-    z32 = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
     L = c.num_layers
+    # fp32 accumulators (norm / bias gradients, tables, ...) come out of ONE zero-filled arena: one memset instead of ~400
+    # tiny fills per step, and the gradients that live in it are converted to bf16 with ONE cast at the end
+    arena = torch.zeros(2 * L * B * G * 3 * D + B * G * 2 * D + (L + 4) * 64 * 1024, dtype=torch.float32, device=dev)
+    arena_ptr = [0]
+    pending = []          # (param, arena offset, numel)
+
+    def z32(*shape):
+        n = 1
+        for k in shape:
+            n *= int(k)
+        a = (arena_ptr[0] + 63) // 64 * 64
+        if a + n > arena.numel():
+            return torch.zeros(*shape, dtype=torch.float32, device=dev)
+        arena_ptr[0] = a + n
+        return arena[a:a + n].view(*shape)
+
     dmod = z32(2 * L, B, G, 3 * D)
     dmodf = z32(B, G, 2 * D)
     grp = ops.groups(S, Nt, per_group)
@@ -418,6 +432,9 @@ def backward(model, sv, dout, drecon=None, grad_hook=None) -> Dict[int, torch.Te
 
     def f32_to_param_grad(param, g32):
         if param is None or not param.requires_grad:
+            return
+        if g32.is_contiguous() and g32.untyped_storage().data_ptr() == arena.untyped_storage().data_ptr():
+            pending.append((param, g32.storage_offset(), g32.numel()))      # converted with the rest of the arena at the end
             return
         g = g32.to(BF16).view(param.shape)
         if id(param) in grads:
@@ -509,7 +526,7 @@ def backward(model, sv, dout, drecon=None, grad_hook=None) -> Dict[int, torch.Te
         bias_p(wo.bias, dy1, M, D)
         datt = e(M, D)
         _dgrad(dy1, wo.weight, datt, M, D, D)
-        dxn1 = _attn_backward(at, ly, ly.xn1, datt, bufs, B, S, Nt, heads, sv.rope, scale, grads, f32_to_param_grad)
+        dxn1 = _attn_backward(at, ly, ly.xn1, datt, bufs, B, S, Nt, heads, sv.rope, scale, grads, f32_to_param_grad, z32)
         dx0 = e(M, D)
         dg, db_ = z32(D), z32(D)
         ops.layernorm_modulate_bwd(dxn1, ly.x0, dx1, dx0, blk.norm1.norm.weight, blk.norm1.norm.bias, m1[..., D:2 * D],
@@ -543,7 +560,7 @@ def backward(model, sv, dout, drecon=None, grad_hook=None) -> Dict[int, torch.Te
             datt = e(mv.R, D)
             _dgrad(dao, wo.weight, datt, mv.R, D, D)
             dxm_n = _attn_backward(mblk.attn1, mly, mly.xm, datt, mv.bufs, mv.Bm, mv.Sm, mv.n_text, heads, sv.rope_view, scale,
-                                   grads, f32_to_param_grad)
+                                   grads, f32_to_param_grad, z32)
             # gather^T: video rows are a bijection (scatter), text rows were replicated over the f frames (sum)
             dxn = torch.zeros(M, D, dtype=BF16, device=dev)
             ops.scatter_gated_rows(dxm_n, mv.idx, ones_gate, D, dxn, mv.R, D, S, Nt)
@@ -709,6 +726,14 @@ def backward(model, sv, dout, drecon=None, grad_hook=None) -> Dict[int, torch.Te
         rows_o = sv.o_emb.shape[0]
         d_o = d_temb if rows_o == d_temb.shape[0] else d_temb.sum(0, keepdim=True)
         mlp2_bwd(model.ofs_embedding, d_o, sv.oe_h1, sv.oe_u1, sv.o_emb)
+    if pending:
+        a16 = arena[:arena_ptr[0]].to(BF16)
+        for param, off, n in pending:
+            g = a16[off:off + n].view(param.shape)
+            if id(param) in grads:
+                grads[id(param)].add_(g)
+            else:
+                grads[id(param)] = g
     return grads
 
 

@@ -251,7 +251,7 @@ def test_overlapped_gradient_exchange_hook_changes_nothing():
         m._dp_grad_hook = None
         if use_hook:
             red, filled = opt._overlap
-            assert len(filled) > 20 and all(red.ready_flag[i] for i in filled)
+            assert len(filled) >= 12 and all(red.ready_flag[i] for i in filled)   # the 6 big weights of each block
         opt.step(average_over=1)
         results.append(opt._flat["g"].clone())
     # the same gradients reach the flat buffer on both paths (fp32 atomics in a few bias / table sums make single runs differ in
