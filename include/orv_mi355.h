@@ -186,7 +186,7 @@ int orv_layernorm_modulate_bwd(const void* dy, const void* x, orv_rowmap_t xmap,
  * dtab fp32 [n_tab, B, 1+T, width] (d out); cond_v bf16 [B*T, E] = SiLU(temb + action_emb) rows, cond_t bf16 [B, E] =
  * SiLU(temb); W device array of n_tab weight pointers as in the forward.  Writes gW bf16 [n_tab, width*(1+text), E]
  * and gb fp32 [n_tab, width*(1+text)] (overwritten), accumulates d_cond_v fp32 [B*T, E] / d_cond_t fp32 [B, E].
- * B*T <= 32. */
+ * Rows are processed 32 at a time (one pass over the weights up to B*T = 32). */
 int orv_modulation_tables_bwd(const float* dtab, const void* cond_v, const void* cond_t, const void* const* W, void* gW,
                               float* gb, float* d_cond_v, float* d_cond_t, int n_tab, int B, int T, int E, int width,
                               int text, void* stream);

@@ -459,43 +459,48 @@ __global__ __launch_bounds__(256) void mod_bwd_dgrad_kernel(const ModBwdArgs p) 
     const int rows = half ? p.B : p.B * p.T;
     const int kk = threadIdx.x & 63, ph = threadIdx.x >> 6, k = blockIdx.x * 64 + kk;
     const bf16_t* W = p.W[tab] + (long)(half ? p.width : 0) * E;
-    float acc[32];
+    for (int r0 = 0; r0 < rows; r0 += 32) {                 // 32 rows per pass (one pass up to B*T = 32; W is re-streamed beyond)
+        const int rr = min(32, rows - r0);
+        float acc[32];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) acc[j] = 0.f;
-    for (int n0 = 0; n0 < p.width; n0 += 128) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < 128 * 32; i += 256) {
-            const int r = i >> 7, nl = i & 127;              // consecutive threads -> consecutive n (coalesced dtab rows)
-            float d = 0.f;
-            if (r < rows && n0 + nl < p.width) {
-                const int b = half ? r : r / p.T, g = half ? 0 : 1 + r % p.T;
-                d = p.dtab[(((long)tab * p.B + b) * G + g) * p.width + n0 + nl];
+        for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+        for (int n0 = 0; n0 < p.width; n0 += 128) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < 128 * 32; i += 256) {
+                const int r = i >> 7, nl = i & 127;          // consecutive threads -> consecutive n (coalesced dtab rows)
+                float d = 0.f;
+                if (r < rr && n0 + nl < p.width) {
+                    const int row = r0 + r;
+                    const int b = half ? row : row / p.T, g = half ? 0 : 1 + row % p.T;
+                    d = p.dtab[(((long)tab * p.B + b) * G + g) * p.width + n0 + nl];
+                }
+                dys[nl][r] = d;
             }
-            dys[nl][r] = d;
-        }
-        __syncthreads();
-        if (k < E) {
-            const int nend = min(128, p.width - n0);
-            for (int nl = ph; nl < nend; nl += 4) {
-                const float w = bf2f(W[(long)(n0 + nl) * E + k]);
+            __syncthreads();
+            if (k < E) {
+                const int nend = min(128, p.width - n0);
+                for (int nl = ph; nl < nend; nl += 4) {
+                    const float w = bf2f(W[(long)(n0 + nl) * E + k]);
 #pragma unroll
-                for (int j = 0; j < 32; j += 4) {
-                    const float4 d4 = *(const float4*)&dys[nl][j];
-                    acc[j] = fmaf(d4.x, w, acc[j]); acc[j + 1] = fmaf(d4.y, w, acc[j + 1]);
-                    acc[j + 2] = fmaf(d4.z, w, acc[j + 2]); acc[j + 3] = fmaf(d4.w, w, acc[j + 3]);
+                    for (int j = 0; j < 32; j += 4) {
+                        const float4 d4 = *(const float4*)&dys[nl][j];
+                        acc[j] = fmaf(d4.x, w, acc[j]); acc[j + 1] = fmaf(d4.y, w, acc[j + 1]);
+                        acc[j + 2] = fmaf(d4.z, w, acc[j + 2]); acc[j + 3] = fmaf(d4.w, w, acc[j + 3]);
+                    }
                 }
             }
         }
-    }
-    if (ph > 0)
+        __syncthreads();
+        if (ph > 0)
 #pragma unroll
-        for (int j = 0; j < 32; ++j) red[ph - 1][j][kk] = acc[j];
-    __syncthreads();
-    if (ph == 0 && k < E) {
-        float* dx = half ? p.d_cond_t : p.d_cond_v;
+            for (int j = 0; j < 32; ++j) red[ph - 1][j][kk] = acc[j];
+        __syncthreads();
+        if (ph == 0 && k < E) {
+            float* dx = half ? p.d_cond_t : p.d_cond_v;
 #pragma unroll
-        for (int j = 0; j < 32; ++j)
-            if (j < rows) atomicAdd(dx + (long)j * E + k, acc[j] + red[0][j][kk] + red[1][j][kk] + red[2][j][kk]);
+            for (int j = 0; j < 32; ++j)
+                if (j < rr) atomicAdd(dx + (long)(r0 + j) * E + k, acc[j] + red[0][j][kk] + red[1][j][kk] + red[2][j][kk]);
+        }
     }
 }
 
@@ -691,8 +696,8 @@ extern "C" int orv_modulation_tables_bwd(const float* dtab, const void* cond_v, 
                                          int width, int text, void* stream) {
     ORV_REQUIRE(dtab && cond_v && W && gW && gb && d_cond_v, "orv_modulation_tables_bwd: null operand");
     ORV_REQUIRE(!text || (cond_t && d_cond_t), "orv_modulation_tables_bwd: text rows need cond_t / d_cond_t");
-    ORV_REQUIRE(n_tab > 0 && B > 0 && T > 0 && B * T <= 32 && E % 64 == 0 && width % 8 == 0,
-                "orv_modulation_tables_bwd: unsupported shape (B*T=%d must be <= 32, E=%d %% 64, width=%d %% 8)", B * T, E, width);
+    ORV_REQUIRE(n_tab > 0 && B > 0 && T > 0 && B * T <= 4096 && E % 64 == 0 && width % 8 == 0,
+                "orv_modulation_tables_bwd: unsupported shape (B*T=%d, E=%d %% 64, width=%d %% 8)", B * T, E, width);
     ModBwdArgs a{dtab, (const bf16_t*)cond_v, (const bf16_t*)cond_t, (const bf16_t* const*)W, (bf16_t*)gW, gb, d_cond_v, d_cond_t,
                  n_tab, B, T, E, width, text ? 1 : 0};
     hipStream_t st = (hipStream_t)stream;

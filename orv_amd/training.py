@@ -623,23 +623,8 @@ def backward(model, sv, dout, drecon=None, grad_hook=None) -> Dict[int, torch.Te
     cond_t = torch.nn.functional.silu(temb32).to(BF16).contiguous()
     d_cond_v, d_cond_t = z32(B * Ta, E), z32(B, E)
 
-    def table_bwd(lin, dtab, width, text, cv=cond_v, dcv=d_cond_v, rows_v=B * Ta):
-        dv = dtab[:, 1:].reshape(rows_v, width).contiguous()
-        train_w = lin.weight.requires_grad
-        gw = _acc_grad(grads, lin.weight) if train_w else torch.zeros_like(lin.weight, dtype=BF16)
-        gb32 = z32(lin.weight.shape[0])
-        ops.small_linear_bwd(dv, cv, lin.weight[:width], gw[:width], gb32[:width], dcv, rows_v, width, E)
-        if text:
-            dt = dtab[:, 0].contiguous()
-            ops.small_linear_bwd(dt, cond_t, lin.weight[width:], gw[width:], gb32[width:], d_cond_t, B, width, E)
-        f32_to_param_grad(lin.bias, gb32)
-
     def tables_bwd(lins, dtab, w_ptrs, width, text, cv, dcv, T_):
-        """Adjoint of one ``ops.modulation_tables`` call: all its AdaLN linears in two launches (B*T <= 32), else per table."""
-        if B * T_ > 32:
-            for i, lin in enumerate(lins):
-                table_bwd(lin, dtab[i], width, text, cv=cv, dcv=dcv, rows_v=B * T_)
-            return
+        """Adjoint of one ``ops.modulation_tables`` call: all its AdaLN linears in two launches."""
         gW, gb = ops.modulation_tables_bwd(dtab, cv, cond_t, w_ptrs, dcv, d_cond_t, len(lins), B, T_, E, width, text)
         gb16 = gb.to(BF16)
         for i, lin in enumerate(lins):

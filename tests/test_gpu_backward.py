@@ -226,3 +226,37 @@ def test_fused_adamw_flat_matches_torch_adamw():
         close(p.detach().float().cpu(), r.detach().cpu(), rtol=2e-2, afrac=1e-2)       # bf16 parameter storage
     w, b = at.packed_qkv()
     assert torch.equal(w, torch.cat([at.to_q.weight, at.to_k.weight, at.to_v.weight]).detach())
+
+
+@pytest.mark.parametrize("B,T,text", [(2, 3, True), (9, 5, True), (4, 1, False)])
+def test_modulation_tables_bwd_matches_torch(B, T, text):
+    """orv_modulation_tables_bwd (all AdaLN linears of a backward in two launches, incl. more than 32 conditioning rows)
+    against torch autograd of the same linears."""
+    from orv_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(B * 10 + T)
+    n_tab, E, width = 3, 64, 96
+    ntot = width * (2 if text else 1)
+    Ws = [q(torch.randn(ntot, E, generator=g) * 0.2) for _ in range(n_tab)]
+    cond_v, cond_t = q(torch.randn(B * T, E, generator=g)), q(torch.randn(B, E, generator=g))
+    dtab = torch.randn(n_tab, B, 1 + T, width, generator=g)
+    Wd = [w.to(dev, BF) for w in Ws]
+    ptrs = torch.tensor([w.data_ptr() for w in Wd], dtype=torch.int64, device=dev)
+    dcv = torch.zeros(B * T, E, device=dev)
+    dct = torch.zeros(B, E, device=dev)
+    gW, gb = ops.modulation_tables_bwd(dtab.to(dev), cond_v.to(dev, BF), cond_t.to(dev, BF), ptrs, dcv, dct, n_tab, B, T, E, width,
+                                       text)
+    ref_dcv, ref_dct = torch.zeros(B * T, E), torch.zeros(B, E)
+    for t in range(n_tab):
+        dv = dtab[t][:, 1:].reshape(B * T, width)
+        close(gW[t][:width].float().cpu(), dv.t() @ cond_v, rtol=2e-2, afrac=1e-2)
+        close(gb[t][:width].cpu(), dv.sum(0), rtol=1e-4, afrac=1e-5)
+        ref_dcv += dv @ Ws[t][:width]
+        if text:
+            dt = dtab[t][:, 0]
+            close(gW[t][width:].float().cpu(), dt.t() @ cond_t, rtol=2e-2, afrac=1e-2)
+            close(gb[t][width:].cpu(), dt.sum(0), rtol=1e-4, afrac=1e-5)
+            ref_dct += dt @ Ws[t][width:]
+    close(dcv.cpu(), ref_dcv, rtol=1e-3, afrac=1e-4)
+    if text:
+        close(dct.cpu(), ref_dct, rtol=1e-3, afrac=1e-4)
