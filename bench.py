@@ -188,8 +188,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
+        backend = os.environ.get("ORV_DIST_BACKEND", "nccl")     # "gloo": functional test of the N > 1 path on ONE GPU (ranks share it)
+        if backend != "nccl":
+            local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))      # RCCL; only used for barrier/max
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL; only used for barrier/max
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
