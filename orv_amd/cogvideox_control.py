@@ -771,6 +771,8 @@ class GraphedTransformer:
                 st["out"] = self.tr(hidden_states=st["x"], encoder_hidden_states=encoder_hidden_states, timestep=st["t"],
                                     **kw)
             st["graph"] = g
+            st["ws"] = self.tr._ws      # the captured launches point into this workspace: keep it alive even if the model
+            #                             later swaps in another one for a different shape
         st["x"].copy_(hidden_states)
         st["t"].copy_(timestep)
         st["graph"].replay()
