@@ -756,7 +756,8 @@ class GraphedTransformer:
         self._state = {}
 
     def __call__(self, hidden_states, encoder_hidden_states, timestep, **kw):
-        key = (tuple(hidden_states.shape), tuple(encoder_hidden_states.shape), encoder_hidden_states.data_ptr())
+        key = (tuple(hidden_states.shape), tuple(encoder_hidden_states.shape), encoder_hidden_states.data_ptr(),
+               _state.weights_epoch[0])      # fused optimizer steps invalidate captured weight pointers
         st = self._state.get(key)
         if st is None:                       # eager warm-up call
             self._state[key] = {"calls": 1}
