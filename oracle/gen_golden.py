@@ -93,22 +93,28 @@ def forward_case(cc, utils, name, cfg_over, b=2, t=3, n_act=8, mask=(False, Fals
     _save(name, full_cfg, tensors, dict(ofs=ofs, num_views=num_views, training=training, mask=list(mask)))
 
 
-def pipeline_case(cc, name, sched_cls, steps=3, guidance=1.0, seed=1234, with_actions=True):
+def pipeline_case(cc, name, sched_cls, steps=3, guidance=1.0, seed=1234, with_actions=True, dtype=torch.float32,
+                  dynamic_cfg=False):
+    """ORV's own ``CogVideoXImageToVideoPipelineTraj.__call__`` (prepare_latents + denoise loop) on a tiny model.
+    ``dtype=torch.bfloat16`` runs the reference the way its entry points do (inference_control_to_video.py:31,95): every
+    ``randn_tensor`` draw (image-latent sample, initial latents, the DPM noise) then consumes the CPU generator in bf16,
+    which is what the product does, so those fixtures can be replayed with ``generator=`` instead of pre-drawn tensors."""
     from . import leaf
     torch.manual_seed(seed)
     cfg = {**TINY, "sample_frames": 9}
     model = cc.CogVideoXTransformer3DModelTraj(**cfg)
     _randomize_zero_init(model)
     model.eval()
+    model.to(dtype)
     sched = sched_cls(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
                       clip_sample=False, set_alpha_to_one=True, prediction_type="v_prediction",
                       rescale_betas_zero_snr=True, snr_shift_scale=3.0, timestep_spacing="trailing")
     pipe = ref_harness.make_pipeline(cc, model, sched)
     b, h, w = 2, 8, 12
-    image = _q(torch.randn(b, 32, 1, h, w))         # un-sampled moments of the reference frame [B, 2C, F, H, W]
-    e = _q(torch.randn(b, 8, 96))
-    ne = _q(torch.randn(b, 8, 96))
-    actions = _q(torch.randn(b, 8, 7))
+    image = _q(torch.randn(b, 32, 1, h, w)).to(dtype)   # un-sampled moments of the reference frame [B, 2C, F, H, W]
+    e = _q(torch.randn(b, 8, 96)).to(dtype)
+    ne = _q(torch.randn(b, 8, 96)).to(dtype)
+    actions = _q(torch.randn(b, 8, 7)).to(dtype)
     gen = torch.Generator().manual_seed(4321)
     trace = []
 
@@ -120,18 +126,31 @@ def pipeline_case(cc, name, sched_cls, steps=3, guidance=1.0, seed=1234, with_ac
     # so guidance_scale > 1 only runs without action controls.
     with ref_harness.forced_action_mask([False] * b):
         out = pipe(image=image, prompt=None, negative_prompt=None, height=h * 8, width=w * 8, num_frames=9,
-                   num_inference_steps=steps, guidance_scale=guidance, generator=gen, prompt_embeds=e,
+                   num_inference_steps=steps, guidance_scale=guidance, use_dynamic_cfg=dynamic_cfg, generator=gen,
+                   prompt_embeds=e,
                    negative_prompt_embeds=ne if guidance > 1 else None, output_type="latent",
                    controls_or_guidances={"actions": actions} if with_actions else {}, callback_on_step_end=cb)
-    tensors = {"in.image": image, "in.prompt_embeds": e, "in.negative_prompt_embeds": ne, "in.actions": actions,
-               "out.latents": out.frames}
+    tensors = {"in.image": image.float(), "in.prompt_embeds": e.float(), "in.negative_prompt_embeds": ne.float(),
+               "in.actions": actions.float(), "out.latents": out.frames.float()}
     for i, tr in enumerate(trace):
-        tensors[f"out.step{i}"] = tr
+        tensors[f"out.step{i}"] = tr.float()
     for k, v in model.state_dict().items():
-        tensors["w." + k] = v
+        tensors["w." + k] = v.float()
     full_cfg = {k: v for k, v in dict(model.config).items() if k != "kwargs"}
     _save(name, full_cfg, tensors, dict(steps=steps, guidance=guidance, gen_seed=4321, scheduler=sched_cls.__name__,
-                                         with_actions=with_actions))
+                                         with_actions=with_actions, dtype=str(dtype).replace("torch.", ""),
+                                         dynamic_cfg=dynamic_cfg, final_guidance=float(pipe.guidance_scale)))
+
+
+def pipeline_bf16_cases(cc):
+    """The reference pipeline as its entry points run it (bf16 end to end, CPU generator): DPM (the scheduler both
+    entry points install, inference_control_to_video.py:91), DDIM, and the dynamic-CFG branch (:1436-1443)."""
+    from . import leaf
+    bf = torch.bfloat16
+    pipeline_case(cc, "pipe_dpm_bf16", leaf.CogVideoXDPMScheduler, steps=4, dtype=bf)
+    pipeline_case(cc, "pipe_ddim_bf16", leaf.CogVideoXDDIMScheduler, dtype=bf)
+    pipeline_case(cc, "pipe_dpm_dyncfg_bf16", leaf.CogVideoXDPMScheduler, steps=4, guidance=3.0, with_actions=False, dtype=bf,
+                  dynamic_cfg=True)
 
 
 def misc_case(cc, comp, utils):
@@ -188,6 +207,8 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "collate":      # add the data-format fixtures without touching the others
         return collate_case()
     cc, comp, utils = ref_harness.load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "pipe_bf16":    # round-2 additions only
+        return pipeline_bf16_cases(cc)
     forward_case(cc, utils, "fwd_actions", {})
     forward_case(cc, utils, "fwd_actions_masked", {}, mask=(True, False))
     forward_case(cc, utils, "fwd_cond", {"visual_guidance": True}, cond=True)
@@ -205,6 +226,7 @@ def main():
     pipeline_case(cc, "pipe_dpm", __import__("oracle.leaf", fromlist=["x"]).CogVideoXDPMScheduler)
     pipeline_case(cc, "pipe_ddim_cfg", __import__("oracle.leaf", fromlist=["x"]).CogVideoXDDIMScheduler, guidance=3.0,
                   with_actions=False)
+    pipeline_bf16_cases(cc)
     misc_case(cc, comp, utils)
     collate_case()
 

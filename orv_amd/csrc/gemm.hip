@@ -703,6 +703,237 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmArgs p) {
     else gemm_ring_body<BN, NSLOT, EPI, NP_G1, (BN > 256)>(p, smem, wave, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Phased kernel (BM = 256, BK = 64, persistent): the 8-phase schedule (4 phases per K-tile, two K-tiles per loop trip).
+//   * 8 waves as 4 (M) x 2 (N); a wave owns 64 rows x BN/2 columns = 2 x NB blocks of 32x32 (C^T accumulators, as above).
+//     The two halves of the workgroup (waves 0-3 | 4-7: the two waves of every SIMD) run ONE barrier apart, so on each SIMD
+//     one wave is in a load segment (ds_read + LDS-DMA issue) while its partner is in an MFMA segment.
+//   * LDS: 2 stages x [A 256 rows | W BN rows] x 128 B (BK = 64: full 128-byte lines through the DMA path), XOR-swizzled
+//     like gemm_kernel.  Every operand tile is stored as two HALF-tiles that are also the unit of consumption: A half h
+//     holds m-block h of all four M-waves, W half h holds n-half h (NB/2 blocks) of both N-waves, so a half-tile is dead
+//     for the current K-tile as soon as its one phase has read it.  Phase order (m0,n0) (m1,n0) (m1,n1) (m0,n1):
+//         P1  read A0 (4 ds_read_b128), W0 (2 NB) | DMA W1 of K-tile g+1 | MFMA (m0,n0)
+//         P2  read A1                             | DMA A0 of K-tile g+2 | MFMA (m1,n0)
+//         P3  read W1                             | DMA W0 of K-tile g+2 | MFMA (m1,n1)
+//         P4  -                                   | DMA A1 of K-tile g+2 | MFMA (m0,n1)   + the ONE counted vmcnt per K-tile
+//     (A0 stays in registers for P4).  A half-tile is re-staged two phases after its last read (A0: one phase, its reads are
+//     retired by a counted lgkmcnt before P1's first barrier); the vmcnt in P4 leaves the three youngest half-tiles in
+//     flight and proves K-tile g+1 complete one barrier before its first read.
+//   * The DMA stream is continuous across the output tiles of the persistent workgroup (each half-tile keeps its own
+//     (output tile, K-tile) cursor), so the next tile's first two K-tiles land under the epilogue; past the last tile the
+//     stream re-fetches it into dead half-tiles (uniform counts, no tail case).
+// ---------------------------------------------------------------------------------------------------------------
+template <int BN, int EPI>
+__global__ __launch_bounds__(512) void gemm_ph_kernel(const GemmArgs p) {
+    constexpr int BM = 256, MB = 2, NB = BN / 64, NBH = NB / 2;
+    constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+    constexpr int APH = 2, BPH = BN / 128;     // DMA pieces (8 rows x 128 B) per wave per half-tile
+    constexpr int HB = BN / 2, QB = BN / 4;    // W rows per half-tile / per N-wave inside a half-tile
+    static_assert(NB % 2 == 0 && QB % 32 == 0 && NBH * 4 <= 15, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2, wq = wave & 3;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int nk = p.K / BK;                   // even (host-checked)
+
+    // ---- DMA side: four half-tile streams, each with its own cursor ----
+    const bf16_t *sA0[APH], *sA1[APH], *sB0[BPH], *sB1[BPH];
+    int kA0 = 0, kA1 = 0, kB0 = 0, kB1 = 0;
+    int tA0 = blockIdx.x, tA1 = blockIdx.x, tB0 = blockIdx.x, tB1 = blockIdx.x;
+#ifdef ORV_PH_ABLATE_NODMA      /* ablation builds (tools/ph_abl.sh): separate compilations, never a run-time branch */
+#define ORV_PH_GLDS(G, L) asm volatile("" ::"v"(G));
+#else
+#define ORV_PH_GLDS(G, L) glds16(G, L);
+#endif
+#ifdef ORV_PH_ABLATE_NOMFMA
+#define ORV_PH_ONE_MFMA(B_, A_, C_) asm volatile("" ::"v"(B_), "v"(A_));
+#else
+#define ORV_PH_ONE_MFMA(B_, A_, C_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B_, A_, C_, 0, 0, 0);
+#endif
+#define ORV_PH_SETUP_A(H, ARR, TILE)                                                                                 \
+    {                                                                                                                \
+        int tm_, tn_;                                                                                                \
+        tile_of_index(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                                                 \
+        _Pragma("unroll") for (int i = 0; i < APH; ++i) {                                                            \
+            const int r = (H) * 128 + (wave + 8 * i) * 8 + (lane >> 3);       /* LDS row of the A region */          \
+            const int trow = ((r >> 5) & 3) * 64 + (H) * 32 + (r & 31);       /* tile row it holds */                \
+            const int chunk = (lane & 7) ^ ((r >> 1) & 7);                                                           \
+            ARR[i] = p.A + (long)min(tm_ * BM + trow, p.M - 1) * p.lda + chunk * 8;                                  \
+        }                                                                                                            \
+    }
+#define ORV_PH_SETUP_B(H, ARR, TILE)                                                                                 \
+    {                                                                                                                \
+        int tm_, tn_;                                                                                                \
+        tile_of_index(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                                                 \
+        _Pragma("unroll") for (int i = 0; i < BPH; ++i) {                                                            \
+            const int q = (wave + 8 * i) * 8 + (lane >> 3);                   /* row inside the half-tile */         \
+            const int r = (H) * HB + q;                                       /* LDS row of the W region */          \
+            const int tcol = (q / QB) * (BN / 2) + (H) * QB + q % QB;         /* tile column it holds */             \
+            const int chunk = (lane & 7) ^ ((r >> 1) & 7);                                                           \
+            ARR[i] = p.W + (long)(tn_ * BN + tcol) * p.ldw + chunk * 8;                                              \
+        }                                                                                                            \
+    }
+#define ORV_PH_ISSUE_A(H, ARR, KC, TC, S)                                                                            \
+    {                                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < APH; ++i)                                                              \
+            ORV_PH_GLDS(ARR[i] + (long)KC * BK, smem + (S) * STAGE + ((H) * 128 + (wave + 8 * i) * 8) * 128);        \
+        if (++KC == nk) { KC = 0; TC += gridDim.x; ORV_PH_SETUP_A(H, ARR, TC) }                                      \
+    }
+#define ORV_PH_ISSUE_B(H, ARR, KC, TC, S)                                                                            \
+    {                                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < BPH; ++i)                                                              \
+            ORV_PH_GLDS(ARR[i] + (long)KC * BK, smem + (S) * STAGE + A_BYTES + ((H) * HB + (wave + 8 * i) * 8) * 128); \
+        if (++KC == nk) { KC = 0; TC += gridDim.x; ORV_PH_SETUP_B(H, ARR, TC) }                                      \
+    }
+    ORV_PH_SETUP_A(0, sA0, tA0)
+    ORV_PH_SETUP_A(1, sA1, tA1)
+    ORV_PH_SETUP_B(0, sB0, tB0)
+    ORV_PH_SETUP_B(1, sB1, tB1)
+
+    // ---- fragment addressing: byte = row * 128 + ((2 ks + hi) ^ sw) * 16 ----
+    const int l31 = lane & 31, hi = lane >> 5, sw = (l31 >> 1) & 7;
+    int coff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) coff[ks] = ((ks * 2 + hi) ^ sw) * 16;
+    const int a_off = (wq * 32 + l31) * 128;                      // + h * 128 rows
+    const int b_off = A_BYTES + (grp * QB + l31) * 128;           // + nh * HB rows + ii * 32 rows
+
+    f32x16 acc[NB][MB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < MB; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    bf16x8 fa0[4], fa1[4], fb0[NBH][4], fb1[NBH][4];
+
+#define ORV_PH_READ_A(H, FA, S)                                                                                      \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                 \
+        FA[ks] = *(const bf16x8*)(smem + (S) * STAGE + (H) * 128 * 128 + a_off + coff[ks]);
+#define ORV_PH_READ_B(H, FB, S)                                                                                      \
+    _Pragma("unroll") for (int ii = 0; ii < NBH; ++ii)                                                               \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                             \
+            FB[ii][ks] = *(const bf16x8*)(smem + (S) * STAGE + ((H) * HB + ii * 32) * 128 + b_off + coff[ks]);
+#define ORV_PH_MFMA(J, NH, FA, FB)                                                                                   \
+    __builtin_amdgcn_s_setprio(1);                                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                 \
+        _Pragma("unroll") for (int ii = 0; ii < NBH; ++ii) { ORV_PH_ONE_MFMA(FB[ii][ks], FA[ks], acc[(NH) * NBH + ii][J]) } \
+    __builtin_amdgcn_s_setprio(0);
+#define ORV_PH_BAR()                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    __builtin_amdgcn_s_barrier();                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);
+    // one K-tile out of stage S (compile-time); the DMA issues target stage S ^ 1 (W1 of the next K-tile) and stage S
+#define ORV_PH_KTILE(S)                                                                                              \
+    {                                                                                                                \
+        /* P1 */                                                                                                     \
+        ORV_PH_READ_A(0, fa0, S)                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        ORV_PH_READ_B(0, fb0, S)                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        ORV_PH_ISSUE_B(1, sB1, kB1, tB1, (S) ^ 1)                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NBH * 4) : "memory");                                             \
+        ORV_PH_BAR()                                                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        ORV_PH_MFMA(0, 0, fa0, fb0)                                                                                  \
+        ORV_PH_BAR()                                                                                                 \
+        /* P2 */                                                                                                     \
+        ORV_PH_READ_A(1, fa1, S)                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        ORV_PH_ISSUE_A(0, sA0, kA0, tA0, S)                                                                          \
+        ORV_PH_BAR()                                                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        ORV_PH_MFMA(1, 0, fa1, fb0)                                                                                  \
+        ORV_PH_BAR()                                                                                                 \
+        /* P3 */                                                                                                     \
+        ORV_PH_READ_B(1, fb1, S)                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        ORV_PH_ISSUE_B(0, sB0, kB0, tB0, S)                                                                          \
+        ORV_PH_BAR()                                                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        ORV_PH_MFMA(1, 1, fa1, fb1)                                                                                  \
+        ORV_PH_BAR()                                                                                                 \
+        /* P4 */                                                                                                     \
+        ORV_PH_ISSUE_A(1, sA1, kA1, tA1, S)                                                                          \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * APH + BPH) : "memory");                                         \
+        ORV_PH_BAR()                                                                                                 \
+        ORV_PH_MFMA(0, 1, fa0, fb1)                                                                                  \
+        ORV_PH_BAR()                                                                                                 \
+    }
+
+    // prologue: K-tile 0 complete into stage 0, K-tile 1's A0, W0, A1 into stage 1
+    ORV_PH_ISSUE_A(0, sA0, kA0, tA0, 0)
+    ORV_PH_ISSUE_B(0, sB0, kB0, tB0, 0)
+    ORV_PH_ISSUE_A(1, sA1, kA1, tA1, 0)
+    ORV_PH_ISSUE_B(1, sB1, kB1, tB1, 0)
+    ORV_PH_ISSUE_A(0, sA0, kA0, tA0, 1)
+    ORV_PH_ISSUE_B(0, sB0, kB0, tB0, 1)
+    ORV_PH_ISSUE_A(1, sA1, kA1, tA1, 1)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * APH + BPH) : "memory");
+    ORV_PH_BAR()
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (grp == 1) { ORV_PH_BAR() }        // the second half of the workgroup runs one barrier behind ...
+        for (int kt = 0; kt < nk; kt += 2) {
+            ORV_PH_KTILE(0)
+            ORV_PH_KTILE(1)
+        }
+        if (grp == 0) { ORV_PH_BAR() }        // ... and both halves run their epilogues side by side
+        int tm, tn;
+        tile_of_index(p, tile, ntiles, tm, tn);
+        gemm_epilogue<NB, MB, EPI>(p, acc, tm * BM + wq * 64, tn * BN + grp * (BN / 2), lane);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < MB; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef ORV_PH_GLDS
+#undef ORV_PH_ONE_MFMA
+#undef ORV_PH_SETUP_A
+#undef ORV_PH_SETUP_B
+#undef ORV_PH_ISSUE_A
+#undef ORV_PH_ISSUE_B
+#undef ORV_PH_READ_A
+#undef ORV_PH_READ_B
+#undef ORV_PH_MFMA
+#undef ORV_PH_BAR
+#undef ORV_PH_KTILE
+}
+
+template <int BN>
+int launch_ph(const GemmArgs& a, int epi, hipStream_t st) {
+    const int smem = 2 * (256 + BN) * 128;
+    const int grid = min(a.tiles_m * a.tiles_n, orv_num_cus());
+#define ORV_GEMM_CASE(E)                                                                                    \
+    case E: {                                                                                               \
+        static bool attr_done = false;                                                                      \
+        if (!attr_done) {                                                                                   \
+            (void)hipFuncSetAttribute((const void*)gemm_ph_kernel<BN, E>,                                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);                    \
+            attr_done = true;                                                                               \
+        }                                                                                                   \
+        hipLaunchKernelGGL((gemm_ph_kernel<BN, E>), dim3(grid), dim3(512), smem, st, a);                    \
+        break;                                                                                              \
+    }
+    switch (epi) {
+        ORV_GEMM_CASE(0)
+        ORV_GEMM_CASE(1)
+        ORV_GEMM_CASE(2)
+        ORV_GEMM_CASE(3)
+        ORV_GEMM_CASE(4)
+        default: orv_set_error("orv_gemm_bf16: bad epilogue %d", epi); return ORV_EINVAL;
+    }
+#undef ORV_GEMM_CASE
+    return orv_check_launch("orv_gemm_bf16");
+}
+
 template <int BN, int NSLOT>
 int launch_pp(const GemmArgs& a, int epi, hipStream_t st) {
     const int smem = NSLOT * (256 + BN) * 64;
@@ -786,8 +1017,11 @@ struct GemmCand { int ring, bm, bn; float rate; int min_rounds; };
 // and the cheapest wins.  The rates are measured on MI355X at M = 12904 (tools/tile_sweep.sh rates); the rounds term is
 // what matters at small batch, where a "better" tile that needs one more, nearly empty, round loses to a smaller one that
 // fills the chip (B = 1: N = 1920 GEMMs take 195 tiles of 256x128 instead of 260 of 128x192).
-static const GemmCand* choose_tile(int M, int N, int epilogue = 0, int heads = 0) {
+static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int heads = 0) {
     static const GemmCand cands[] = {
+        // ring = 2: the phased (8-phase, BK = 64) persistent kernel; needs an even number of K-tiles
+        // (256x384 does not fit: 192 accumulator + 64 fragment registers of the 256 a wave gets at two waves per SIMD)
+        {2, 256, 256, 1.10f, 0}, {2, 256, 128, 0.90f, 0},
         // 256x384 keeps ONE fragment set (192 accumulator registers) and leans on its neighbour tiles to hide the exposed
         // prologue / epilogue: measured +8 % on QKV (765 tiles), a loss when every CU gets a single tile (N = 1920: 255)
         {1, 256, 384, 1.075f, 2}, {1, 256, 256, 1.060f, 0}, {1, 256, 192, 1.000f, 0}, {1, 256, 128, 0.885f, 0},
@@ -800,6 +1034,8 @@ static const GemmCand* choose_tile(int M, int N, int epilogue = 0, int heads = 0
         if (const char* e = getenv("ORV_GEMM_TILE")) sscanf(e, "%d,%d,%d", &force_ring, &force_bm, &force_bn);
         if (const char* e = getenv("ORV_GEMM_ALGO")) { if (atoi(e) == 0) force_ring = 0; }   // legacy switch: simple kernel only
     }
+    static int no_phased = -1;   // ORV_GEMM_PHASED=0: A/B switch for the phased kernel
+    if (no_phased < 0) { const char* e = getenv("ORV_GEMM_PHASED"); no_phased = (e && atoi(e) == 0) ? 1 : 0; }
     static int no384 = -1;   // ORV_GEMM_BN384=0: A/B switch for the 384-wide variant
     if (no384 < 0) { const char* e = getenv("ORV_GEMM_BN384"); no384 = (e && atoi(e) == 0) ? 1 : 0; }
     const int ncu = orv_num_cus();
@@ -807,13 +1043,14 @@ static const GemmCand* choose_tile(int M, int N, int epilogue = 0, int heads = 0
     double best_cost = 0;
     for (const GemmCand& c : cands) {
         if (N % c.bn) continue;
+        if (c.ring == 2 && (K % 128 != 0 || no_phased)) continue;
         // epilogue 4 normalises whole 64-wide heads inside a wave (BN / 2 columns) that must not straddle q | k | v
         if (epilogue == 4 && ((c.bn / 2) % 64 != 0 || (heads * 64) % (c.bn / 2) != 0)) continue;
         if (force_bm && (c.ring != force_ring || c.bm != force_bm || c.bn != force_bn)) continue;
         if (!force_bm && force_ring == 0 && c.ring) continue;
         const long tiles = (long)((M + c.bm - 1) / c.bm) * (N / c.bn);
         if (!force_bm && tiles < (long)c.min_rounds * ncu) continue;
-        if (!force_bm && c.bn == 384 && no384) continue;
+        if (!force_bm && c.ring == 1 && c.bn == 384 && no384) continue;
         // full rounds cost 1 each; the last, partial round runs faster than a full one because the chip is power-capped
         // (fewer active CUs clock higher): 0.62 (= 1.5 GHz / 2.4 GHz) + 0.38 x the fraction of CUs it occupies.
         // Rows of the last M tile that do not exist still cost their MFMAs (tiles are counted whole).
@@ -827,11 +1064,11 @@ static const GemmCand* choose_tile(int M, int N, int epilogue = 0, int heads = 0
 
 // the kernel symbol orv_gemm_bf16 launches for a shape, as rocprofv3 prints it (bench.py labels its timings with it)
 extern "C" int orv_gemm_kernel_name(int M, int N, int K, int epilogue, char* buf, int len) {
-    (void)K;
     ORV_REQUIRE(buf && len > 0 && M > 0 && N > 0 && N % 64 == 0, "orv_gemm_kernel_name: bad arguments");
-    const GemmCand* c = choose_tile(M, N, epilogue, epilogue == 4 ? N / 192 : 0);
+    const GemmCand* c = choose_tile(M, N, K, epilogue, epilogue == 4 ? N / 192 : 0);
     ORV_REQUIRE(c, "orv_gemm_kernel_name: no tile configuration for N=%d", N);
-    if (c->ring) snprintf(buf, len, "gemm_pp_kernel<%d, %d, %d>", c->bn, c->bn == 384 ? 4 : 5, epilogue);
+    if (c->ring == 2) snprintf(buf, len, "gemm_ph_kernel<%d, %d>", c->bn, epilogue);
+    else if (c->ring) snprintf(buf, len, "gemm_pp_kernel<%d, %d, %d>", c->bn, c->bn == 384 ? 4 : 5, epilogue);
     else snprintf(buf, len, "gemm_kernel<%d, %d, %d>", c->bm, c->bn, epilogue);
     return ORV_OK;
 }
@@ -866,10 +1103,14 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
     }
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("ORV_GEMM_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     hipStream_t st = (hipStream_t)stream;
-    const GemmCand* best = choose_tile(g->M, g->N, g->epilogue, g->qn_heads);
+    const GemmCand* best = choose_tile(g->M, g->N, g->K, g->epilogue, g->qn_heads);
     ORV_REQUIRE(best, "orv_gemm_bf16: no tile configuration for N=%d (ORV_GEMM_TILE override?)", g->N);
     a.tiles_n = g->N / best->bn;
     a.tiles_m = (g->M + best->bm - 1) / best->bm;
+    if (best->ring == 2) {
+        if (best->bn == 256) return launch_ph<256>(a, g->epilogue, st);
+        return launch_ph<128>(a, g->epilogue, st);
+    }
     if (best->ring) {
         if (best->bn == 384) return launch_pp<384, 4>(a, g->epilogue, st);
         if (best->bn == 256) return launch_pp<256, 5>(a, g->epilogue, st);

@@ -14,7 +14,7 @@ static inline float bf2f(uint16_t h){ uint32_t u=((uint32_t)h)<<16; float f; mem
 static float gelu(float x){ float u=0.7978845608028654f*(x+0.044715f*x*x*x); return 0.5f*x*(1.f+tanhf(u)); }
 
 struct Dev { void* p=nullptr; size_t n=0; };
-static std::vector<uint16_t> rnd_bf(size_t n, float scale, uint32_t seed){ std::mt19937 g(seed); std::uniform_real_distribution<float> d(-1.f,1.f); std::vector<uint16_t> v(n); for(auto& x:v) x=f2bf(d(g)*scale); return v; }
+static std::vector<uint16_t> rnd_bf(size_t n, float scale, uint32_t seed){ if(getenv("KB_ZERO")) return std::vector<uint16_t>(n,0); if(getenv("KB_UNIT")) scale=1.f; std::mt19937 g(seed); std::uniform_real_distribution<float> d(-1.f,1.f); std::vector<uint16_t> v(n); for(auto& x:v) x=f2bf(d(g)*scale); return v; }
 template<class T> static T* up(const std::vector<T>& h){ T* d; CK(hipMalloc(&d,h.size()*sizeof(T))); CK(hipMemcpy(d,h.data(),h.size()*sizeof(T),hipMemcpyHostToDevice)); return d; }
 
 static int check(int M,int N,int K,int epi,int seq,int ntext,int pg){
@@ -47,6 +47,7 @@ static void bench(int M,int N,int K,int epi,int iters){
 }
 int main(int argc,char**argv){
   if(orv_device_check(0)){ printf("%s\n",orv_last_error()); return 2; }
+  if(argc>=9 && !strcmp(argv[1],"check")){ return check(atoi(argv[2]),atoi(argv[3]),atoi(argv[4]),atoi(argv[5]),atoi(argv[6]),atoi(argv[7]),atoi(argv[8])); }
   if(argc>=7 && !strcmp(argv[1],"bench")){ bench(atoi(argv[2]),atoi(argv[3]),atoi(argv[4]),atoi(argv[5]),atoi(argv[6])); return 0; }
   int bad=0;
   bad+=check(64,128,128,0,64,8,0); bad+=check(100,192,256,1,50,8,14); bad+=check(300,64,1920,0,300,0,0);
