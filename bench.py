@@ -115,13 +115,22 @@ def cpu_baseline(cfg, layers, threads):
             "s_per_step": per_step}
 
 
+def ranks_seen(world, dev):
+    """World size as the process group (RCCL) actually sees it: every rank adds 1 (collective; call on all ranks)."""
+    if world == 1:
+        return 1
+    import torch.distributed as dist
+    t = torch.ones(1, device=dev)
+    dist.all_reduce(t)
+    return int(t.item())
+
+
 def train_mode(args, model, latents, image_latents, prompt, actions, sched, dev, rank, world):
     """BASELINE configs[2]: CogVideoX-2B SFT step (train_cogvideox_control_to_video_sft.py:1005-1104), B clips per GPU, bf16
     params/grads, data parallel: forward+backward through the HIP kernels, ONE bucketed RCCL all-reduce of the gradients,
     global-norm clip + fused AdamW.  value = trained clips per second (all GPUs)."""
     import torch.distributed as dist
     from orv_amd.optim import FusedAdamW
-    from orv_amd.sharding import allreduce_gradients
     B = args.batch
     model.train()
     opt = FusedAdamW(model.parameters(), lr=1e-5, betas=(0.9, 0.95), weight_decay=1e-3, max_grad_norm=1.0)
@@ -153,12 +162,14 @@ def train_mode(args, model, latents, image_latents, prompt, actions, sched, dev,
         w = torch.tensor([wall], device=dev, dtype=torch.float64)
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
+    seen = ranks_seen(world, dev)
     if rank == 0:
         fl = 3.0 * flops_per_sample({**CFG_2B, "num_layers": args.layers}, 3226)
         value = world * B * args.steps / wall
         print(json.dumps({
             "metric": "train-clips/sec", "value": round(value, 3), "unit": "clips/s (SFT step: fwd+bwd+allreduce+AdamW)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 3),
+            "n_gpus": world, "ranks_seen": seen, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * wall / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "achieved_tflops_attn_ffn": round(value * fl / 1e12, 1), "final_loss": float(loss),
             "config": {"workload": "configs[2]: CogVideoX-2B SFT step, 320x480x17f latents, bf16 params+grads, DP",
@@ -166,6 +177,40 @@ def train_mode(args, model, latents, image_latents, prompt, actions, sched, dev,
                        "valid": args.layers == 30}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def self_launch(n: int) -> int:
+    """Re-run this command line as N ranks of `python -m torch.distributed.run` on this node (the shape the driver itself
+    uses for N > 1): one process per GPU, rendezvous on 127.0.0.1, HIP_VISIBLE_DEVICES untouched (each rank picks
+    cuda:LOCAL_RANK)."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(rank: int, world: int, args) -> int:
+    """Launcher check without a GPU: every rank joins a gloo group and contributes 1 to an all-reduce."""
+    seen = 1
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": args.gpus, "ranks_seen": seen, "mode": args.mode}), flush=True)
+    return 0 if seen == args.gpus else 1
 
 
 def main():
@@ -181,11 +226,18 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the transformer forward from a HIP graph (B=1 latency); "
                                                          "the per-kernel roofline needs the eager path and is omitted")
     ap.add_argument("--cpu-baseline-layers", type=int, default=6)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch the ranks, rendezvous (gloo, no GPU work), print the ranks seen and exit: checks the launcher")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: start N ranks (one per GPU) of this same command under torch.distributed.run
+        return self_launch(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        return dry_run(rank, world, args)
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get("ORV_DIST_BACKEND", "nccl")     # "gloo": functional test of the N > 1 path on ONE GPU (ranks share it)
@@ -196,7 +248,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL; only used for barrier/max
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -254,6 +306,7 @@ def main():
         w = torch.tensor([wall], device=dev, dtype=torch.float64)
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
+    seen = ranks_seen(world, dev)
 
     if rank == 0:
         S = 226 + 3000
@@ -302,7 +355,8 @@ def main():
                 traffic = None
         line = {
             "metric": "denoise-steps/sec", "value": round(value, 3), "unit": "steps/s (clips x denoise steps per second)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 3),
+            "n_gpus": world, "ranks_seen": seen, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * wall / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "frames_per_sec": round(17.0 * world * B * args.steps / 50.0 / wall, 3),
             "achieved_tflops_attn_ffn": round(value * fl / 1e12, 1),
@@ -327,4 +381,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -204,6 +204,12 @@ int orv_adamw(void* p, const void* g, float* m, float* v, long n, float lr, floa
 int orv_adamw_flat(void* p, const void* g, float* m, float* v, long n, const long* seg_start,
                    const unsigned char* seg_active, int nseg, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int step, const float* clip_coef, void* stream);
+/* Same, with ONE STEP COUNT PER SEGMENT (seg_step[nseg] int32 on the device, the count INCLUDING this update; NULL = the
+ * global `step`): torch.optim.AdamW keeps `state[p]["step"]` per parameter, so a parameter that was skipped in earlier
+ * steps (no gradient) gets the bias correction of its own count. */
+int orv_adamw_flat_steps(void* p, const void* g, float* m, float* v, long n, const long* seg_start,
+                         const unsigned char* seg_active, const int* seg_step, int nseg, float lr, float beta1, float beta2,
+                         float eps, float weight_decay, int step, const float* clip_coef, void* stream);
 /* out[0] += sum g^2 (gradient-norm reduction, orv/utils.py:166-174). */
 int orv_sumsq(const void* g, long n, float* out, void* stream);
 

@@ -202,8 +202,56 @@ def collate_case():
                                       metainfos=[d["metainfo"] for d in data]))
 
 
+def bucket_sampler_case():
+    """orv/dataset/dataset.py:1972-2050 ``BucketSampler`` (AST-sliced; it only needs ``random`` and a data source with
+    ``resolutions`` / ``get_ref_nums_for_all_samples`` / ``get_n_views_for_all_samples``): the yielded (index, ref_num, n_view)
+    order for a seeded ``random``, two epochs each (left-over buckets survive an epoch in the reference)."""
+    import random
+
+    class _Console:
+        @staticmethod
+        def log(*a, **k):
+            pass
+
+    Ref = ref_harness.load_reference_class(
+        "orv/dataset/dataset.py", "BucketSampler",
+        extra_globals={"Sampler": torch.utils.data.Sampler, "CONSOLE": _Console, "RobotDataset": object,
+                       "MultiViewRobotDataset": int, "random": random})
+
+    class DS:
+        def __init__(self, refs, views):
+            self.refs, self.views = refs, views
+            self.resolutions = sorted(set(zip(refs, views)))
+
+        def __len__(self):
+            return len(self.refs)
+
+        def get_ref_nums_for_all_samples(self):
+            return list(self.refs)
+
+        def get_n_views_for_all_samples(self, train=True):
+            return list(self.views)
+
+    rng = random.Random(99)
+    refs = [rng.choice([1, 2, 3]) for _ in range(53)]
+    views = [rng.choice([1, 3]) for _ in range(53)]
+    cases = []
+    for bs, shuffle, drop in [(4, True, False), (4, True, True), (4, False, False), (8, True, False), (3, False, True)]:
+        random.seed(1234)
+        smp = Ref(DS(refs, views), batch_size=bs, shuffle=shuffle, drop_last=drop)
+        order = [list(x) for x in smp]
+        second = [list(x) for x in smp]
+        cases.append(dict(batch_size=bs, shuffle=shuffle, drop_last=drop, seed=1234, order=order, second_epoch=second,
+                          length=len(smp)))
+    with open(os.path.join(OUT, "bucket_sampler.json"), "w") as f:
+        json.dump(dict(refs=refs, views=views, cases=cases), f)
+    print("bucket_sampler:", [len(c["order"]) for c in cases])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "sampler":
+        return bucket_sampler_case()
     if len(sys.argv) > 1 and sys.argv[1] == "collate":      # add the data-format fixtures without touching the others
         return collate_case()
     cc, comp, utils = ref_harness.load_reference()
@@ -229,6 +277,7 @@ def main():
     pipeline_bf16_cases(cc)
     misc_case(cc, comp, utils)
     collate_case()
+    bucket_sampler_case()
 
 
 if __name__ == "__main__":

@@ -350,9 +350,12 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, subfolder: Optional[str] = None, torch_dtype=None,
                         revision=None, variant=None, **kwargs):
-        """Loads an ORV checkpoint directly, or converts a vanilla CogVideoX transformer (2B: T2V->I2V channel doubling
-        with the new half zeroed, :1016-1030).  Errors follow the reference: RuntimeError on missing/unexpected/
-        mismatched keys when loading as this class (:955-967)."""
+        """Loads an ORV checkpoint directly, or converts: a vanilla CogVideoX transformer (2B: T2V->I2V channel doubling with
+        the new half zeroed, :1016-1030), or an ORV checkpoint into a model with EXTRA modules requested through kwargs
+        (``multiview=True``, ``recon_action=True``, ``visual_guidance=True`` - the train script's finetune flow,
+        train...sft.py:276-283): the reference's strict load fails there, is caught (:970) and answered by
+        ``from_config(base.config, **kwargs)`` + ``load_state_dict(strict=False)`` + the ``mv_blocks`` copy (:1043-1050).
+        Without kwargs a same-class checkpoint with missing / unexpected keys is a RuntimeError (:955-967)."""
         from .checkpoint import load_state_dict_dir
         path = str(pretrained_model_name_or_path)
         d = os.path.join(path, subfolder) if subfolder and os.path.isdir(os.path.join(path, subfolder)) else path
@@ -360,36 +363,44 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         state = load_state_dict_dir(d)
         same_class = config.get("_class_name") == cls.__name__
         cfg = {k: v for k, v in config.items() if not k.startswith("_")}
+        model = None
         if same_class:
-            cfg.update(kwargs)
-            model = cls(**cfg)
-            missing, unexpected = model.load_state_dict(state, strict=False)
-            bad = [k for k, v in state.items() if k in model.state_dict() and model.state_dict()[k].shape != v.shape]
-            msg = ""
-            if missing:
-                msg += f"Some weights of {cls.__name__} are not found in pretrained weights: {missing}. "
-            if unexpected:
-                msg += f"Some weights may be lost in {cls.__name__}: {unexpected}. "
-            if bad:
-                msg += f"Some weights have mismatched shapes: {bad}."
-            if msg:
-                raise RuntimeError(msg)
-        else:
+            # :954-968 - load as this class with the caller's overrides applied; any missing / unexpected / mismatched key is
+            # an error there, which the reference catches (:970) and answers with the conversion path below
+            try:
+                cand = cls(**{**cfg, **kwargs})
+                missing, unexpected = cand.load_state_dict(state, strict=False)   # size mismatches raise RuntimeError
+                msg = ""
+                if missing:
+                    msg += f"Some weights of {cls.__name__} are not found in pretrained weights: {missing}. "
+                if unexpected:
+                    msg += f"Some weights may be lost in {cls.__name__}: {unexpected}. "
+                if msg:
+                    raise RuntimeError(msg)
+                model = cand
+            except RuntimeError as e:
+                if not kwargs:           # nothing to convert to: the checkpoint itself is inconsistent with its config
+                    raise
+                cls._last_load_fallback = str(e)
+        if model is None:
+            # :974-1050 - conversion: build from the CHECKPOINT's config plus the caller's kwargs, load what matches
+            # (strict=False; a shape mismatch still raises, as torch does), widen a T2V patch embedding, seed mv_blocks
+            kwargs = dict(kwargs)
             if fnmatch.fnmatch(path, 'THUDM*CogVideoX*'):
                 for k in ("sample_height", "sample_width", "sample_frames"):
                     cfg[k] = kwargs.pop(k)
             if fnmatch.fnmatch(path, 'THUDM*CogVideoX*-2b*'):
                 assert cfg['in_channels'] == 16, f'Wrong `in_channels` in config of {path}!'
                 cfg['in_channels'] = 32
-                cfg.update(kwargs)
-                model = cls(**cfg, from_t2v=True)
+                model = cls(**{**cfg, **kwargs, "from_t2v": True})
+                state = dict(state)
                 w = state.pop('patch_embed.proj.weight')
                 model.load_state_dict(state, strict=False)
                 model.patch_embed.proj.weight.data[:, :16, ...].copy_(w)
             else:
-                cfg.update(kwargs)
-                model = cls(**cfg)
+                model = cls(**{**cfg, **kwargs})
                 model.load_state_dict(state, strict=False)
+            # a checkpoint that is not multiview itself seeds every mv_block from the 3-D attention block beside it (:1043-1050)
             if model.config.multiview and not ('multiview' in path or config.get("multiview", False)):
                 for i in range(len(model.mv_blocks)):
                     model.mv_blocks[i].load_state_dict(model.transformer_blocks[i].state_dict(), strict=False)
@@ -748,34 +759,95 @@ _FUSE_QKNORM = os.environ.get("ORV_FUSED_QKNORM", "1") != "0"      # A/B switch:
 class GraphedTransformer:
     """One denoise step's transformer forward replayed from a HIP graph (``torch.cuda.CUDAGraph`` over the library's
     launches on the capture stream): ~330 kernel launches become one submission, which matters when the step is short
-    (B=1: ~17 ms of kernels).  Static shapes; inputs are copied into fixed buffers.  The first call per shape runs eagerly
-    (builds pointer tables / workspaces / position tables), the second is captured, later ones replay."""
+    (B=1: ~17 ms of kernels).
 
-    def __init__(self, transformer):
+    A captured graph bakes in the ADDRESS of every tensor it touched, so the wrapper owns static copies of ALL tensor
+    inputs (latents, prompt embeddings, timestep, ofs, rotary tables, every control tensor) and refreshes them with
+    ``copy_`` before each replay; callers may pass fresh tensors on every call.  The cache key is the inputs' shapes /
+    dtypes / structure plus the non-tensor arguments, the model's weights epoch (fused optimizer steps) and the sum of the
+    parameters' ``_version`` counters (``load_state_dict`` / in-place edits), so stale weights are never replayed.  The
+    first call per key runs eagerly (builds pointer tables / workspaces / position tables), the second is captured, later
+    ones replay.  At most ``max_entries`` graphs are kept (least recently used is dropped with its workspace)."""
+
+    def __init__(self, transformer, max_entries: int = 4):
+        from collections import OrderedDict
         self.tr = transformer
-        self._state = {}
+        self.max_entries = max_entries
+        self._state = OrderedDict()
+
+    @staticmethod
+    def _flatten(kw):
+        """(tensor leaves in a fixed order, structure descriptor) of the call's keyword arguments."""
+        leaves, desc = [], []
+        for k in sorted(kw):
+            v = kw[k]
+            if torch.is_tensor(v):
+                leaves.append(v); desc.append((k, "t", tuple(v.shape), str(v.dtype)))
+            elif isinstance(v, (tuple, list)) and v and all(torch.is_tensor(x) for x in v):
+                leaves.extend(v); desc.append((k, "seq", tuple((tuple(x.shape), str(x.dtype)) for x in v)))
+            elif isinstance(v, dict):
+                sub = []
+                for kk in sorted(v):
+                    vv = v[kk]
+                    if torch.is_tensor(vv):
+                        leaves.append(vv); sub.append((kk, tuple(vv.shape), str(vv.dtype)))
+                    elif vv is None:
+                        sub.append((kk, None))
+                    else:
+                        raise TypeError(f"GraphedTransformer: unsupported entry {k}[{kk!r}] of type {type(vv).__name__}")
+                desc.append((k, "dict", tuple(sub)))
+            elif v is None or isinstance(v, (bool, int, float, str)):
+                desc.append((k, "v", v))
+            else:
+                raise TypeError(f"GraphedTransformer: unsupported argument {k} of type {type(v).__name__}")
+        return leaves, tuple(desc)
+
+    @staticmethod
+    def _rebuild(kw, static):
+        """kw with every tensor leaf replaced by the matching static buffer (same traversal order as ``_flatten``)."""
+        it = iter(static)
+        out = {}
+        for k in sorted(kw):
+            v = kw[k]
+            if torch.is_tensor(v):
+                out[k] = next(it)
+            elif isinstance(v, (tuple, list)) and v and all(torch.is_tensor(x) for x in v):
+                out[k] = tuple(next(it) for _ in v)
+            elif isinstance(v, dict):
+                out[k] = {kk: (next(it) if torch.is_tensor(vv) else vv) for kk, vv in sorted(v.items())}
+            else:
+                out[k] = v
+        return out
+
+    def _weights_version(self):
+        return sum(p._version for p in self.tr.parameters())
 
     def __call__(self, hidden_states, encoder_hidden_states, timestep, **kw):
-        key = (tuple(hidden_states.shape), tuple(encoder_hidden_states.shape), encoder_hidden_states.data_ptr(),
-               _state.weights_epoch[0])      # fused optimizer steps invalidate captured weight pointers
+        kw = dict(kw, hidden_states=hidden_states, encoder_hidden_states=encoder_hidden_states, timestep=timestep)
+        leaves, desc = self._flatten(kw)
+        key = (desc, _state.weights_epoch[0], self._weights_version(), self.tr.training)
         st = self._state.get(key)
         if st is None:                       # eager warm-up call
             self._state[key] = {"calls": 1}
+            while len(self._state) > self.max_entries:
+                self._state.popitem(last=False)
             with torch.no_grad():
-                return self.tr(hidden_states=hidden_states, encoder_hidden_states=encoder_hidden_states, timestep=timestep,
-                               **kw)
+                return self.tr(**kw)
+        self._state.move_to_end(key)
         if "graph" not in st:
-            st["x"], st["t"] = hidden_states.clone(), timestep.clone()
+            st["static"] = [t.clone() for t in leaves]
+            skw = self._rebuild(kw, st["static"])
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.no_grad(), torch.cuda.graph(g):
-                st["out"] = self.tr(hidden_states=st["x"], encoder_hidden_states=encoder_hidden_states, timestep=st["t"],
-                                    **kw)
+                st["out"] = self.tr(**skw)
             st["graph"] = g
             st["ws"] = self.tr._ws      # the captured launches point into this workspace: keep it alive even if the model
             #                             later swaps in another one for a different shape
-        st["x"].copy_(hidden_states)
-        st["t"].copy_(timestep)
+        else:
+            for dst, src in zip(st["static"], leaves):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src)
         st["graph"].replay()
         return st["out"]
 
@@ -786,10 +858,20 @@ class CogVideoXPipelineOutput:
 
 
 class CogVideoXImageToVideoPipelineTraj:
-    """Latent-space part of the reference's I2V pipeline: ``prepare_latents`` (:1115-1225) and the denoise loop of
-    ``__call__`` (:1402-1473).  VAE encode/decode and T5 are SURVEY §8(f) "next" rows: pass pre-encoded latents /
-    ``prompt_embeds`` and ``output_type='latent'`` (what the reference's dataset cache provides), or plug a ``vae`` /
-    ``text_encoder`` object with the diffusers interface."""
+    """The reference's I2V pipeline (:1090-1489) with the call surface its entry points use
+    (/root/reference/orv/pipeline/inference_control_to_video.py:71-146, evaluation_control_to_video.py:245-349):
+    ``from_pretrained`` / ``save_pretrained`` / ``to`` / ``__call__(image=<PIL | tensor>, prompt=<str>, negative_prompt=...,
+    output_type='pil' | 'latent' | 'pt' | 'np')`` / ``.scheduler`` / ``.vae`` / ``.text_encoder`` / ``.transformer``.
+
+    Built here (MI355X): ``prepare_latents`` (:1115-1225) and the denoise loop (:1402-1473).  The VAE and T5 arithmetic are
+    SURVEY §8(f) rows outside this build: the pipeline DELEGATES to whatever ``vae`` / ``text_encoder`` / ``tokenizer``
+    objects it holds, with exactly the calls the reference and its diffusers base class make (``vae.encode(x).latent_dist
+    .sample(generator)``, ``vae.decode(z).sample``, ``tokenizer(prompt, padding='max_length', ...)``,
+    ``text_encoder(ids)[0]``), so diffusers' ``AutoencoderKLCogVideoX`` and transformers' ``T5EncoderModel`` drop in.  Without
+    them, pass pre-encoded latents / ``prompt_embeds`` and ``output_type='latent'`` (what the reference's dataset cache
+    provides)."""
+
+    config_name = "model_index.json"
 
     def __init__(self, tokenizer=None, text_encoder=None, vae=None, transformer: CogVideoXTransformer3DModelTraj = None,
                  scheduler: Union[CogVideoXDDIMScheduler, CogVideoXDPMScheduler] = None):
@@ -801,20 +883,189 @@ class CogVideoXImageToVideoPipelineTraj:
         self.vae_scale_factor_spatial = 2 ** (len(vcfg.block_out_channels) - 1) if vcfg is not None else 8
         self.vae_scale_factor_temporal = getattr(vcfg, "temporal_compression_ratio", 4) if vcfg is not None else 4
         self.vae_scaling_factor_image = getattr(vcfg, "scaling_factor", 1.15258426) if vcfg is not None else 1.15258426
-        self.invert_scale_latents = bool(getattr(vcfg, "invert_scale_latents", False)) if vcfg is not None else False
         self._guidance_scale, self._interrupt, self._num_timesteps = 1.0, False, 0
         self._graphed: Optional[GraphedTransformer] = None
-        self.video_processor = None        # a caller with diffusers may attach VideoProcessor(vae_scale_factor=...) here
+        from .components import VideoProcessor
+        self.video_processor = VideoProcessor(vae_latent_channels=getattr(vcfg, "latent_channels", 16) if vcfg is not None else 16,
+                                              vae_scale_factor=self.vae_scale_factor_spatial)          # :1110-1113
 
     guidance_scale = property(lambda self: self._guidance_scale)
     interrupt = property(lambda self: self._interrupt)
     num_timesteps = property(lambda self: self._num_timesteps)
 
+    @property
+    def invert_scale_latents(self) -> bool:
+        """Read at call time like the reference (:1186): its entry points overwrite ``pipe.vae`` config AFTER construction
+        (inference_control_to_video.py:108)."""
+        vcfg = getattr(self.vae, "config", None)
+        if vcfg is None:
+            return False
+        try:
+            return bool(vcfg["invert_scale_latents"] if isinstance(vcfg, dict) else getattr(vcfg, "invert_scale_latents", False))
+        except KeyError:
+            return False
+
+    # ---- construction / persistence (diffusers DiffusionPipeline subset the entry points use) ----
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, transformer=None, scheduler=None, vae=None, text_encoder=None,
+                        tokenizer=None, torch_dtype=None, **_unused):
+        """Reads ``model_index.json`` of a pipeline directory (the layout ``save_pretrained`` and the reference's final export
+        write, train...sft.py:1184-1199): ``transformer/`` through ``CogVideoXTransformer3DModelTraj.from_pretrained`` (ORV
+        or vanilla CogVideoX weights), ``scheduler/scheduler_config.json`` into this package's scheduler of the recorded
+        class.  Components passed as keyword arguments win (inference_control_to_video.py:80-84 passes ``transformer=``).
+        ``vae`` / ``text_encoder`` / ``tokenizer`` are not built here: supply the objects; a T5 under ``text_encoder/`` +
+        ``tokenizer/`` is loaded through ``transformers`` when that package is importable."""
+        path = str(pretrained_model_name_or_path)
+        index = {}
+        ipath = os.path.join(path, cls.config_name)
+        if os.path.exists(ipath):
+            with open(ipath, "r", encoding="utf-8") as f:
+                index = json.load(f)
+        if transformer is None:
+            if not os.path.isdir(os.path.join(path, "transformer")):
+                raise OSError(f"{path} has no transformer/ folder: pass transformer=")
+            transformer = CogVideoXTransformer3DModelTraj.from_pretrained(path, subfolder="transformer", torch_dtype=torch_dtype)
+        if scheduler is None:
+            spath = os.path.join(path, "scheduler", "scheduler_config.json")
+            if os.path.exists(spath):
+                with open(spath, "r", encoding="utf-8") as f:
+                    scfg = json.load(f)
+                name = scfg.get("_class_name") or (index.get("scheduler") or [None, "CogVideoXDDIMScheduler"])[1]
+                sched_cls = {"CogVideoXDDIMScheduler": CogVideoXDDIMScheduler, "CogVideoXDPMScheduler": CogVideoXDPMScheduler}.get(name)
+                if sched_cls is None:
+                    raise ValueError(f"scheduler class {name} is not a CogVideoX scheduler")
+                scheduler = sched_cls.from_config(scfg)
+            else:
+                raise OSError(f"{path} has no scheduler/scheduler_config.json: pass scheduler=")
+        if text_encoder is None and os.path.isdir(os.path.join(path, "text_encoder")):
+            try:
+                from transformers import T5EncoderModel
+                text_encoder = T5EncoderModel.from_pretrained(path, subfolder="text_encoder", torch_dtype=torch_dtype)
+            except Exception:            # absent package / weights: stays None, prompt= then asks for prompt_embeds
+                text_encoder = None
+        if tokenizer is None and os.path.isdir(os.path.join(path, "tokenizer")):
+            try:
+                from transformers import T5Tokenizer
+                tokenizer = T5Tokenizer.from_pretrained(path, subfolder="tokenizer")
+            except Exception:
+                tokenizer = None
+        pipe = cls(tokenizer=tokenizer, text_encoder=text_encoder, vae=vae, transformer=transformer, scheduler=scheduler)
+        if torch_dtype is not None:
+            pipe.to(dtype=torch_dtype)
+        return pipe
+
+    def save_pretrained(self, save_directory, safe_serialization: bool = True, max_shard_size: Union[int, str] = "5GB", **kw):
+        """``model_index.json`` + ``transformer/`` + ``scheduler/scheduler_config.json``; ``vae`` / ``text_encoder`` /
+        ``tokenizer`` are written by their own ``save_pretrained`` when they have one."""
+        os.makedirs(save_directory, exist_ok=True)
+        index = {"_class_name": type(self).__name__, "_diffusers_version": "0.32.0.dev0",
+                 "transformer": ["orv_amd", type(self.transformer).__name__],
+                 "scheduler": ["orv_amd", type(self.scheduler).__name__]}
+        self.transformer.save_pretrained(os.path.join(save_directory, "transformer"), safe_serialization=safe_serialization,
+                                         max_shard_size=max_shard_size)
+        os.makedirs(os.path.join(save_directory, "scheduler"), exist_ok=True)
+        with open(os.path.join(save_directory, "scheduler", "scheduler_config.json"), "w", encoding="utf-8") as f:
+            json.dump({**dict(self.scheduler.config), "_class_name": type(self.scheduler).__name__,
+                       "_diffusers_version": "0.32.0.dev0"}, f, indent=2)
+        for name in ("vae", "text_encoder", "tokenizer"):
+            obj = getattr(self, name)
+            if obj is not None and hasattr(obj, "save_pretrained"):
+                obj.save_pretrained(os.path.join(save_directory, name))
+                index[name] = [type(obj).__module__.split(".")[0], type(obj).__name__]
+        with open(os.path.join(save_directory, self.config_name), "w", encoding="utf-8") as f:
+            json.dump(index, f, indent=2)
+
+    # memory management of the reference's entry points: one MI355X holds every component (288 GB), nothing is offloaded
+    def enable_model_cpu_offload(self, *a, **k):
+        return self
+
+    def enable_sequential_cpu_offload(self, *a, **k):
+        return self
+
+    def maybe_free_model_hooks(self):
+        return None
+
+    def progress_bar(self, iterable=None, total=None):
+        try:
+            from tqdm.auto import tqdm
+            return tqdm(iterable, total=total, disable=getattr(self, "_progress_bar_disabled", True))
+        except Exception:                # pragma: no cover
+            import contextlib
+            return contextlib.nullcontext()
+
+    def set_progress_bar_config(self, **kw):
+        self._progress_bar_disabled = bool(kw.get("disable", False))
+
+    # ---- text side: delegate to the attached T5 (diffusers CogVideoXPipeline.encode_prompt / _get_t5_prompt_embeds) ----
+    def _get_t5_prompt_embeds(self, prompt, num_videos_per_prompt=1, max_sequence_length=226, device=None, dtype=None):
+        if self.tokenizer is None or self.text_encoder is None:
+            raise NotImplementedError("prompt= needs the pipeline's `tokenizer` and `text_encoder` (T5) objects; they are not "
+                                      "built here (SURVEY §8f): attach them or pass prompt_embeds (the reference's dataset "
+                                      "caches them, dataset.py:1056-1059)")
+        prompt = [prompt] if isinstance(prompt, str) else list(prompt)
+        text_inputs = self.tokenizer(prompt, padding="max_length", max_length=max_sequence_length, truncation=True,
+                                     add_special_tokens=True, return_tensors="pt")
+        ids = text_inputs.input_ids if hasattr(text_inputs, "input_ids") else text_inputs["input_ids"]
+        enc_dev = getattr(self.text_encoder, "device", device)
+        embeds = self.text_encoder(ids.to(enc_dev))[0].to(dtype=dtype, device=device)
+        b, seq, _ = embeds.shape
+        return embeds.repeat(1, num_videos_per_prompt, 1).view(b * num_videos_per_prompt, seq, -1)
+
+    def encode_prompt(self, prompt, negative_prompt=None, do_classifier_free_guidance: bool = True,
+                      num_videos_per_prompt: int = 1, prompt_embeds=None, negative_prompt_embeds=None,
+                      max_sequence_length: int = 226, device=None, dtype=None):
+        device = device or self._execution_device
+        dtype = dtype or self.transformer.dtype
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        batch_size = len(prompt) if prompt is not None else prompt_embeds.shape[0]
+        if prompt_embeds is None:
+            prompt_embeds = self._get_t5_prompt_embeds(prompt, num_videos_per_prompt, max_sequence_length, device, dtype)
+        if do_classifier_free_guidance and negative_prompt_embeds is None:
+            negative_prompt = negative_prompt or ""
+            negative_prompt = batch_size * [negative_prompt] if isinstance(negative_prompt, str) else negative_prompt
+            if prompt is not None and type(prompt) is not type(negative_prompt):
+                raise TypeError(f"`negative_prompt` should be the same type to `prompt`, but got {type(negative_prompt)} !="
+                                f" {type(prompt)}.")
+            if batch_size != len(negative_prompt):
+                raise ValueError(f"`negative_prompt`: {negative_prompt} has batch size {len(negative_prompt)}, but `prompt`:"
+                                 f" {prompt} has batch size {batch_size}. Please make sure that passed `negative_prompt` matches"
+                                 " the batch size of `prompt`.")
+            negative_prompt_embeds = self._get_t5_prompt_embeds(negative_prompt, num_videos_per_prompt, max_sequence_length,
+                                                                device, dtype)
+        return prompt_embeds, negative_prompt_embeds
+
+    def check_inputs(self, image, prompt, height, width, negative_prompt, callback_on_step_end_tensor_inputs,
+                     prompt_embeds=None, negative_prompt_embeds=None):
+        """diffusers ``CogVideoXImageToVideoPipeline.check_inputs`` (called at :1261-1270)."""
+        import PIL.Image
+        if not torch.is_tensor(image) and not isinstance(image, PIL.Image.Image) and not isinstance(image, list):
+            raise ValueError("`image` has to be of type `torch.Tensor` or `PIL.Image.Image` or `List[PIL.Image.Image]` but is"
+                             f" {type(image)}")
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        allowed = {"latents", "prompt_embeds", "negative_prompt_embeds"}
+        if callback_on_step_end_tensor_inputs is not None and not all(k in allowed for k in callback_on_step_end_tensor_inputs):
+            raise ValueError(f"`callback_on_step_end_tensor_inputs` has to be in {sorted(allowed)}")
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError(f"Cannot forward both `prompt`: {prompt} and `prompt_embeds`: {prompt_embeds}. Please make sure to"
+                             " only forward one of the two.")
+        if prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` undefined.")
+        if prompt is not None and not isinstance(prompt, (str, list)):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if negative_prompt is not None and negative_prompt_embeds is not None:
+            raise ValueError(f"Cannot forward both `negative_prompt`: {negative_prompt} and `negative_prompt_embeds`:"
+                             f" {negative_prompt_embeds}. Please make sure to only forward one of the two.")
+        if prompt_embeds is not None and negative_prompt_embeds is not None and prompt_embeds.shape != negative_prompt_embeds.shape:
+            raise ValueError("`prompt_embeds` and `negative_prompt_embeds` must have the same shape when passed directly, but"
+                             f" got: `prompt_embeds` {prompt_embeds.shape} != `negative_prompt_embeds`"
+                             f" {negative_prompt_embeds.shape}.")
+
     def decode_latents(self, latents: torch.Tensor) -> torch.Tensor:
         """Hands the latents to the CALLER-SUPPLIED VAE exactly as the base diffusers pipeline does (``[B,F,C,h,w] ->
         [B,C,F,h,w]``, divided by the VAE scaling factor, ``vae.decode(...).sample``; the arithmetic of the decode itself is
         the VAE object's, SURVEY §8f rank 1, out of scope here)."""
-        if self.vae is None:
+        if self.vae is None or not hasattr(self.vae, "decode"):
             raise NotImplementedError("VAE decode is a SURVEY §8(f) next row: pass a `vae` object (e.g. diffusers' "
                                       "AutoencoderKLCogVideoX) or use output_type='latent'")
         z = latents.permute(0, 2, 1, 3, 4) / self.vae_scaling_factor_image
@@ -827,7 +1078,13 @@ class CogVideoXImageToVideoPipelineTraj:
         return self
 
     def to(self, device=None, dtype=None):
+        """``pipe.to(device, dtype=dtype)`` (inference_control_to_video.py:95): every attached torch module follows."""
+        if isinstance(device, torch.dtype):
+            device, dtype = None, device
         self.transformer.to(device=device, dtype=dtype)
+        for obj in (self.vae, self.text_encoder):
+            if obj is not None and hasattr(obj, "to"):
+                obj.to(device=device, dtype=dtype)
         return self
 
     @property
@@ -851,13 +1108,26 @@ class CogVideoXImageToVideoPipelineTraj:
                  width // self.vae_scale_factor_spatial)
         if pt is not None:
             shape = shape[:1] + (shape[1] + shape[1] % pt,) + shape[2:]
-        if image.ndim == 4:
-            raise NotImplementedError("RGB reference frames need the VAE encoder (SURVEY §8(f) next row); pass latents")
-        if image.ndim != 5:
+        if image.ndim not in (4, 5):
             raise RuntimeError(f'Invalid dimensions of image input: {image.shape=}')
         ch = image.size(1)
         image = image.to(device=device, dtype=dtype)
-        if ch == num_channels_latents * 2:
+        if image.ndim == 4:
+            # RGB reference frames [(b v f), 3, H, W]: encoded by the ATTACHED vae exactly as :1150-1167 (one clip at a time,
+            # `retrieve_latents(vae.encode(x), generator)` = latent_dist.sample(generator))
+            if ch != 3:
+                raise RuntimeError(f'Invalid input channels {image.shape=}!')
+            if self.vae is None or not hasattr(self.vae, "encode"):
+                raise NotImplementedError("RGB reference frames need a `vae` object with .encode() (SURVEY §8(f) next row is "
+                                          "not built here): attach one or pass pre-encoded latents")
+            img = image.reshape(batch_size * num_views, -1, *image.shape[1:]).permute(0, 2, 1, 3, 4)     # [(b v), C, f, H, W]
+            gens = generator if isinstance(generator, list) else [generator] * img.shape[0]
+            lats = [_retrieve_latents(self.vae.encode(img[i].unsqueeze(0)), gens[i if isinstance(generator, list) else 0])
+                    for i in range(img.shape[0])]
+            image_latents = torch.cat(lats, dim=0).to(dtype).permute(0, 2, 1, 3, 4)                      # [(b v), f, C, h, w]
+            image_latents = image_latents.reshape(batch_size, -1, *image_latents.shape[2:])              # [b, (v f), C, h, w]
+            image_latents = self._scale() * image_latents
+        elif ch == num_channels_latents * 2:
             eps = _randn(tuple(image.shape[:1]) + (num_channels_latents,) + tuple(image.shape[2:]), generator, device, dtype)
             image_latents = ops.gaussian_sample(image, eps.float(), self._scale())         # fused sample+scale+permute
         elif ch == num_channels_latents:
@@ -891,14 +1161,17 @@ class CogVideoXImageToVideoPipelineTraj:
                  callback_on_step_end_tensor_inputs: List[str] = ["latents"], max_sequence_length: int = 226,
                  controls_or_guidances: Dict[str, torch.Tensor] = {}):
         tr, sched = self.transformer, self.scheduler
+        self.check_inputs(image, prompt, height, width, negative_prompt, callback_on_step_end_tensor_inputs, prompt_embeds,
+                          negative_prompt_embeds)
         self._guidance_scale, self._interrupt = guidance_scale, False
-        if prompt_embeds is None:
-            raise NotImplementedError("T5 prompt encoding is a SURVEY §8(f) next row: pass prompt_embeds "
-                                      "(the reference's dataset caches them, dataset.py:1056-1059)")
         device = self._execution_device
         dtype = tr.dtype
-        batch_size = prompt_embeds.shape[0]
         do_cfg = guidance_scale > 1.0
+        prompt_embeds, negative_prompt_embeds = self.encode_prompt(        # :1290-1299 (T5 only when prompt= is used)
+            prompt=prompt, negative_prompt=negative_prompt, do_classifier_free_guidance=do_cfg,
+            num_videos_per_prompt=num_videos_per_prompt, prompt_embeds=prompt_embeds,
+            negative_prompt_embeds=negative_prompt_embeds, max_sequence_length=max_sequence_length, device=device, dtype=dtype)
+        batch_size = prompt_embeds.shape[0] // (num_videos_per_prompt if prompt is not None else 1)
         prompt_embeds = prompt_embeds.to(device=device, dtype=dtype)
         if do_cfg:
             prompt_embeds = torch.cat([negative_prompt_embeds.to(device=device, dtype=dtype), prompt_embeds], dim=0)
@@ -927,7 +1200,7 @@ class CogVideoXImageToVideoPipelineTraj:
                 eps = torch.randn((cm.shape[0], latent_channels) + tuple(cm.shape[2:]), device=device, dtype=dtype)
                 lat = ops.gaussian_sample(cm, eps.float(), self._scale())
                 controls[key] = torch.cat([lat, lat], dim=2)
-        image = image.to(device=device, dtype=dtype) if torch.is_tensor(image) else image
+        image = self.video_processor.preprocess(image, height=height, width=width).to(device=device, dtype=dtype)   # :1366
         latents, image_latents = self.prepare_latents(image, batch_size * num_videos_per_prompt, latent_channels,
                                                       num_frames, num_views, height, width, dtype, device, generator,
                                                       latents)
@@ -979,11 +1252,20 @@ class CogVideoXImageToVideoPipelineTraj:
         video = latents
         if output_type != "latent":                                                  # :1477-1479
             video = self.decode_latents(latents)
-            if self.video_processor is not None:
-                video = self.video_processor.postprocess_video(video=video, output_type=output_type)
+            video = self.video_processor.postprocess_video(video=video, output_type=output_type)
+        self.maybe_free_model_hooks()
         if not return_dict:
             return (video,)
         return CogVideoXPipelineOutput(frames=video)
+
+
+def _retrieve_latents(encoder_output, generator=None):
+    """diffusers ``retrieve_latents`` (sample_mode='sample')."""
+    if hasattr(encoder_output, "latent_dist"):
+        return encoder_output.latent_dist.sample(generator)
+    if hasattr(encoder_output, "latents"):
+        return encoder_output.latents
+    raise AttributeError("Could not access latents of provided encoder_output")
 
 
 def _randn(shape, generator, device, dtype):

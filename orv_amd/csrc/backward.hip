@@ -528,11 +528,17 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(bf16_t* __restrict__ p,
                                                          float* __restrict__ m, float* __restrict__ v,
                                                          const long* __restrict__ seg_start, const uint8_t* __restrict__ active,
                                                          int nseg, float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                         float bc2, const float* __restrict__ clip) {
+                                                         float bc2, const float* __restrict__ clip,
+                                                         const int* __restrict__ seg_step) {
     const long e0 = (long)blockIdx.x * 2048;
     int lo = 0, hi = nseg - 1;                 // last segment with seg_start <= e0 (wave-uniform binary search)
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (seg_start[mid] <= e0) lo = mid; else hi = mid - 1; }
     if (!active[lo]) return;
+    if (seg_step) {                            // torch.optim.AdamW keeps one step count PER PARAMETER (bias correction)
+        const float st = (float)seg_step[lo];
+        bc1 = 1.f - powf(b1, st);
+        bc2 = 1.f - powf(b2, st);
+    }
     const long i = e0 + threadIdx.x * 8;
     const float c = clip ? *clip : 1.f;
     const uint4 up = *(const uint4*)(p + i), ug = *(const uint4*)(g + i);
@@ -716,16 +722,23 @@ extern "C" int orv_adamw(void* p, const void* g, float* m, float* v, long n, flo
     return orv_check_launch("orv_adamw");
 }
 
-extern "C" int orv_adamw_flat(void* p, const void* g, float* m, float* v, long n, const long* seg_start,
-                              const unsigned char* seg_active, int nseg, float lr, float beta1, float beta2, float eps,
-                              float weight_decay, int step, const float* clip_coef, void* stream) {
+extern "C" int orv_adamw_flat_steps(void* p, const void* g, float* m, float* v, long n, const long* seg_start,
+                                    const unsigned char* seg_active, const int* seg_step, int nseg, float lr, float beta1,
+                                    float beta2, float eps, float weight_decay, int step, const float* clip_coef, void* stream) {
     ORV_REQUIRE(p && g && m && v && seg_start && seg_active && nseg > 0 && step > 0, "orv_adamw_flat: bad arguments");
     ORV_REQUIRE(n > 0 && n % 2048 == 0, "orv_adamw_flat: n=%ld must be a multiple of 2048 (pad every segment)", n);
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)(n / 2048)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)p,
                        (const bf16_t*)g, m, v, seg_start, seg_active, nseg, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
-                       clip_coef);
+                       clip_coef, seg_step);
     return orv_check_launch("orv_adamw_flat");
+}
+
+extern "C" int orv_adamw_flat(void* p, const void* g, float* m, float* v, long n, const long* seg_start,
+                              const unsigned char* seg_active, int nseg, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, int step, const float* clip_coef, void* stream) {
+    return orv_adamw_flat_steps(p, g, m, v, n, seg_start, seg_active, nullptr, nseg, lr, beta1, beta2, eps, weight_decay, step,
+                                clip_coef, stream);
 }
 
 extern "C" int orv_sumsq(const void* g, long n, float* out, void* stream) {

@@ -96,3 +96,57 @@ class CollateFunctionControl:
         out["num_views"] = out["metainfos"][0]["num_view"]
         out["num_frames"] = out["metainfos"][0]["num_frame"]
         return out
+
+
+class BucketSampler(torch.utils.data.Sampler):
+    """Groups samples into same-shape batches: every ``batch_size`` consecutive yields share (reference-frame count, view
+    count), so a data-parallel step gets a rectangular batch on every rank (the part of SURVEY §8f rank 3 that keeps 8 GPUs
+    fed).  Mirror of /root/reference/orv/dataset/dataset.py:1972-2050, behaviour for behaviour:
+
+    * yields ``(index, ref_num, n_view)`` TUPLES (the reference's datasets index by that tuple), drawn with the GLOBAL
+      ``random`` module - seeding ``random`` reproduces the reference's order exactly (golden: tests/golden/bucket_sampler.json);
+    * a bucket is flushed (and shuffled again) the moment it holds ``batch_size`` entries;
+    * left-over partial buckets are emitted at the end only when ``drop_last`` is False AND ``shuffle`` is True - with
+      ``shuffle=False`` the reference silently drops them (:2036-2043, the ``extend`` sits inside ``if self.shuffle``); kept,
+      because the order of an epoch is part of what "same batches as the reference" means;
+    * ``__len__`` is ``ceil(len(data_source) / batch_size)`` whatever ``drop_last`` says (:2012-2018).
+
+    ``data_source`` needs ``resolutions`` (iterable of (ref_num, n_view) keys), ``get_ref_nums_for_all_samples()`` and
+    ``get_n_views_for_all_samples(train=...)``."""
+
+    def __init__(self, data_source, batch_size: int = 8, shuffle: bool = True, drop_last: bool = False, train: bool = True) -> None:
+        self.data_source = data_source
+        self.batch_size = batch_size
+        self.shuffle = shuffle
+        self.drop_last = drop_last
+        self.train = train
+        self.buckets = {resolution: [] for resolution in data_source.resolutions}
+
+    def __len__(self):
+        return (len(self.data_source) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        import random
+        order = []
+        entries = [(i, r, v) for i, (r, v) in enumerate(zip(self.data_source.get_ref_nums_for_all_samples(),
+                                                            self.data_source.get_n_views_for_all_samples(train=self.train)))]
+        if self.shuffle:
+            random.shuffle(entries)
+        for entry in entries:
+            key = (entry[1], entry[2])
+            bucket = self.buckets[key]
+            bucket.append(entry)
+            if len(bucket) == self.batch_size:
+                if self.shuffle:
+                    random.shuffle(bucket)
+                order.extend(bucket)
+                del self.buckets[key]          # re-inserted at the END of the dict, as in the reference: the order in which
+                self.buckets[key] = []         # left-over buckets are emitted below depends on it
+        if not self.drop_last and self.shuffle:
+            for key, bucket in list(self.buckets.items()):
+                if bucket:
+                    random.shuffle(bucket)
+                    order.extend(bucket)
+                    del self.buckets[key]
+                    self.buckets[key] = []
+        yield from order

@@ -289,10 +289,10 @@ def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, clip_coef=None)
                           float(weight_decay), int(step), _p(clip_coef), _stream()), "orv_adamw")
 
 
-def adamw_flat(p, g, m, v, seg_start, seg_active, lr, beta1, beta2, eps, weight_decay, step, clip_coef=None):
-    check(lib().orv_adamw_flat(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(seg_start), _p(seg_active), seg_active.numel(),
-                               float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
-                               _p(clip_coef), _stream()), "orv_adamw_flat")
+def adamw_flat(p, g, m, v, seg_start, seg_active, lr, beta1, beta2, eps, weight_decay, step, clip_coef=None, seg_step=None):
+    check(lib().orv_adamw_flat_steps(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(seg_start), _p(seg_active), _p(seg_step),
+                                     seg_active.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                                     float(weight_decay), int(step), _p(clip_coef), _stream()), "orv_adamw_flat_steps")
 
 
 def sumsq(g, out):

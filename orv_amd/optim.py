@@ -7,8 +7,11 @@ flat bf16 gradient and fp32 moment buffers beside it (1.69 B parameters: 3.4 + 3
 is then: gather the autograd gradients into the flat buffer (multi-tensor copy) -> optional RCCL all-reduce of the flat
 buffer in 256 MB pieces -> ONE ``orv_sumsq`` -> clip coefficient on the device (no host sync before the update) -> ONE
 ``orv_adamw_flat`` (clip + moments + decoupled decay + bf16 write, 16-byte accesses).  Parameters that received no gradient
-in a step are skipped exactly as ``torch.optim.AdamW`` skips them (segment activity mask).  Moments are fp32 (the reference
-keeps them in the parameter dtype)."""
+in a step are skipped exactly as ``torch.optim.AdamW`` skips them (segment activity mask) and every parameter carries its
+OWN step count for the bias correction (``state[p]["step"]`` in torch).  Under data parallel every trainable parameter is
+active on every rank (a rank without a gradient contributes zeros: DDP's ``find_unused_parameters`` behaviour, which the
+reference enables, base_train.yaml:181), so the collective schedule and the update are identical on all ranks.  Moments
+are fp32 (the reference keeps them in the parameter dtype)."""
 from __future__ import annotations
 
 from typing import Iterable, List, Optional
@@ -55,7 +58,8 @@ class FusedAdamW:
             p=flat_p, g=flat_g, m=torch.zeros(total, dtype=torch.float32, device=dev),
             v=torch.zeros(total, dtype=torch.float32, device=dev), views_g=views_g,
             seg_start=torch.tensor(offs + [total], dtype=torch.int64, device=dev),
-            active=torch.zeros(len(self.params), dtype=torch.uint8, device=dev), active_host=[False] * len(self.params))
+            active=torch.zeros(len(self.params), dtype=torch.uint8, device=dev), active_host=[False] * len(self.params),
+            seg_step=torch.zeros(len(self.params), dtype=torch.int32, device=dev))
 
     # ---- data parallel: exchange overlapped with the backward ----
     def begin_overlapped_allreduce(self):
@@ -71,6 +75,11 @@ class FusedAdamW:
         filled = set()
 
         def hook(params, grads):
+            # Which segments one call makes final is decided by the CODE PATH of the backward, not by the data: the big weights
+            # of a block have their gradient here, its small fp32-accumulated ones (biases, LayerNorm affine) are converted
+            # at the very end on every rank alike, and the parameters whose gradient may exist on one rank only (action
+            # reconstruction head, mask embedding, control fuse) are in no block list - they travel in ``finish`` as zeros
+            # where a rank has none.  So every rank issues the same collectives in the same order.
             idx, srcs, dsts = [], [], []
             for p in params:
                 i, g = index.get(id(p)), grads.get(id(p))
@@ -100,14 +109,22 @@ class FusedAdamW:
         if self._flat is None:
             self._build()
         f = self._flat
-        live = [p.grad is not None for p in self.params]
-        if not any(live):
-            return 0.0
         overlap = getattr(self, "_overlap", None)
         self._overlap = None
+        distributed = overlap is not None or bool(average_over and average_over > 1)
+        has_grad = [p.grad is not None for p in self.params]
+        # data parallel: every trainable parameter takes part on every rank (zeros where this rank has no gradient)
+        live = [True] * len(self.params) if distributed else has_grad
+        if not any(live):
+            return 0.0
         done = overlap[1] if overlap else ()
-        srcs = [p.grad for i, (p, a) in enumerate(zip(self.params, live)) if a and i not in done]
-        dsts = [v for i, (v, a) in enumerate(zip(f["views_g"], live)) if a and i not in done]
+        if distributed:
+            missing = [v for i, (v, h) in enumerate(zip(f["views_g"], has_grad)) if not h and i not in done]
+            if missing:
+                torch._foreach_zero_(missing)
+        live_src = has_grad
+        srcs = [p.grad for i, (p, a) in enumerate(zip(self.params, live_src)) if a and i not in done]
+        dsts = [v for i, (v, a) in enumerate(zip(f["views_g"], live_src)) if a and i not in done]
         if srcs:
             torch._foreach_copy_(dsts, srcs)
         if live != f["active_host"]:
@@ -127,21 +144,36 @@ class FusedAdamW:
         norm = ss.sqrt()
         clip = torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0) if self.max_grad_norm else torch.ones_like(norm)
         self.step_count += 1
+        f["seg_step"].add_(f["active"].to(torch.int32))          # per-parameter step counts (torch.optim.AdamW state["step"])
         ops.adamw_flat(f["p"], f["g"], f["m"], f["v"], f["seg_start"], f["active"], self.param_groups[0]["lr"], self.betas[0],
-                       self.betas[1], self.eps, self.weight_decay, self.step_count, clip)
+                       self.betas[1], self.eps, self.weight_decay, self.step_count, clip, seg_step=f["seg_step"])
         _state.bump_weights_epoch()      # parameters changed without a tensor._version bump: drop derived-weight caches
         return float(norm.item())
 
     # ---- checkpointing (torch.optim-like) ----
     def state_dict(self):
+        """Flat moments plus the layout they are stored in (parameter element counts and segment offsets), so that a resume
+        with a different trainable set fails loudly instead of mis-assigning moments."""
+        layout = [int(p.numel()) for p in self.params]
         if self._flat is None:
-            return {"step": self.step_count, "exp_avg": None, "exp_avg_sq": None}
-        return {"step": self.step_count, "exp_avg": self._flat["m"], "exp_avg_sq": self._flat["v"]}
+            return {"step": self.step_count, "exp_avg": None, "exp_avg_sq": None, "numels": layout}
+        return {"step": self.step_count, "exp_avg": self._flat["m"], "exp_avg_sq": self._flat["v"], "numels": layout,
+                "seg_start": self._flat["seg_start"].tolist(), "seg_step": self._flat["seg_step"]}
 
     def load_state_dict(self, sd):
+        layout = [int(p.numel()) for p in self.params]
+        if sd.get("numels") is not None and list(sd["numels"]) != layout:
+            raise ValueError("FusedAdamW.load_state_dict: the checkpoint was written for a different set of trainable parameters "
+                             f"({len(sd['numels'])} segments vs {len(layout)} here, or different sizes)")
         self.step_count = int(sd["step"])
         if sd.get("exp_avg") is not None:
             if self._flat is None:
                 self._build()
+            if sd["exp_avg"].numel() != self._flat["m"].numel():
+                raise ValueError("FusedAdamW.load_state_dict: moment buffers do not match the flat layout")
             self._flat["m"].copy_(sd["exp_avg"])
             self._flat["v"].copy_(sd["exp_avg_sq"])
+            if sd.get("seg_step") is not None:
+                self._flat["seg_step"].copy_(sd["seg_step"])
+            else:                           # checkpoints written before per-parameter counts existed
+                self._flat["seg_step"].fill_(self.step_count)

@@ -139,25 +139,38 @@ def sft_loss(transformer, scheduler, b: Batch, noise: torch.Tensor, timesteps: t
 
 
 def sft_step(transformer, scheduler, optimizer, b: Batch, generator: Optional[torch.Generator] = None,
-             use_rope: bool = False, is_ofs_embed: bool = False, data_parallel: bool = False):
-    """One optimizer step (:1005-1104).  ``optimizer`` is ``orv_amd.optim.FusedAdamW`` (global-norm clip inside, on
-    device).  With ``data_parallel`` the flat bf16 gradient buffer is averaged over the RCCL group in 256 MB pieces first."""
+             use_rope: bool = False, is_ofs_embed: bool = False, data_parallel: bool = False,
+             gradient_accumulation_steps: int = 1, micro_step: int = 0):
+    """One micro-batch of the loop body (:863-1107).  ``optimizer`` is ``orv_amd.optim.FusedAdamW`` (global-norm clip inside,
+    on device).  With ``data_parallel`` the flat bf16 gradient buffer is averaged over the RCCL group.
+
+    Gradient accumulation follows ``accelerator.accumulate`` (:863; reference default 4 micro-batches,
+    base_train.yaml ``gradient_accumulation_steps``): the loss is divided by ``gradient_accumulation_steps``
+    (``accelerator.backward``), gradients add up in ``p.grad`` and NO collective runs on the first N-1 micro-batches (DDP
+    ``no_sync``); the optimizer step, the ONE gradient exchange and ``zero_grad`` happen on the micro-batch that closes the
+    window (``(micro_step + 1) % N == 0``).  The backward-overlapped exchange needs the gradients of one backward to be
+    final when a block closes, so it is used only without accumulation; with accumulation the accumulated buffer is
+    exchanged once after the last backward (same bytes, one step later start).  The learning-rate scaling is the caller's,
+    as in the reference (:496-501 scales lr by accumulation x batch x processes when ``scale_lr``).  Returns
+    ``(loss, parts)``; ``parts["grad_norm"]`` is present on synchronising micro-batches only."""
     dev = b.video_latents.device
     noise = torch.randn(b.video_latents.shape, device=dev, dtype=torch.float32, generator=generator).to(b.video_latents.dtype)
     timesteps = torch.randint(0, scheduler.config.num_train_timesteps, (b.video_latents.shape[0],), dtype=torch.int64,
                               device=dev, generator=generator)                          # :1013-1019
     loss, parts = sft_loss(transformer, scheduler, b, noise, timesteps, use_rope, is_ofs_embed)
+    n_acc = max(1, int(gradient_accumulation_steps))
+    sync = (micro_step + 1) % n_acc == 0
     world = 1
     if data_parallel:
         import torch.distributed as dist
         world = dist.get_world_size()
-    if world > 1:        # the exchange starts inside the backward, block by block (sharding.FlatGradReducer)
+    if world > 1 and n_acc == 1:   # the exchange starts inside the backward, block by block (sharding.FlatGradReducer)
         transformer._dp_grad_hook = optimizer.begin_overlapped_allreduce()
     try:
-        loss.backward()
+        (loss / n_acc if n_acc > 1 else loss).backward()
     finally:
         transformer._dp_grad_hook = None
-    grad_norm = optimizer.step(average_over=world)       # finishes the exchange, averages, clips, updates
-    optimizer.zero_grad()
-    parts["grad_norm"] = grad_norm
+    if sync:
+        parts["grad_norm"] = optimizer.step(average_over=world)       # (finishes) the exchange, averages, clips, updates
+        optimizer.zero_grad()
     return loss.detach(), parts

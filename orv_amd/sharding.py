@@ -32,52 +32,6 @@ def merge_rank_results(results: Dict, wall: torch.Tensor) -> Tuple[Dict, float]:
 
 
 # ---- training: data parallel gradient all-reduce (the ONE collective of the path) ----------------------------------------
-def allreduce_gradients(params, bucket_bytes: int = 256 << 20, group=None, average: bool = True) -> int:
-    """Sum (or average) ``p.grad`` over the data-parallel group in large flat buckets.
-
-    The reference wraps the model in DDP (accelerate, `train_cogvideox_control_to_video_sft.py:750,1093`; 25 MB buckets,
-    `find_unused_parameters`).  Here gradients of one step materialise layer by layer in the hand-written backward, so
-    they are packed into few LARGE flat bf16 buckets (xGMI is point-to-point, 7 links per GPU: ring all-reduce is
-    per-link bound and wants big messages; 3.4 GB of bf16 gradients for the 2B model = 14 buckets of 256 MB) and reduced
-    with RCCL (`backend='nccl'` on ROCm).  Parameters without a gradient (frozen / unused) contribute zeros, which is what
-    DDP's ``find_unused_parameters`` amounts to.  Returns the number of collectives issued.
-    """
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return 0
-    world = dist.get_world_size(group)
-    plist = [p for p in params if p.requires_grad]
-    n_coll, bucket, size = 0, [], 0
-
-    def flush():
-        nonlocal n_coll, bucket, size
-        if not bucket:
-            return
-        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        if average:
-            flat.div_(world)
-        off = 0
-        for p in bucket:
-            n = p.numel()
-            g = flat[off:off + n].view_as(p)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-            off += n
-        n_coll += 1
-        bucket, size = [], 0
-
-    for p in plist:
-        nb = p.numel() * p.element_size()
-        if bucket and (size + nb > bucket_bytes or bucket[0].dtype != p.dtype):
-            flush()
-        bucket.append(p)
-        size += nb
-    flush()
-    return n_coll
-
-
 def allreduce_flat_(flat: torch.Tensor, chunk_elems: int = 128 * 1024 * 1024, group=None, average: bool = True) -> int:
     """In-place sum / average of ONE flat gradient buffer (``FusedAdamW``'s) over the data-parallel group, ``chunk_elems``
     elements per collective (256 MB of bf16: ring all-reduce over xGMI is per-link bound, so few large messages).

@@ -260,3 +260,41 @@ def test_modulation_tables_bwd_matches_torch(B, T, text):
     close(dcv.cpu(), ref_dcv, rtol=1e-3, afrac=1e-4)
     if text:
         close(dct.cpu(), ref_dct, rtol=1e-3, afrac=1e-4)
+
+
+def test_fused_adamw_per_parameter_step_counts_and_state_layout():
+    """A parameter that gets no gradient in some steps keeps its OWN step count (torch.optim.AdamW ``state[p]['step']``): its
+    bias correction must follow that count, not the optimizer's global one.  Also: state_dict carries the segment layout and
+    load_state_dict refuses a different trainable set."""
+    from orv_amd.optim import FusedAdamW
+    dev = _dev()
+    torch.manual_seed(1)
+    always = torch.nn.Parameter(torch.randn(3000, device=dev).to(BF))
+    sometimes = torch.nn.Parameter((0.01 * torch.randn(500, device=dev)).to(BF))   # small values: bf16 ulp << one update
+    params = [always, sometimes]
+    ref = [p.detach().float().clone().requires_grad_(True) for p in params]
+    topt = torch.optim.AdamW(ref, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=1e-3)
+    opt = FusedAdamW(params, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=1e-3, max_grad_norm=0.0)
+    for it in range(6):
+        for p, r in zip(params, ref):
+            if p is sometimes and it in (0, 1, 2, 4):       # first gradient arrives at global step 4 (its own step 1)
+                p.grad, r.grad = None, None
+                continue
+            g = (torch.randn(p.shape, device=dev) * 0.1).to(BF)
+            p.grad, r.grad = g.clone(), g.float()
+        topt.step()
+        opt.step()
+        opt.zero_grad()
+    assert opt._flat["seg_step"].tolist() == [6, 2]
+    for p, r in zip(params, ref):
+        close(p.detach().float().cpu(), r.detach().cpu(), rtol=2e-2, afrac=1e-2)
+    # a parameter's first update is exactly lr in magnitude; with the GLOBAL count (4) its bias corrections would make it
+    # 0.56 lr: a 4.4e-3 error per element, far above bf16 rounding at these magnitudes
+    assert (ref[1].detach() - sometimes.detach().float()).abs().max().item() < 1.5e-3
+    sd = opt.state_dict()
+    assert sd["numels"] == [3000, 500] and sd["seg_start"][-1] % 2048 == 0
+    opt2 = FusedAdamW([torch.nn.Parameter(p.detach().clone()) for p in params], lr=1e-2)
+    opt2.load_state_dict(sd)
+    assert torch.equal(opt2._flat["m"], opt._flat["m"]) and opt2._flat["seg_step"].tolist() == [6, 2]
+    with pytest.raises(ValueError, match="different set of trainable parameters"):
+        FusedAdamW([torch.nn.Parameter(always.detach().clone())], lr=1e-2).load_state_dict(sd)

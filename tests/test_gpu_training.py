@@ -257,3 +257,66 @@ def test_overlapped_gradient_exchange_hook_changes_nothing():
     # the same gradients reach the flat buffer on both paths (fp32 atomics in a few bias / table sums make single runs differ in
     # the last bf16 bit, so not bit-equal - and AdamW's first step would turn such a flip into +-lr)
     assert results[0].abs().sum() > 0 and rel_l2(results[1], results[0]) <= 2e-3
+
+
+def test_gaussian_sample_exact_with_injected_eps():
+    """orv_gaussian_sample against ``(mean + exp(0.5 clamp(logvar, -30, 20)) * eps) * sf`` permuted to [B,F,C,H,W], element by
+    element (DiagonalGaussianDistribution.sample x scaling factor, train...sft.py:887-895 / cogvideox_control.py:1173-1187).
+    eps = 0 makes the result ``bf16(mean * sf)``: bit-exact, which pins the gather / permute; with eps != 0 the only freedom is
+    the last bit of expf, so every element is within ONE bf16 ulp and all but a sliver are identical."""
+    from orv_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(17)
+    B, C, F, H, W = 3, 16, 5, 8, 12
+    mom = torch.randn(B, 2 * C, F, H, W, generator=g)
+    mom[:, C:] = mom[:, C:] * 12                                   # logvar beyond both clamps
+    mom = mom.to(BF)
+    sf = 1.15258426
+    mean, logvar = mom.float()[:, :C], mom.float()[:, C:].clamp(-30, 20)
+    out0 = ops.gaussian_sample(mom.to(dev), torch.zeros(B, C, F, H, W, device=dev), sf).cpu()
+    assert out0.shape == (B, F, C, H, W)
+    assert torch.equal(out0, (mean * torch.tensor(sf)).to(BF).permute(0, 2, 1, 3, 4))
+    eps = torch.randn(B, C, F, H, W, generator=g)
+    got = ops.gaussian_sample(mom.to(dev), eps.to(dev), sf).cpu()
+    want = ((mean + torch.exp(0.5 * logvar) * eps) * torch.tensor(sf)).to(BF).permute(0, 2, 1, 3, 4)
+    ulp = (got.view(torch.int16).int() - want.view(torch.int16).int()).abs()
+    assert int(ulp.max()) <= 1 and float((ulp != 0).float().mean()) < 5e-3
+
+
+def test_gradient_accumulation_window_equals_one_step():
+    """sft_step with gradient_accumulation_steps=2 on the same micro-batch twice (same RNG stream) must leave the parameters
+    exactly where ONE plain step leaves them: loss / 2 per micro-batch, gradients summed in p.grad, no optimizer step, no
+    zero_grad and no grad_norm on the first micro-batch (accelerator.accumulate, train...sft.py:863)."""
+    from orv_amd import schedulers, sft
+    from orv_amd.cogvideox_control import CogVideoXTransformer3DModelTraj
+    from orv_amd.optim import FusedAdamW
+    dev = torch.device("cuda:0")
+    cfg, extra, ins, w, outs = load_golden("fwd_actions")
+    sched = schedulers.CogVideoXDDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012,
+                                              beta_schedule="scaled_linear", prediction_type="v_prediction",
+                                              rescale_betas_zero_snr=True, snr_shift_scale=3.0, timestep_spacing="trailing")
+    g0 = torch.Generator().manual_seed(5)
+    x0 = torch.randn(2, 3, 16, 8, 12, generator=g0).to(dev, BF)
+    batch = sft.Batch(x0, torch.zeros_like(x0), ins["encoder_hidden_states"].to(dev, BF), ins["actions"].to(dev), None, None,
+                      torch.ones(3, dtype=torch.bool, device=dev), 1)
+    results = []
+    for n_acc in (1, 2):
+        m = CogVideoXTransformer3DModelTraj(**cfg)
+        m.load_state_dict(w)
+        m = m.to(dev, BF).train()
+        m.action_embed.forced_mask = torch.zeros(2, dtype=torch.bool)
+        opt = FusedAdamW(m.parameters(), lr=1e-3, betas=(0.9, 0.95), weight_decay=1e-3, max_grad_norm=1.0)
+        for micro in range(n_acc):
+            gen = torch.Generator(device=dev).manual_seed(123)         # same noise / timesteps in every micro-batch
+            before = m.transformer_blocks[0].ff.net[2].weight.detach().clone()
+            loss, parts = sft.sft_step(m, sched, opt, batch, generator=gen, gradient_accumulation_steps=n_acc, micro_step=micro)
+            if micro + 1 < n_acc:
+                assert "grad_norm" not in parts and torch.equal(m.transformer_blocks[0].ff.net[2].weight.detach(), before)
+                assert m.transformer_blocks[0].ff.net[2].weight.grad is not None
+            else:
+                assert parts["grad_norm"] > 0 and m.transformer_blocks[0].ff.net[2].weight.grad is None
+        results.append(({k: v.detach().clone() for k, v in m.state_dict().items()}, loss.item(), parts["grad_norm"]))
+    (sd1, l1, n1), (sd2, l2, n2) = results
+    assert l1 == l2 and abs(n1 - n2) <= 1e-3 * n1                  # g/2 + g/2 in bf16 = g up to one rounding
+    worst = max(((sd1[k].float() - sd2[k].float()).abs().max() / (sd1[k].float().abs().max() + 1e-6)).item() for k in sd1)
+    assert worst <= 1e-2, worst

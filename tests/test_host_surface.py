@@ -87,6 +87,40 @@ def test_vanilla_cogvideox_2b_conversion(tmp_path):
         CogVideoXTransformer3DModelTraj(**base, loaded_pretrained_model_name_or_path="THUDM/CogVideoX-2b")
 
 
+def test_same_class_checkpoint_converts_when_kwargs_add_modules(tmp_path):
+    """train...sft.py:276-283 passes extra_init_kwargs (multiview / recon_action / visual_guidance) when finetuning FROM an ORV
+    checkpoint: the strict load fails, the reference falls through to from_config(base.config, **kwargs) +
+    load_state_dict(strict=False) and, for a non-multiview source, copies transformer_blocks[i] into mv_blocks[i]
+    (cogvideox_control.py:970-1050)."""
+    cfg, _, _, w, _ = load_golden("fwd_actions")
+    src = CogVideoXTransformer3DModelTraj(**cfg)
+    src.load_state_dict(w)
+    src.save_pretrained(str(tmp_path / "transformer"))
+    m = CogVideoXTransformer3DModelTraj.from_pretrained(str(tmp_path), subfolder="transformer", torch_dtype=torch.float32,
+                                                        multiview=True, max_n_view=3, recon_action=True)
+    assert m.config.multiview and m.config.recon_action and m.action_recon is not None
+    sd = m.state_dict()
+    for k, v in w.items():                                  # everything the checkpoint holds arrives unchanged
+        assert torch.equal(sd[k], v), k
+    for i, blk in enumerate(m.mv_blocks):                   # stage-3 initialisation: attention + norm1 copied from the 3-D block
+        ref = m.transformer_blocks[i].state_dict()
+        for k, v in blk.state_dict().items():
+            if k in ref:
+                assert torch.equal(v, ref[k]), (i, k)
+        assert blk.proj_out.weight.abs().max() == 0        # zero-init stays (not in the 3-D block)
+    # only the multiview blocks train afterwards (:641-656)
+    assert all(p.requires_grad == n.startswith("mv_blocks.") for n, p in m.named_parameters())
+    # a multiview checkpoint is loaded directly next time (no copy): change an mv weight, save, reload
+    with torch.no_grad():
+        m.mv_blocks[0].attn1.to_q.weight.add_(1.0)
+    m.save_pretrained(str(tmp_path / "mv" / "transformer"))
+    m2 = CogVideoXTransformer3DModelTraj.from_pretrained(str(tmp_path / "mv"), subfolder="transformer")
+    assert torch.equal(m2.mv_blocks[0].attn1.to_q.weight, m.mv_blocks[0].attn1.to_q.weight)
+    # a shape mismatch is still an error in the conversion path
+    with pytest.raises(RuntimeError):
+        CogVideoXTransformer3DModelTraj.from_pretrained(str(tmp_path), subfolder="transformer", time_embed_dim=32)
+
+
 def test_pipeline_rejects_wrong_transformer_type():
     with pytest.raises(ValueError, match="must be of type CogVideoXTransformer3DModelTraj"):
         CogVideoXImageToVideoPipelineTraj(transformer=torch.nn.Linear(2, 2), scheduler=None)
@@ -213,3 +247,35 @@ def test_collate_matches_reference_golden(name, tmp_path):
         paths.append(f"d{vi}.pt")
     ctl = data.load_latent_controls(str(tmp_path), ["depth"], latent_depth_paths=paths)
     assert torch.equal(ctl["latents_depth"], samples[0]["latents_depth"]) and "latents_label" not in ctl
+
+
+def test_bucket_sampler_matches_reference_golden():
+    """orv_amd.data.BucketSampler yields the reference class's exact (index, ref_num, n_view) stream for a seeded `random`
+    (fixture produced by the AST-sliced reference class, oracle/gen_golden.py::bucket_sampler_case), both epochs, including
+    the reference's quirks (left-overs dropped when shuffle=False; left-over buckets carried into the next epoch)."""
+    import random
+    from orv_amd.data import BucketSampler
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "bucket_sampler.json")))
+
+    class DS:
+        resolutions = sorted(set(zip(fx["refs"], fx["views"])))
+
+        def __len__(self):
+            return len(fx["refs"])
+
+        def get_ref_nums_for_all_samples(self):
+            return list(fx["refs"])
+
+        def get_n_views_for_all_samples(self, train=True):
+            return list(fx["views"])
+
+    for c in fx["cases"]:
+        random.seed(c["seed"])
+        s = BucketSampler(DS(), batch_size=c["batch_size"], shuffle=c["shuffle"], drop_last=c["drop_last"])
+        assert [list(x) for x in s] == c["order"], c
+        assert [list(x) for x in s] == c["second_epoch"], c
+        assert len(s) == c["length"]
+        # every full batch is shape-homogeneous: what keeps the per-rank batches rectangular
+        full = c["order"][: len(c["order"]) // c["batch_size"] * c["batch_size"]] if c["drop_last"] else []
+        for i in range(0, len(full), c["batch_size"]):
+            assert len({(r, v) for _, r, v in full[i:i + c["batch_size"]]}) == 1

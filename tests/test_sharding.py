@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from orv_amd.sharding import allreduce_gradients, merge_rank_results, shard_clips
+from orv_amd.sharding import merge_rank_results, shard_clips
 
 
 def _free_port():
@@ -54,12 +54,6 @@ def _dp_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(0)
-    params = [torch.nn.Parameter(torch.zeros(n)) for n in (1000, 7, 300000, 64)]
-    frozen = torch.nn.Parameter(torch.zeros(5), requires_grad=False)
-    for i, p in enumerate(params):
-        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
-    params[1].grad = None if rank == 1 else params[1].grad            # an "unused" parameter on one rank
-    n = allreduce_gradients(params + [frozen], bucket_bytes=1 << 20)
     # the flat-buffer form used by FusedAdamW: one buffer, several collectives, averaged in place
     from orv_amd.sharding import allreduce_flat_
     flat = torch.arange(10000, dtype=torch.float32) * (rank + 1)
@@ -76,25 +70,21 @@ def _dp_worker(rank, world, port, out):
     nr = red.finish()
     if rank == 0:
         # numpy copies, not tensors: a tensor travels as a shared-memory fd that dies with this process (flaky FileNotFoundError)
-        out.put((n, [p.grad.numpy().copy() for p in params], None if frozen.grad is None else 1, nf, flat.numpy().copy(), nr,
-                 buf.numpy().copy()))
+        out.put((nf, flat.numpy().copy(), nr, buf.numpy().copy()))
     dist.destroy_process_group()
 
 
 def test_two_rank_gradient_allreduce():
-    """training's one collective: bucketed all-reduce(avg) of gradients, world_size 2 over gloo."""
+    """training's one collective: all-reduce(avg) of the flat gradient buffer (whole, and overlapped in coalesced runs),
+    world_size 2 over gloo."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     [p.start() for p in procs]
-    n, grads, frozen_grad, nf, flat, nr, buf = q.get(timeout=120)
-    grads, flat, buf = [torch.from_numpy(g) for g in grads], torch.from_numpy(flat), torch.from_numpy(buf)
+    nf, flat, nr, buf = q.get(timeout=120)
+    flat, buf = torch.from_numpy(flat), torch.from_numpy(buf)
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    assert n >= 2 and frozen_grad is None                               # 300000 floats alone exceed the 1 MiB bucket
-    want = [1.5 * 1, 0.5 * 2, 1.5 * 3, 1.5 * 4]                          # mean over ranks; missing grad counts as zero
-    for g, w in zip(grads, want):
-        assert torch.allclose(g, torch.full_like(g, w))
     assert nf == 3 and torch.allclose(flat, torch.arange(10000, dtype=torch.float32) * 1.5)
     assert nr == 2 + 1 + 2 + 4 and torch.allclose(buf, torch.arange(10000, dtype=torch.float32) * 1.5)
