@@ -1021,7 +1021,7 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
     static const GemmCand cands[] = {
         // ring = 2: the phased (8-phase, BK = 64) persistent kernel; needs an even number of K-tiles
         // (256x384 does not fit: 192 accumulator + 64 fragment registers of the 256 a wave gets at two waves per SIMD)
-        {2, 256, 256, 1.10f, 0}, {2, 256, 128, 0.90f, 0},
+        {2, 256, 256, 1.10f, 0}, {2, 256, 128, 0.80f, 0},
         // 256x384 keeps ONE fragment set (192 accumulator registers) and leans on its neighbour tiles to hide the exposed
         // prologue / epilogue: measured +8 % on QKV (765 tiles), a loss when every CU gets a single tile (N = 1920: 255)
         {1, 256, 384, 1.075f, 2}, {1, 256, 256, 1.060f, 0}, {1, 256, 192, 1.000f, 0}, {1, 256, 128, 0.885f, 0},

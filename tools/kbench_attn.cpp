@@ -5,7 +5,7 @@
 #include <vector>
 #include <cstring>
 #include "../include/orv_mi355.h"
-int main(int argc,char**argv){ int B=argc>1?atoi(argv[1]):4, S=3226, H=30; int s_pad=(S+63)/64*64; size_t n=(size_t)B*S*3*H*64;
+int main(int argc,char**argv){ int B=argc>1?atoi(argv[1]):4, S=argc>2?atoi(argv[2]):3226, H=argc>3?atoi(argv[3]):30; int s_pad=(S+63)/64*64; size_t n=(size_t)B*S*3*H*64;
   std::vector<uint16_t> h(n); for(size_t i=0;i<n;i++){ float f=((rand()&0xffff)/32768.f-1.f); uint32_t u; memcpy(&u,&f,4); h[i]=u>>16; }
   uint16_t *qkv,*vT,*out; hipMalloc(&qkv,n*2); hipMalloc(&vT,(size_t)B*H*64*s_pad*2); hipMalloc(&out,(size_t)B*S*H*64*2); hipMemcpy(qkv,h.data(),n*2,hipMemcpyHostToDevice); hipMemset(vT,0,(size_t)B*H*64*s_pad*2);
   float premul = getenv("FUSED") ? 0.125f*1.4426950408889634f : 1.0f; float sc = getenv("FUSED") ? 1.0f/1.4426950408889634f : 0.125f;
