@@ -125,6 +125,33 @@ def ranks_seen(world, dev):
     return int(t.item())
 
 
+def vae_decode_leg(latents, dev, loop_wall, steps, world, B, barrier):
+    """SURVEY §8(f) rank 1, reported BESIDE the headline (never inside `value`): the MI355X VAE (orv_amd.vae, real 2B geometry,
+    random weights) decodes the B clips [B,16,5,40,60] -> [B,3,17,320,480]; frames/s of a whole 50-step sample including it =
+    17 B / (50 x step time + decode time)."""
+    from orv_amd.vae import AutoencoderKLCogVideoX
+    torch.manual_seed(1)
+    with torch.device(dev):
+        vae = AutoencoderKLCogVideoX()
+    g = torch.Generator(device=dev).manual_seed(1)
+    for p in vae.parameters():
+        if p.ndim > 1:
+            p.data.normal_(0, 1.0 / (p[0].numel() ** 0.5), generator=g)
+    vae = vae.to(torch.bfloat16).eval()
+    z = (latents.permute(0, 2, 1, 3, 4) / 1.15258426).contiguous()            # decode_latents layout (:1476-1479)
+    vae.decode(z[:1])
+    barrier()
+    t0 = time.perf_counter()
+    out = vae.decode(z).sample
+    barrier()
+    dt = time.perf_counter() - t0
+    assert out.shape == (B, 3, 17, 320, 480) and torch.isfinite(out.float()).all()
+    step_s = loop_wall / steps
+    return {"ms_per_clip": round(1e3 * dt / B, 2), "parity": "unpinned (oracle/vae.py restates diffusers; no reference fixture)",
+            "frames_per_sec_50_steps_incl_decode": round(17.0 * world * B / (50 * step_s + dt), 3),
+            "frames_per_sec_50_steps_excl_decode": round(17.0 * world * B / (50 * step_s), 3)}
+
+
 def train_mode(args, model, latents, image_latents, prompt, actions, sched, dev, rank, world):
     """BASELINE configs[2]: CogVideoX-2B SFT step (train_cogvideox_control_to_video_sft.py:1005-1104), B clips per GPU, bf16
     params/grads, data parallel: forward+backward through the HIP kernels, ONE bucketed RCCL all-reduce of the gradients,
@@ -226,6 +253,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the transformer forward from a HIP graph (B=1 latency); "
                                                          "the per-kernel roofline needs the eager path and is omitted")
     ap.add_argument("--cpu-baseline-layers", type=int, default=6)
+    ap.add_argument("--no-vae", action="store_true", help="skip the VAE-decode leg (frames/s including decode)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch the ranks, rendezvous (gloo, no GPU work), print the ranks seen and exit: checks the launcher")
     args = ap.parse_args()
@@ -307,6 +335,9 @@ def main():
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
     seen = ranks_seen(world, dev)
+    vae_leg = None
+    if not args.no_vae and args.layers == 30:
+        vae_leg = vae_decode_leg(lat, dev, wall, args.steps, world, B, barrier)
 
     if rank == 0:
         S = 226 + 3000
@@ -371,6 +402,7 @@ def main():
                 "unit": "TFLOP/s", "frac": round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "launches": dom["launches"], "avg_ms": dom["avg_ms"]},
             "kernels": kernels[:8],
+            "vae_decode": vae_leg,
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = max(1, (os.cpu_count() or 2) // 2)

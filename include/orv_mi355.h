@@ -257,6 +257,28 @@ int orv_sched_step(const void* x, const void* v_c, const void* v_u, float guidan
 int orv_gaussian_sample(const void* moments, const float* eps, void* out, int B, int C, int F, int HW, float scale,
                         void* stream);
 
+/* -- VAE: AutoencoderKLCogVideoX decode / encode, reference call sites
+ *    orv/models/cogvideox_control.py:1476-1479 (decode_latents) and :1161-1166 (vae.encode of the reference frame); the
+ *    arithmetic is diffusers' (absent: parity unpinned, oracle/vae.py).  Activations are channels-last bf16 [B,T,H,W,C]. -- */
+/* Patch matrix of a causal 3-D / per-frame 2-D convolution for orv_gemm_bf16: dst[mc, Kpad] rows for voxels [m0, m0+mc) of the
+ * [B*T*H*W] output grid, column = tap * C + channel (tap = (dt*kh + dy)*kw + dx), tail columns zero.  Folded into the gather:
+ * replicate-first-frame temporal padding (CogVideoXCausalConv3d), zero spatial padding (pad_lo in front), spatial stride 1|2,
+ * nearest x2 upsampling of the source in H,W (ups_s) and in T (ups_t: 1 = every frame doubled, 2 = first frame kept).
+ * t_shift = frames of temporal context the caller prepended to src (the conv_cache diffusers carries from one frame batch to
+ * the next): output frame t reads source frames t + t_shift - (kt-1) + dt; with 0 the first frame is replicated instead. */
+int orv_vae_im2col(const void* src, void* dst, int B, int Ts, int Hs, int Ws, int C, int T, int H, int W, int kt, int kh, int kw,
+                   int stride, int pad_lo, int ups_s, int ups_t, int t_shift, int Kpad, long m0, long mc, void* stream);
+/* GroupNorm statistics: sums[B, G, 2] = (sum, sum of squares) of x[B, N, C] per group, fp32, no atomics (bit-reproducible).
+ * scratch: orv_vae_groupnorm_scratch(B, N, C, G) floats. */
+long orv_vae_groupnorm_scratch(int B, long N, int C, int G);
+int orv_vae_groupnorm_stats(const void* x, float* sums, float* scratch, int B, long N, int C, int G, void* stream);
+/* out = act(GroupNorm(x) [* zy[z(v)] + zb[z(v)]]): affine GroupNorm from `sums`, CogVideoXSpatialNorm3D modulation by
+ * conv_y(zq) / conv_b(zq) given at LATENT resolution [B,Tz,hz,wz,C] and looked up by F.interpolate(nearest) index rules
+ * (first frame of an odd-length clip apart), optional SiLU.  zy == zb == NULL: plain GroupNorm. */
+int orv_vae_norm_apply(const void* x, void* out, const float* sums, const void* gamma, const void* beta, const void* zy,
+                       const void* zb, int B, int T, int H, int W, int C, int G, int Tz, int hz, int wz, float eps, int silu_act,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,6 +84,10 @@ SIGNATURES = {
     "orv_sched_step": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                c_float, c_float, c_float, c_float, c_float, c_float, c_long, c_void_p]),
     "orv_gaussian_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "orv_vae_im2col": (c_int, [c_void_p, c_void_p] + [c_int] * 17 + [c_long, c_long, c_void_p]),
+    "orv_vae_groupnorm_scratch": (c_long, [c_int, c_long, c_int, c_int]),
+    "orv_vae_groupnorm_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_void_p]),
+    "orv_vae_norm_apply": (c_int, [c_void_p] * 7 + [c_int] * 9 + [c_float, c_int, c_void_p]),
 }
 
 _lib = None

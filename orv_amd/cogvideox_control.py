@@ -863,13 +863,13 @@ class CogVideoXImageToVideoPipelineTraj:
     ``from_pretrained`` / ``save_pretrained`` / ``to`` / ``__call__(image=<PIL | tensor>, prompt=<str>, negative_prompt=...,
     output_type='pil' | 'latent' | 'pt' | 'np')`` / ``.scheduler`` / ``.vae`` / ``.text_encoder`` / ``.transformer``.
 
-    Built here (MI355X): ``prepare_latents`` (:1115-1225) and the denoise loop (:1402-1473).  The VAE and T5 arithmetic are
-    SURVEY §8(f) rows outside this build: the pipeline DELEGATES to whatever ``vae`` / ``text_encoder`` / ``tokenizer``
-    objects it holds, with exactly the calls the reference and its diffusers base class make (``vae.encode(x).latent_dist
-    .sample(generator)``, ``vae.decode(z).sample``, ``tokenizer(prompt, padding='max_length', ...)``,
-    ``text_encoder(ids)[0]``), so diffusers' ``AutoencoderKLCogVideoX`` and transformers' ``T5EncoderModel`` drop in.  Without
-    them, pass pre-encoded latents / ``prompt_embeds`` and ``output_type='latent'`` (what the reference's dataset cache
-    provides)."""
+    Built here (MI355X): ``prepare_latents`` (:1115-1225), the denoise loop (:1402-1473) and - SURVEY §8(f) rank 1 - the VAE
+    (``orv_amd.vae.AutoencoderKLCogVideoX``, parity unpinned).  T5 is outside this build.  The pipeline DELEGATES to whatever
+    ``vae`` / ``text_encoder`` / ``tokenizer`` objects it holds with exactly the calls the reference and its diffusers base
+    class make (``vae.encode(x).latent_dist.sample(generator)``, ``vae.decode(z).sample``, ``tokenizer(prompt,
+    padding='max_length', ...)``, ``text_encoder(ids)[0]``), so diffusers' own ``AutoencoderKLCogVideoX`` and transformers'
+    ``T5EncoderModel`` drop in as well.  Without them, pass pre-encoded latents / ``prompt_embeds`` and
+    ``output_type='latent'`` (what the reference's dataset cache provides)."""
 
     config_name = "model_index.json"
 
@@ -913,8 +913,9 @@ class CogVideoXImageToVideoPipelineTraj:
         write, train...sft.py:1184-1199): ``transformer/`` through ``CogVideoXTransformer3DModelTraj.from_pretrained`` (ORV
         or vanilla CogVideoX weights), ``scheduler/scheduler_config.json`` into this package's scheduler of the recorded
         class.  Components passed as keyword arguments win (inference_control_to_video.py:80-84 passes ``transformer=``).
-        ``vae`` / ``text_encoder`` / ``tokenizer`` are not built here: supply the objects; a T5 under ``text_encoder/`` +
-        ``tokenizer/`` is loaded through ``transformers`` when that package is importable."""
+        A ``vae/`` folder is loaded into ``orv_amd.vae.AutoencoderKLCogVideoX`` (diffusers' key names); a T5 under
+        ``text_encoder/`` + ``tokenizer/`` is loaded through ``transformers`` when that package is importable; otherwise supply
+        the objects."""
         path = str(pretrained_model_name_or_path)
         index = {}
         ipath = os.path.join(path, cls.config_name)
@@ -937,6 +938,9 @@ class CogVideoXImageToVideoPipelineTraj:
                 scheduler = sched_cls.from_config(scfg)
             else:
                 raise OSError(f"{path} has no scheduler/scheduler_config.json: pass scheduler=")
+        if vae is None and os.path.exists(os.path.join(path, "vae", "config.json")):
+            from .vae import AutoencoderKLCogVideoX            # the MI355X VAE (parity unpinned)
+            vae = AutoencoderKLCogVideoX.from_pretrained(path, subfolder="vae", torch_dtype=torch_dtype)
         if text_encoder is None and os.path.isdir(os.path.join(path, "text_encoder")):
             try:
                 from transformers import T5EncoderModel
@@ -1062,12 +1066,11 @@ class CogVideoXImageToVideoPipelineTraj:
                              f" {negative_prompt_embeds.shape}.")
 
     def decode_latents(self, latents: torch.Tensor) -> torch.Tensor:
-        """Hands the latents to the CALLER-SUPPLIED VAE exactly as the base diffusers pipeline does (``[B,F,C,h,w] ->
-        [B,C,F,h,w]``, divided by the VAE scaling factor, ``vae.decode(...).sample``; the arithmetic of the decode itself is
-        the VAE object's, SURVEY §8f rank 1, out of scope here)."""
+        """Hands the latents to the attached VAE exactly as the base diffusers pipeline does (``[B,F,C,h,w] -> [B,C,F,h,w]``,
+        divided by the VAE scaling factor, ``vae.decode(...).sample``)."""
         if self.vae is None or not hasattr(self.vae, "decode"):
-            raise NotImplementedError("VAE decode is a SURVEY §8(f) next row: pass a `vae` object (e.g. diffusers' "
-                                      "AutoencoderKLCogVideoX) or use output_type='latent'")
+            raise NotImplementedError("VAE decode needs the pipeline's `vae` object (orv_amd.vae.AutoencoderKLCogVideoX or "
+                                      "diffusers' class): attach one or use output_type='latent'")
         z = latents.permute(0, 2, 1, 3, 4) / self.vae_scaling_factor_image
         out = self.vae.decode(z)
         return getattr(out, "sample", out)

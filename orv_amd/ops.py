@@ -320,3 +320,27 @@ def qkv_prep_bwd(qkv_raw, dqkv, gq, gk, rope, dgq, dbq, dgk, dbk, B, S, H, n_tex
     scratch = torch.empty(nblk * 256, dtype=torch.float32, device=dqkv.device)
     check(lib().orv_qkv_prep_bwd(_p(qkv_raw), _p(dqkv), _p(gq), _p(gk), _p(cos), _p(sin), _p(dgq), _p(dbq), _p(dgk), _p(dbk),
                                  _p(scratch), B, S, H, n_text, float(eps), _stream()), "orv_qkv_prep_bwd")
+
+
+# ---- VAE building blocks (vae.hip): channels-last activations [B, T, H, W, C] ----
+def vae_im2col(src, dst, B, Ts, Hs, Ws, C, T, H, W, kt, kh, kw, stride, pad_lo, ups_s, ups_t, t_shift, Kpad, m0, mc):
+    _need(src, BF16, "src"), _need(dst, BF16, "dst")
+    check(lib().orv_vae_im2col(_p(src), _p(dst), B, Ts, Hs, Ws, C, T, H, W, kt, kh, kw, stride, pad_lo, int(ups_s), int(ups_t),
+                               int(t_shift), Kpad, int(m0), int(mc), _stream()), "orv_vae_im2col")
+    return dst
+
+
+def vae_groupnorm_stats(x, B, N, C, G):
+    """-> sums fp32 [B, G, 2] (sum, sum of squares per group), deterministic."""
+    _need(x, BF16, "x")
+    sums = torch.empty(B, G, 2, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(lib().orv_vae_groupnorm_scratch(B, int(N), C, G), dtype=torch.float32, device=x.device)
+    check(lib().orv_vae_groupnorm_stats(_p(x), _p(sums), _p(scratch), B, int(N), C, G, _stream()), "orv_vae_groupnorm_stats")
+    return sums
+
+
+def vae_norm_apply(x, out, sums, gamma, beta, zy, zb, B, T, H, W, C, G, Tz, hz, wz, eps, silu):
+    _need(x, BF16, "x"), _need(out, BF16, "out"), _need(gamma, BF16, "gamma"), _need(beta, BF16, "beta")
+    check(lib().orv_vae_norm_apply(_p(x), _p(out), _p(sums), _p(gamma), _p(beta), _p(zy), _p(zb), B, T, H, W, C, G, Tz, hz, wz,
+                                   float(eps), int(bool(silu)), _stream()), "orv_vae_norm_apply")
+    return out

@@ -289,7 +289,7 @@ def test_pipeline_hands_latents_to_a_caller_supplied_vae():
     want = ((lat.permute(0, 2, 1, 3, 4).float() / 2.0 * 3) / 2 + 0.5).clamp(0, 1).permute(0, 2, 1, 3, 4)
     assert vid.shape == (b, 3, 16, 8, 12) and torch.allclose(vid.float(), want, atol=1e-2)
     bare = CogVideoXImageToVideoPipelineTraj(transformer=m, scheduler=schedulers.CogVideoXDDIMScheduler(**kw))
-    with pytest.raises(NotImplementedError, match="VAE decode"):
+    with pytest.raises(NotImplementedError, match="VAE decode needs"):
         bare(latents=lat0.clone(), output_type="pt", **args)
 
 
