@@ -33,6 +33,11 @@ CFG_2B = dict(num_attention_heads=30, attention_head_dim=64, in_channels=32, out
               text_embed_dim=4096, num_layers=30, sample_width=60, sample_height=40, sample_frames=17, patch_size=2,
               max_text_seq_length=226, modulate_encoder_hidden_states=True,
               loaded_pretrained_model_name_or_path="THUDM/CogVideoX-2b")
+# BASELINE configs[4]: CogVideoX1.5-5B-I2V (config/traj_image_5b_finetune.yaml:15) on DROID 256x384x29f clips
+CFG_5B = dict(num_attention_heads=48, attention_head_dim=64, in_channels=32, out_channels=16, time_embed_dim=512,
+              text_embed_dim=4096, num_layers=42, sample_width=48, sample_height=32, sample_frames=29, patch_size=2, patch_size_t=2,
+              ofs_embed_dim=512, use_rotary_positional_embeddings=True, max_text_seq_length=226,
+              modulate_encoder_hidden_states=True, loaded_pretrained_model_name_or_path="THUDM/CogVideoX1.5-5b-I2V")
 SCHED = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
              clip_sample=False, set_alpha_to_one=True, prediction_type="v_prediction", rescale_betas_zero_snr=True,
              snr_shift_scale=3.0, timestep_spacing="trailing")
@@ -44,13 +49,13 @@ def flops_per_sample(cfg, S):
     return L * (24 * S * D * D + 4 * S * S * D)
 
 
-def synthetic_inputs(B, dev, dtype):
+def synthetic_inputs(B, dev, dtype, frames=5, h=40, w=60):
     g = torch.Generator().manual_seed(42)
-    latents = torch.randn(B, 5, 16, 40, 60, generator=g)
-    image_latents = torch.zeros(B, 5, 16, 40, 60)
-    image_latents[:, 0] = torch.randn(B, 16, 40, 60, generator=g) * 1.15258426
+    latents = torch.randn(B, frames, 16, h, w, generator=g)
+    image_latents = torch.zeros(B, frames, 16, h, w)
+    image_latents[:, 0] = torch.randn(B, 16, h, w, generator=g) * 1.15258426
     prompt = torch.randn(B, 226, 4096, generator=g) * 0.2
-    actions = torch.randn(B, 16, 7, generator=g) * torch.tensor([20.0] * 6 + [1.0])
+    actions = torch.randn(B, 4 * (frames - 1), 7, generator=g) * torch.tensor([20.0] * 6 + [1.0])
     actions[..., 6].clamp_(0, 1)
     return (latents.to(dev, dtype), image_latents.to(dev, dtype), prompt.to(dev, dtype), actions.to(dev))
 
@@ -105,14 +110,30 @@ def cpu_baseline(cfg, layers, threads):
     e = torch.randn(1, 226, 4096, generator=g) * 0.2
     a = torch.randn(1, 16, 7, generator=g)
     t = torch.tensor([500])
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        dit.dit_forward(sd, c, x, e, t, actions=a, is_mask=torch.zeros(1, dtype=torch.bool))
-        dt = time.perf_counter() - t0
-    per_step = dt * 30.0 / layers
+
+    def timed(n_layers, n_threads, dtype):
+        torch.set_num_threads(n_threads)
+        keep = lambda k: not k.startswith("transformer_blocks.") or int(k.split(".")[1]) < n_layers
+        w = {k: v.to(dtype) for k, v in sd.items() if keep(k)}
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            dit.dit_forward(w, {**cfg, "num_layers": n_layers}, x.to(dtype), e.to(dtype), t, actions=a.to(dtype),
+                            is_mask=torch.zeros(1, dtype=torch.bool))
+            d = time.perf_counter() - t0
+        return d, d * 30.0 / n_layers
+
+    dt, per_step = timed(layers, threads, torch.float32)
+    # bf16 beside fp32, and 8 threads beside the host's own count (the build container has 8 cores)
+    dt_bf, per_bf = timed(layers, threads, torch.bfloat16)
+    small = max(1, layers // 3)
+    dt_8, per_8 = timed(small, min(8, threads), torch.float32)
+    torch.set_num_threads(threads)
     return {"value": 1.0 / per_step, "unit": "denoise-steps/s", "cores": threads, "kind": "port",
             "sample": f"1 clip x 1 step, fp32 eager PyTorch oracle, {layers}/30 blocks timed ({dt:.2f} s) and scaled to 30",
-            "s_per_step": per_step}
+            "s_per_step": per_step,
+            "variants": [
+                {"dtype": "bf16", "cores": threads, "s_per_step": per_bf, "sample": f"{layers}/30 blocks ({dt_bf:.2f} s)"},
+                {"dtype": "f32", "cores": min(8, threads), "s_per_step": per_8, "sample": f"{small}/30 blocks ({dt_8:.2f} s)"}]}
 
 
 def ranks_seen(world, dev):
@@ -152,7 +173,7 @@ def vae_decode_leg(latents, dev, loop_wall, steps, world, B, barrier):
             "frames_per_sec_50_steps_excl_decode": round(17.0 * world * B / (50 * step_s), 3)}
 
 
-def train_mode(args, model, latents, image_latents, prompt, actions, sched, dev, rank, world):
+def train_mode(args, model, latents, image_latents, prompt, actions, sched, dev, rank, world, cfg=None):
     """BASELINE configs[2]: CogVideoX-2B SFT step (train_cogvideox_control_to_video_sft.py:1005-1104), B clips per GPU, bf16
     params/grads, data parallel: forward+backward through the HIP kernels, ONE bucketed RCCL all-reduce of the gradients,
     global-norm clip + fused AdamW.  value = trained clips per second (all GPUs)."""
@@ -166,10 +187,14 @@ def train_mode(args, model, latents, image_latents, prompt, actions, sched, dev,
     batch = sft.Batch(latents, image_latents, prompt, actions, None, None,
                       torch.ones(latents.shape[1], dtype=torch.bool, device=dev), 1)
 
+    is5b = cfg is not None and cfg.get("patch_size_t") is not None
+    if getattr(args, "grad_ckpt", False):
+        model.enable_gradient_checkpointing()       # accepted; nothing is recomputed here (all activations stay in HBM)
+
     def step():
         # orv_amd.sft.sft_step = train script :1005-1104 (noise + timestep draw, add_noise, forward, x0 loss, backward,
         # gradient all-reduce when world > 1, global-norm clip, fused AdamW)
-        return sft.sft_step(model, sched, opt, batch, generator=g, data_parallel=world > 1)[0]
+        return sft.sft_step(model, sched, opt, batch, generator=g, data_parallel=world > 1, use_rope=is5b, is_ofs_embed=is5b)[0]
 
     def barrier():
         torch.cuda.synchronize()
@@ -191,7 +216,9 @@ def train_mode(args, model, latents, image_latents, prompt, actions, sched, dev,
         wall = float(w.item())
     seen = ranks_seen(world, dev)
     if rank == 0:
-        fl = 3.0 * flops_per_sample({**CFG_2B, "num_layers": args.layers}, 3226)
+        c_ = cfg or {**CFG_2B, "num_layers": args.layers}
+        S_ = 226 + (latents.shape[1] // (c_.get("patch_size_t") or 1)) * (latents.shape[3] // 2) * (latents.shape[4] // 2)
+        fl = 3.0 * flops_per_sample(c_, S_)
         value = world * B * args.steps / wall
         print(json.dumps({
             "metric": "train-clips/sec", "value": round(value, 3), "unit": "clips/s (SFT step: fwd+bwd+allreduce+AdamW)",
@@ -199,9 +226,13 @@ def train_mode(args, model, latents, image_latents, prompt, actions, sched, dev,
             "ms_per_step": round(1e3 * wall / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "achieved_tflops_attn_ffn": round(value * fl / 1e12, 1), "final_loss": float(loss),
-            "config": {"workload": "configs[2]: CogVideoX-2B SFT step, 320x480x17f latents, bf16 params+grads, DP",
-                       "batch_per_gpu": B, "num_layers": args.layers, "parallelism": f"dp{world} (one RCCL all-reduce/step)",
-                       "valid": args.layers == 30}}), flush=True)
+            "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+            "config": {"workload": ("configs[4]: CogVideoX1.5-5B SFT step, DROID 256x384x29f latents [B,8,16,32,48], p_t=2, RoPE, "
+                                    "ofs, bf16 params+grads, all activations resident (no recompute)") if is5b else
+                                   "configs[2]: CogVideoX-2B SFT step, 320x480x17f latents, bf16 params+grads, DP",
+                       "batch_per_gpu": B, "num_layers": c_["num_layers"], "seq_len": S_,
+                       "parallelism": f"dp{world} (one RCCL all-reduce/step)",
+                       "valid": c_["num_layers"] == (42 if is5b else 30)}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -253,6 +284,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the transformer forward from a HIP graph (B=1 latency); "
                                                          "the per-kernel roofline needs the eager path and is omitted")
     ap.add_argument("--cpu-baseline-layers", type=int, default=6)
+    ap.add_argument("--model", choices=["2b", "5b"], default="2b",
+                    help="2b = the headline (BASELINE configs[1]/[2]); 5b = configs[4] (CogVideoX1.5-5B, DROID 256x384x29f, p_t=2, "
+                         "RoPE, ofs) - train mode only")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE-decode leg (frames/s including decode)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch the ranks, rendezvous (gloo, no GPU work), print the ranks seen and exit: checks the launcher")
@@ -284,8 +318,16 @@ def main():
     from orv_amd._lib import check, lib
     check(lib().orv_device_check(local), "orv_device_check")
 
-    cfg = {**CFG_2B, "num_layers": args.layers}
     B = args.batch
+    if args.model == "5b":
+        assert args.mode == "train", "--model 5b is the configs[4] training line (use --mode train)"
+        cfg = {**CFG_5B, "num_layers": 42 if args.layers == 30 else args.layers}
+        model = build_model(cfg, dev)
+        model.action_embed.forced_mask = torch.zeros(B, dtype=torch.bool)
+        latents, image_latents, prompt, actions = synthetic_inputs(B, dev, torch.bfloat16, frames=8, h=32, w=48)
+        sched = schedulers.CogVideoXDDIMScheduler(**{**SCHED, "snr_shift_scale": 1.0})
+        return train_mode(args, model, latents, image_latents, prompt, actions, sched, dev, rank, world, cfg=cfg)
+    cfg = {**CFG_2B, "num_layers": args.layers}
     model = build_model(cfg, dev)
     model.action_embed.forced_mask = torch.zeros(B, dtype=torch.bool)       # is_mask forced False
     latents, image_latents, prompt, actions = synthetic_inputs(B, dev, torch.bfloat16)

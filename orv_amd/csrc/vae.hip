@@ -102,13 +102,21 @@ __global__ __launch_bounds__(256) void vae_gn_stats_kernel(const bf16_t* __restr
         o[0] = ts; o[1] = tq;
     }
 }
-__global__ void vae_gn_reduce_kernel(const float* __restrict__ scratch, float* __restrict__ sums, int nblk, int G2) {
-    const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < G2; i += blockDim.x) {
-        float t = 0.f;
-        for (int k = 0; k < nblk; ++k) t += scratch[((long)b * nblk + k) * G2 + i];
-        sums[(long)b * G2 + i] = t;
+// sums[b, i] = sum over blocks of scratch[b, blk, i]: one workgroup per (b, i), 256 threads stride over the blocks, fixed-order
+// LDS tree - deterministic and parallel (a full-resolution clip has ~10^4 block partials per batch element)
+__global__ __launch_bounds__(256) void vae_gn_reduce_kernel(const float* __restrict__ scratch, float* __restrict__ sums, int nblk,
+                                                            int G2) {
+    __shared__ float red[256];
+    const int b = blockIdx.y, i = blockIdx.x;
+    float t = 0.f;
+    for (int k = threadIdx.x; k < nblk; k += 256) t += scratch[((long)b * nblk + k) * G2 + i];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
     }
+    if (threadIdx.x == 0) sums[(long)b * G2 + i] = red[0];
 }
 
 struct NormArgs {
@@ -200,7 +208,7 @@ extern "C" int orv_vae_groupnorm_stats(const void* x, float* sums, float* scratc
     const long nblk = (N + vpb - 1) / vpb;
     hipLaunchKernelGGL(vae_gn_stats_kernel, dim3((unsigned)nblk, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, scratch, N,
                        C, G, vpb);
-    hipLaunchKernelGGL(vae_gn_reduce_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, scratch, sums, (int)nblk, 2 * G);
+    hipLaunchKernelGGL(vae_gn_reduce_kernel, dim3(2 * G, B), dim3(256), 0, (hipStream_t)stream, scratch, sums, (int)nblk, 2 * G);
     return orv_check_launch("orv_vae_groupnorm_stats");
 }
 

@@ -320,3 +320,72 @@ def test_gradient_accumulation_window_equals_one_step():
     assert l1 == l2 and abs(n1 - n2) <= 1e-3 * n1                  # g/2 + g/2 in bf16 = g up to one rounding
     worst = max(((sd1[k].float() - sd2[k].float()).abs().max() / (sd1[k].float().abs().max() + 1e-6)).item() for k in sd1)
     assert worst <= 1e-2, worst
+
+
+def test_full_width_5b_layer_gradients():
+    """CogVideoX1.5-5B widths (BASELINE configs[4]: D=3072, 48 heads, FF=12288, RoPE, p_t=2, ofs; DROID 256x384 latents
+    [1,8,32,32,48] -> S=1762), one block: the hand-written backward at the 5B shapes (3072 / 9216 / 12288-wide dgrad / wgrad
+    tilings, RoPE adjoint, p_t patch-embed adjoint) against torch autograd through the fp32 oracle."""
+    from orv_amd.cogvideox_control import CogVideoXTransformer3DModelTraj
+    from orv_amd.utils import prepare_rotary_positional_embeddings
+    dev = torch.device("cuda:0")
+    torch.manual_seed(7)
+    cfg = dict(num_attention_heads=48, attention_head_dim=64, num_layers=1, in_channels=32, out_channels=16, patch_size_t=2,
+               ofs_embed_dim=512, use_rotary_positional_embeddings=True, sample_height=32, sample_width=48, sample_frames=29,
+               modulate_encoder_hidden_states=True, loaded_pretrained_model_name_or_path="THUDM/CogVideoX1.5-5b-I2V")
+    m = CogVideoXTransformer3DModelTraj(**cfg)
+    for p in m.parameters():
+        if p.ndim >= 2:
+            p.data.normal_(0, 0.02)
+        p.data.copy_(p.data.to(BF).float())
+    rope = prepare_rotary_positional_embeddings(height=256, width=384, num_frames=8, vae_scale_factor_spatial=8, patch_size=2,
+                                                patch_size_t=2, attention_head_dim=64, device=torch.device("cpu"))
+    ins = dict(hidden_states=torch.randn(1, 8, 32, 32, 48).to(BF).float(),
+               encoder_hidden_states=(torch.randn(1, 226, 4096) * 0.2).to(BF).float(),
+               actions=torch.randn(1, 28, 7).to(BF).float(), timestep=torch.tensor([321]), rope_cos=rope[0], rope_sin=rope[1])
+    w = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    wout = torch.randn(1, 8, 16, 32, 48)
+    ref_out, ref_g = _oracle_grads(dict(m.config), w, ins, torch.zeros(1, dtype=torch.bool), wout,
+                                   {"ofs": 2.0, "num_views": 1, "training": False})
+    m = m.to(dev, BF).train()
+    m.action_embed.forced_mask = torch.zeros(1, dtype=torch.bool)
+    out = m(ins["hidden_states"].to(dev, BF), ins["encoder_hidden_states"].to(dev, BF), {"actions": ins["actions"].to(dev)},
+            ins["timestep"].to(dev), ofs=torch.full((1,), 2.0, device=dev), image_rotary_emb=(rope[0].to(dev), rope[1].to(dev)),
+            return_dict=False)[0]
+    assert rel_l2(out.detach(), ref_out) <= 2e-2
+    (out.float() * wout.to(dev)).sum().backward()
+    named = dict(m.named_parameters())
+    for k in ["transformer_blocks.0.ff.net.0.proj.weight", "transformer_blocks.0.ff.net.2.weight",
+              "transformer_blocks.0.attn1.to_q.weight", "transformer_blocks.0.attn1.to_k.weight",
+              "transformer_blocks.0.attn1.to_v.weight", "transformer_blocks.0.attn1.to_out.0.weight",
+              "transformer_blocks.0.attn1.norm_q.weight", "transformer_blocks.0.norm1.linear.weight",
+              "transformer_blocks.0.norm2.linear.weight", "patch_embed.proj.weight", "patch_embed.text_proj.weight",
+              "proj_out.weight", "time_embedding.linear_1.weight", "ofs_embedding.linear_1.weight", "action_embed.mlp.0.weight"]:
+        assert rel_l2(named[k].grad, ref_g[k]) <= 6e-2, k
+
+
+def test_gradient_checkpointing_flag_is_accepted_and_changes_nothing():
+    """The reference wraps every block in torch.utils.checkpoint when ``gradient_checkpointing`` is on
+    (cogvideox_control.py:867-899; train...sft.py:387-388) to fit 80 GB cards.  Here every activation the backward needs stays
+    resident (288 GB HBM, DESIGN.md §4 'Training step'): the flag is part of the surface, is honoured as 'nothing to recompute',
+    and must not change a single gradient bit-pattern beyond run-to-run noise."""
+    from orv_amd.cogvideox_control import CogVideoXTransformer3DModelTraj
+    dev = torch.device("cuda:0")
+    cfg, extra, ins, w, outs = load_golden("fwd_actions")
+    wout = torch.randn(outs["sample"].shape, generator=torch.Generator().manual_seed(1)).to(dev)
+    grads = []
+    for ckpt in (False, True):
+        m = CogVideoXTransformer3DModelTraj(**cfg)
+        m.load_state_dict(w)
+        m = m.to(dev, BF).train()
+        if ckpt:
+            m.enable_gradient_checkpointing()
+            assert m.gradient_checkpointing is True
+        m.action_embed.forced_mask = torch.tensor(extra["mask"])
+        out = m(ins["hidden_states"].to(dev, BF), ins["encoder_hidden_states"].to(dev, BF), {"actions": ins["actions"].to(dev)},
+                ins["timestep"].to(dev), return_dict=False)[0]
+        (out.float() * wout).sum().backward()
+        grads.append({n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys()
+    for n in grads[0]:
+        assert rel_l2(grads[1][n], grads[0][n]) <= 2e-3, n
