@@ -399,7 +399,7 @@ def main():
                 flop, name = 2.0 * M * N * K, f"{sym} M={M} N={N} K={K}"
             else:
                 _, b, s, h = key
-                flop, name = 4.0 * b * h * s * s * 64, f"attn_fwd_v1_kernel<true, true> B={b} S={s} H={h}"
+                flop, name = 4.0 * b * h * s * s * 64, f"attn_fwd_v2_kernel<true, true> B={b} S={s} H={h}"
             avg = sum(ms) / len(ms)
             kernels.append({"kernel": name, "launches": len(ms), "avg_ms": round(avg, 4), "total_ms": round(sum(ms), 2),
                             "tflops": round(flop / avg / 1e9, 1)})

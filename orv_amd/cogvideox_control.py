@@ -10,7 +10,7 @@ forward (reference lines :715-948) runs in the hand-written HIP kernels of libor
     patch embed          orv_patchify + orv_gemm_bf16 (pos-embed add fused)    (:788)
     action embedding     orv_skinny_linear x2                                  (:805-820, components.py:47-71)
     AdaLN tables         orv_skinny_linear (SiLU + split-linear trick fused)   (:117-130, :172)
-    per block            orv_layernorm_modulate -> orv_gemm_bf16(QKV) -> orv_qkv_prep -> orv_attention_fwd
+    per block            orv_layernorm_modulate -> orv_gemm_bf16(QKV + qk LayerNorm epilogue) -> orv_attention_fwd
                          -> orv_gemm_bf16(out-proj, gated residual) -> orv_layernorm_modulate
                          -> orv_gemm_bf16(FFN1, GELU) -> orv_gemm_bf16(FFN2, gated residual)   (:394-445)
     head                 orv_layernorm_modulate x2 -> orv_gemm_bf16 -> orv_unpatchify          (:909-936)
@@ -443,8 +443,7 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             s_pad = (S + 63) // 64 * 64
             M = B * S
             e = lambda *shape, dt=BF16: torch.empty(*shape, dtype=dt, device=dev)
-            self._ws = {key: dict(x=e(M, D), xn=e(M, D), qkv=e(M, 3 * D), att=e(M, D), h=e(M, 4 * D),
-                                  vT=torch.zeros(B, H, 64, s_pad, dtype=BF16, device=dev), vis=e(B * Nv, D),
+            self._ws = {key: dict(x=e(M, D), xn=e(M, D), qkv=e(M, 3 * D), att=e(M, D), h=e(M, 4 * D), vis=e(B * Nv, D),
                                   vis2=e(B * Nv, D), s_pad=s_pad)}
         return self._ws[key]
 
@@ -524,8 +523,7 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             s_pad = (Sm + 63) // 64 * 64
             R = b * f * Sm
             e = lambda *shape: torch.empty(*shape, dtype=BF16, device=dev)
-            self._ws[key] = dict(idx=idx.view(-1), xm=e(R, D), qkv=e(R, 3 * D), att=e(R, D), s_pad=s_pad, Sm=Sm, R=R,
-                                 vT=torch.zeros(b * f, H, 64, s_pad, dtype=BF16, device=dev))
+            self._ws[key] = dict(idx=idx.view(-1), xm=e(R, D), qkv=e(R, 3 * D), att=e(R, D), s_pad=s_pad, Sm=Sm, R=R)
         return self._ws[key]
 
     def _mv_pointer_tables(self, dev):
@@ -537,11 +535,11 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         return self._mv_ptr_tables[1:]
 
     @staticmethod
-    def _qkv_projection(at, xn, qkv, vT, rope, B, S, heads, n_text, s_pad, scale, raw=None):
-        """to_q / to_k / to_v + norm_q / norm_k (+ RoPE) + V^T (:232-254): q', k', v into ``qkv``, V^T per head into ``vT``.
-        Without RoPE the qk LayerNorm and the softmax pre-multiplier (scale * log2 e, one rounding) ride in the GEMM epilogue
-        and only V is touched again (transpose); with RoPE the projection is followed by ``orv_qkv_prep``.  ``raw`` (training)
-        receives the un-normalised projection for the LayerNorm adjoint."""
+    def _qkv_projection(at, xn, qkv, rope, B, S, heads, n_text, s_pad, scale, raw=None):
+        """to_q / to_k / to_v + norm_q / norm_k (+ RoPE) (:232-254): q', k', v into ``qkv``; the attention kernel reads all three
+        in place (V through transposing LDS reads: no V^T copy).  Without RoPE the qk LayerNorm and the softmax pre-multiplier
+        (scale * log2 e, one rounding) ride in the GEMM epilogue; with RoPE the projection is followed by ``orv_qkv_prep``.
+        ``raw`` (training) receives the un-normalised projection for the LayerNorm adjoint."""
         D = heads * 64
         M = B * S
         wqkv, bqkv = at.packed_qkv()
@@ -549,11 +547,10 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         if rope is None and _FUSE_QKNORM:
             ops.gemm(xn, wqkv, bqkv, qkv, M, 3 * D, D, epilogue=4, Y=raw,
                      qknorm=(nq.weight, nq.bias, nk.weight, nk.bias, at.eps, scale * LOG2E, heads))
-            ops.head_transpose(qkv, 2 * D, vT, B, S, heads, s_pad, ld=3 * D)
         else:
             dst = qkv if raw is None else raw
             ops.gemm(xn, wqkv, bqkv, dst, M, 3 * D, D)
-            ops.qkv_prep(qkv, vT, nq.weight, nq.bias, nk.weight, nk.bias, rope, B, S, heads, n_text, s_pad, at.eps,
+            ops.qkv_prep(qkv, None, nq.weight, nq.bias, nk.weight, nk.bias, rope, B, S, heads, n_text, s_pad, at.eps,
                          q_premul=scale * LOG2E, src=raw)
 
     def _mv_block(self, blk, mv, m, x, xn, grp0, Bv, S, Nt, n_view, n_frame, rope_view=None):
@@ -567,8 +564,8 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         R, Sm, s_pad = mv["R"], mv["Sm"], mv["s_pad"]
         ops.gather_rows(xn, mv["idx"], mv["xm"], R, D)
         scale = 1.0 / math.sqrt(c.attention_head_dim)
-        self._qkv_projection(at, mv["xm"], mv["qkv"], mv["vT"], rope_view, R // Sm, Sm, heads, n_view * Nt, s_pad, scale)
-        ops.attention_fwd(mv["qkv"], mv["vT"], mv["att"], R // Sm, Sm, heads, s_pad, 1.0 / LOG2E)
+        self._qkv_projection(at, mv["xm"], mv["qkv"], rope_view, R // Sm, Sm, heads, n_view * Nt, s_pad, scale)
+        ops.attention_fwd(mv["qkv"], None, mv["att"], R // Sm, Sm, heads, s_pad, 1.0 / LOG2E)
         ops.gemm(mv["att"], at.to_out[0].weight, at.to_out[0].bias, mv["xm"], R, D, D)
         ops.gemm(mv["xm"], blk.proj_out.weight, blk.proj_out.bias, mv["att"], R, D, D)
         # '(b f) (v s) d -> (b v) (f s) d' + gated residual on the video rows only (the text output of attn1 is dropped)
@@ -592,7 +589,7 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         Nv = Tq * P
         S = Nt + Nv
         ws = self._workspace(B, S, Nv, dev)
-        x, xn, qkv, att, hbuf, vT, s_pad = ws["x"], ws["xn"], ws["qkv"], ws["att"], ws["h"], ws["vT"], ws["s_pad"]
+        x, xn, qkv, att, hbuf, s_pad = ws["x"], ws["xn"], ws["qkv"], ws["att"], ws["h"], ws["s_pad"]
 
         # 1. time (+ofs) embedding  (:762-775)
         tvec = torch.as_tensor(timestep, device=dev).reshape(-1).to(torch.float32)
@@ -711,8 +708,8 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             at = blk.attn1
             ops.layernorm_modulate(x, xn, blk.norm1.norm.weight, blk.norm1.norm.bias, m1[..., D:2 * D], m1[..., :D],
                                    mb, mg, grp, B, D, c.norm_eps)
-            self._qkv_projection(at, xn, qkv, vT, rope, B, S, heads, Nt, s_pad, scale)
-            ops.attention_fwd(qkv, vT, att, B, S, heads, s_pad, 1.0 / LOG2E)
+            self._qkv_projection(at, xn, qkv, rope, B, S, heads, Nt, s_pad, scale)
+            ops.attention_fwd(qkv, None, att, B, S, heads, s_pad, 1.0 / LOG2E)
             ops.gemm(att, at.to_out[0].weight, at.to_out[0].bias, x, M, D, D, epilogue=2, R=x, ldr=D,
                      gate=m1[..., 2 * D:], gate_b=mb, gate_g=mg, grp=grp)
             ops.layernorm_modulate(x, xn, blk.norm2.norm.weight, blk.norm2.norm.bias, m2[..., D:2 * D], m2[..., :D],

@@ -193,13 +193,170 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_v1_kernel(const AttnArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// v2: V is read IN PLACE from the packed projection as well (no V^T copy, no orv_head_transpose launch, 50 MB less traffic per
+// layer).  The V tile is staged like K ([64 keys][64 d], 128-byte rows, LDS-DMA) and the PV MFMA's A operand (V^T rows) is
+// produced by ds_read_b64_tr_b16, gfx950's transposing LDS read: within a 16-lane group lane r points at 4 consecutive
+// d of key k0 + r/4 (d block 4 (r % 4)), and lane i receives V[k0 .. k0+3][d0 + i] - four consecutive keys of its own d
+// (semantics measured with tools/probe_tr16.cpp).  Two reads (keys +0..3 and +8..11 from 4 hi) line up with the 8 accumulator
+// registers of S^T that feed the B operand, so P still goes from the softmax straight into the MFMA.  Bank conflicts: the 4
+// key rows of one read are 128 B apart, i.e. two rows per 64-byte bank quarter; the two 64-byte halves of every key row with
+// (key >> 1) & 1 are swapped (on the DMA source address, lane-linear LDS image) so the 4 rows land in 4 different quarters.
+// ---------------------------------------------------------------------------------------------------------------
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 tr_read_pair(const char* a, const char* b) {
+    const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)a);
+    const v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)b);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <bool LAZY, bool FUSED>
+__global__ __launch_bounds__(512, 4) void attn_fwd_v2_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * SLOT_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
+    const int nqt = (p.S + 255) / 256;
+    const int item = orv_xcd_item(blockIdx.x, gridDim.x);
+    const int bh = item / nqt, h = bh % p.H, b = bh / p.H;
+    const int q0 = (item % nqt) * 256 + wave * 32;
+    const int D = p.H * 64;
+    const long row0 = (long)b * p.S;
+
+    bf16x8 qf[4];
+    {
+        const int qr = min(q0 + l31, p.S - 1);
+        const bf16_t* qp = p.qkv + (row0 + qr) * p.ld + h * 64 + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+    }
+
+    // ---- staging: wave w moves K rows 8w..8w+7 and V rows 8w..8w+7 of each 64-key tile ----
+    const int srow = wave * 8 + (lane >> 3), slot = lane & 7;
+    const int kchunk = slot ^ ((srow >> 1) & 7);              // K: conflict-free image for ds_read_b128 (as the GEMM)
+    const int vchunk = slot ^ (((srow >> 1) & 1) << 2);       // V: 64-byte halves swapped on rows with (key >> 1) & 1
+    const bf16_t* kbase = p.qkv + D + h * 64 + kchunk * 8;        // + key row * ld
+    const bf16_t* vbase = p.qkv + 2 * D + h * 64 + vchunk * 8;
+    auto stage_load = [&](int s, int kv0) {
+        const long krow = (row0 + min(kv0 + srow, p.S - 1)) * p.ld;   // keys past S: a valid (finite) row; their P is 0
+        glds16(kbase + krow, smem + s * SLOT_BYTES + wave * 1024);
+        glds16(vbase + krow, smem + s * SLOT_BYTES + TILE_BYTES + wave * 1024);
+    };
+
+    f32x16 oT[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oT[i][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c = p.scale_log2;
+    const int row_off = l31 * 128;
+    // tr-read lane offsets inside the V tile: key row 4 hi + r / 4, d block g16 * 16 + 4 (r % 4), halves swapped when r >> 3
+    const int r16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int v_row = (4 * hi + (r16 >> 2)) * 128 + g16 * 32 + (r16 & 3) * 8;
+    const int v_off0 = v_row + ((r16 >> 3) << 6);             // d block 0 (d 0..31)
+    const int v_off1 = v_row + ((1 - (r16 >> 3)) << 6);       // d block 1 (d 32..63)
+
+    const int nt = (p.S + KV - 1) / KV;
+    stage_load(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) stage_load((t + 1) & 1, (t + 1) * KV);
+        const char* sK = smem + (t & 1) * SLOT_BYTES;
+        const char* sV = sK + TILE_BYTES;
+
+        f32x16 sT[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sT[kb][e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(sK + kb * 4096 + row_off + (((ks * 2 + hi) ^ sw) * 16));
+                sT[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sT[kb], 0, 0, 0);
+            }
+        }
+        if (t == nt - 1 && (p.S & (KV - 1)) != 0) {
+            const int kv0 = t * KV;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= p.S) sT[kb][r] = -INFINITY;
+                }
+        }
+        float tmax = sT[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sT[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sT[1][r]);
+        tmax = max_with_partner_half(tmax);
+        const float cc = FUSED ? 1.0f : c;
+        if (!LAZY || !__all((tmax - m_run) * cc <= RESCALE_THR)) {
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = fast_exp2((m_run - m_new) * cc);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oT[i][e] *= alpha;
+        }
+        const float mc = m_run * cc;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = FUSED ? fast_exp2(sT[kb][r] - mc) : fast_exp2(fmaf(sT[kb][r], c, -mc));
+                sT[kb][r] = pv;
+                psum += pv;
+            }
+        l_run += psum;
+
+        // O^T[db] += V^T[db rows] . P^T ; k-step kk = keys kk*16 + {0-3, 8-11} + 4 hi (the accumulator order of S^T)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            union { bf16x8 v; uint32_t u[4]; } pf;
+            const int kb = kk >> 1, r0 = (kk & 1) * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pf.u[i] = pack2bf(sT[kb][r0 + 2 * i], sT[kb][r0 + 2 * i + 1]);
+            const char* vk = sV + kk * 16 * 128;
+            const bf16x8 vf0 = tr_read_pair(vk + v_off0, vk + 8 * 128 + v_off0);
+            const bf16x8 vf1 = tr_read_pair(vk + v_off1, vk + 8 * 128 + v_off1);
+            oT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, pf.v, oT[0], 0, 0, 0);
+            oT[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, pf.v, oT[1], 0, 0, 0);
+        }
+    }
+
+    const float l_tot = sum_with_partner_half(l_run);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + l31;
+    if (q < p.S) {
+        bf16_t* op = p.out + (row0 + q) * p.ld_out + h * 64 + hi * 4;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                uint2 o;
+                o.x = pack2bf(oT[db][qd * 4 + 0] * inv, oT[db][qd * 4 + 1] * inv);
+                o.y = pack2bf(oT[db][qd * 4 + 2] * inv, oT[db][qd * 4 + 3] * inv);
+                *(uint2*)(op + db * 32 + qd * 8) = o;
+            }
+        if (p.lse && hi == 0)
+            p.lse[((long)b * p.H + h) * p.S + q] = FUSED ? (m_run + __log2f(l_tot)) * 0.6931471805599453f : m_run * p.scale + __logf(l_tot);
+    }
+}
+
 }  // namespace
 
 extern "C" int orv_attention_fwd(const void* qkv, int ld_qkv, const void* vT, void* out, int ld_out, float* lse, int B,
                                  int S, int H, int s_pad, float scale, void* stream) {
-    ORV_REQUIRE(qkv && vT && out, "orv_attention_fwd: null operand");
+    ORV_REQUIRE(qkv && out, "orv_attention_fwd: null operand");
     ORV_REQUIRE(B > 0 && S > 0 && H > 0, "orv_attention_fwd: empty problem");
-    ORV_REQUIRE(s_pad % 64 == 0 && s_pad >= S, "orv_attention_fwd: s_pad=%d must be a multiple of 64 and >= S=%d", s_pad, S);
+    ORV_REQUIRE(!vT || (s_pad % 64 == 0 && s_pad >= S), "orv_attention_fwd: s_pad=%d must be a multiple of 64 and >= S=%d", s_pad, S);
     ORV_REQUIRE(ld_qkv % 8 == 0 && ld_out % 4 == 0, "orv_attention_fwd: misaligned leading dimension");
     AttnArgs a;
     a.qkv = (const bf16_t*)qkv; a.ld = ld_qkv; a.vT = (const bf16_t*)vT; a.out = (bf16_t*)out; a.ld_out = ld_out;
@@ -209,7 +366,10 @@ extern "C" int orv_attention_fwd(const void* qkv, int ld_qkv, const void* vT, vo
     // q pre-multiplied by scale*log2(e) in orv_qkv_prep (q_premul) arrives here as scale == 1/log2(e): fused fast path
     const bool fused = fabsf(a.scale_log2 - 1.0f) < 1e-6f;
     hipStream_t st = (hipStream_t)stream;
-    if (fused) hipLaunchKernelGGL((attn_fwd_v1_kernel<true, true>), grid, dim3(512), 0, st, a);
+    if (!vT) {                       // V read in place from the packed projection (transposing LDS reads): the shipped path
+        if (fused) hipLaunchKernelGGL((attn_fwd_v2_kernel<true, true>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((attn_fwd_v2_kernel<true, false>), grid, dim3(512), 0, st, a);
+    } else if (fused) hipLaunchKernelGGL((attn_fwd_v1_kernel<true, true>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((attn_fwd_v1_kernel<true, false>), grid, dim3(512), 0, st, a);
     return orv_check_launch("orv_attention_fwd");
 }

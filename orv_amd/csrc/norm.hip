@@ -169,6 +169,17 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(const bf16_t* src, bf16_t
             }
         }
     }
+    if (!vT) {                                   // attention reads V in place (attn_fwd_v2): only the out-of-place copy remains
+        if (src != qkv)
+            for (int it = 0; it < 2; ++it) {
+                const int s = s0 + wave * 16 + it * 8 + (lane >> 3);
+                if (s < S) {
+                    const long voff = ((long)b * S + s) * ld + 2 * H * 64 + h * 64 + sub * 8;
+                    *(uint4*)(qkv + voff) = *(const uint4*)(src + voff);
+                }
+            }
+        return;
+    }
     // v tile -> LDS [token][d]
     for (int it = 0; it < 2; ++it) {
         const int tl = wave * 16 + it * 8 + (lane >> 3);
@@ -240,7 +251,7 @@ extern "C" int orv_qkv_prep(void* qkv, void* vT, const void* gq, const void* bq,
 extern "C" int orv_qkv_prep_from(const void* src, void* qkv, void* vT, const void* gq, const void* bq, const void* gk,
                                  const void* bk, const float* rope_cos, const float* rope_sin, int B, int S, int H, int n_text,
                                  int s_pad, float eps, float q_premul, void* stream) {
-    ORV_REQUIRE(src && qkv && vT, "orv_qkv_prep: null operand");
+    ORV_REQUIRE(src && qkv, "orv_qkv_prep: null operand");      // vT may be NULL: no V^T copy (attention reads V in place)
     ORV_REQUIRE(B > 0 && S > 0 && H > 0, "orv_qkv_prep: empty problem");
     ORV_REQUIRE(s_pad % 64 == 0 && s_pad >= S && s_pad == ((S + 63) / 64) * 64,
                 "orv_qkv_prep: s_pad=%d must be S=%d rounded up to 64", s_pad, S);

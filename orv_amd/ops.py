@@ -158,7 +158,9 @@ def modulation_tables(temb, action_emb, w_ptrs, b_ptrs, n_tab, B, T, E, width, t
 def qkv_prep(qkv, vT, gq, bq, gk, bk, rope: Optional[Tuple[torch.Tensor, torch.Tensor]], B, S, H, n_text, s_pad, eps,
              q_premul: float = 1.0, src=None):
     """In place on ``qkv``, or (``src`` given) out of place: reads ``src``, writes q' / k' / v to ``qkv``."""
-    _need(qkv, BF16, "qkv"), _need(vT, BF16, "vT")
+    _need(qkv, BF16, "qkv")
+    if vT is not None:
+        _need(vT, BF16, "vT")
     cos = sin = None
     if rope is not None:
         cos, sin = (_need(r.contiguous(), torch.float32, "rope") for r in rope)
@@ -203,7 +205,9 @@ def linear(x2d, W, bias=None, epilogue=0):
 
 
 def attention_fwd(qkv, vT, out, B, S, H, s_pad, scale, lse=None, ld_qkv=None, ld_out=None):
-    _need(qkv, BF16, "qkv"), _need(vT, BF16, "vT"), _need(out, BF16, "out")
+    _need(qkv, BF16, "qkv"), _need(out, BF16, "out")
+    if vT is not None:               # legacy form: pre-transposed V (attn_fwd_v1); None = V read in place (attn_fwd_v2)
+        _need(vT, BF16, "vT")
     with _timed(("attention", B, S, H)):
         check(lib().orv_attention_fwd(_p(qkv), ld_qkv or 3 * H * 64, _p(vT), _p(out), ld_out or H * 64, _p(lse), B, S,
                                       H, s_pad, float(scale), _stream()), "orv_attention_fwd")

@@ -86,7 +86,7 @@ class _AttnBufs:
     def __init__(self, B_, S_, heads, dev):
         self.s_pad = (S_ + 63) // 64 * 64
         z = lambda: torch.zeros(B_, heads, 64, self.s_pad, dtype=BF16, device=dev)
-        self.vT, self.qT, self.kT, self.doT = z(), z(), z(), z()
+        self.qT, self.kT, self.doT = z(), z(), z()
         self.nl = torch.empty(B_, heads, self.s_pad, dtype=torch.float32, device=dev)
         self.nd = torch.empty(B_, heads, self.s_pad, dtype=torch.float32, device=dev)
 
@@ -99,10 +99,10 @@ def _attn_forward(at, xn, ly, bufs, B_, S_, n_text, heads, rope, scale):
     from .cogvideox_control import CogVideoXTransformer3DModelTraj as _M
     ly.qkv_raw = torch.empty(M_, 3 * D, dtype=BF16, device=dev)       # raw projection: input of the qk-LayerNorm adjoint
     ly.qkvn = torch.empty(M_, 3 * D, dtype=BF16, device=dev)          # q' | k' | v as the attention kernels read them (kept:
-    _M._qkv_projection(at, xn, ly.qkvn, bufs.vT, rope, B_, S_, heads, n_text, bufs.s_pad, scale, raw=ly.qkv_raw)   # 148 MB/layer)
+    _M._qkv_projection(at, xn, ly.qkvn, rope, B_, S_, heads, n_text, bufs.s_pad, scale, raw=ly.qkv_raw)   # 148 MB/layer)
     ly.att = torch.empty(M_, D, dtype=BF16, device=dev)
     ly.lse = torch.empty(B_, heads, S_, dtype=torch.float32, device=dev)
-    ops.attention_fwd(ly.qkvn, bufs.vT, ly.att, B_, S_, heads, bufs.s_pad, 1.0 / LOG2E, lse=ly.lse)
+    ops.attention_fwd(ly.qkvn, None, ly.att, B_, S_, heads, bufs.s_pad, 1.0 / LOG2E, lse=ly.lse)
 
 
 def _attn_backward(at, ly, xn, datt, bufs, B_, S_, n_text, heads, rope, scale, grads, f32_to_param_grad, z32):

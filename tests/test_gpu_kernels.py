@@ -166,6 +166,12 @@ def test_qkv_prep_and_attention(B, S, H, nt, use_rope, fused):
     ops.attention_fwd(dq, vT, out, B, S, H, s_pad, 1.0 / LOG2E if fused else 0.125, lse=lse)
     close(out, ref)
     close(lse, lse_ref, rtol=2e-2, afrac=5e-3)
+    # shipped form: V read in place from the packed projection through ds_read_b64_tr_b16 (no V^T): same contraction order, so
+    # the result is bit-identical to the pre-transposed form
+    out2 = torch.full((B * S, D), float("nan"), dtype=BF, device=dev)
+    lse2 = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+    ops.attention_fwd(dq, None, out2, B, S, H, s_pad, 1.0 / LOG2E if fused else 0.125, lse=lse2)
+    assert torch.equal(out2, out) and torch.equal(lse2, lse)
 
 
 @pytest.mark.parametrize("fused", [False, True])
@@ -189,6 +195,9 @@ def test_attention_online_softmax_rescale_branch(fused):
     out = torch.empty(B * S, 64, dtype=BF, device=dev)
     ops.attention_fwd(dq, vT, out, B, S, H, s_pad, 1.0 / LOG2E if fused else 0.125)
     close(out, ref)
+    out2 = torch.empty(B * S, 64, dtype=BF, device=dev)
+    ops.attention_fwd(dq, None, out2, B, S, H, s_pad, 1.0 / LOG2E if fused else 0.125)      # V in place (shipped form)
+    assert torch.equal(out2, out)
 
 
 @pytest.mark.parametrize("pt", [None, 2])
