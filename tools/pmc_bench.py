@@ -39,8 +39,10 @@ for k in sorted(dur, key=lambda k: -sum(dur[k])):
     d = med(dur[k])
     gui = a.get("GRBM_GUI_ACTIVE", 0) / 8
     wc = a.get("SQ_WAVE_CYCLES", 0) or 1
-    fb = 2 * 1024 * med(fe[k]["FETCH_SIZE"]) if k in fe else None
-    wb = (cal or 1.0) * 1024 * med(wr[k]["WRITE_SIZE"]) if k in wr else None
+    mean = lambda v: sum(v) / len(v)
+    # traffic per launch = MEAN over the symbol's launches (all its shapes together), like bench.py's avg_ms for the symbol
+    fb = 2 * 1024 * mean(fe[k]["FETCH_SIZE"]) if k in fe else None
+    wb = (cal or 1.0) * 1024 * mean(wr[k]["WRITE_SIZE"]) if k in wr else None
     traffic[k] = {"launches": len(dur[k]), "fetch_bytes": fb, "write_bytes": wb, "total_bytes": (fb or 0) + (wb or 0)}
     rows.append(dict(kernel=k, n=len(dur[k]), us=d / 1e3, total_ms=sum(dur[k]) / 1e6, clk=gui / d if d else 0,
                      mfma=a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024 * gui) if gui else 0,
