@@ -114,6 +114,7 @@ def test_pipeline_with_generator_matches_bf16_reference(name):
                controls_or_guidances={"actions": ins["actions"].to(dev, BF)} if extra["with_actions"] else {},
                callback_on_step_end=lambda p, i, t, kw: (trace.append(kw["latents"].clone()), {})[1])
     assert len(trace) == extra["steps"]
+    print(f"[loop-err] {name}: per-step rel-L2 " + " ".join(f"{rel_l2(tr, outs[f'step{i}']):.2e}" for i, tr in enumerate(trace)))
     for i, tr in enumerate(trace):
         assert rel_l2(tr, outs[f"step{i}"]) <= 5e-2, i
     assert rel_l2(out.frames, outs["latents"]) <= 5e-2

@@ -72,7 +72,7 @@ def test_parameter_gradients_match_oracle_autograd(name):
         assert recon is not None and recon.requires_grad
         loss = loss + (recon.float() * wrec.to(dev)).sum()
     loss.backward()
-    bad = []
+    bad, errs = [], []
     gmax = max(g.norm().item() for g in ref_g.values())
     checked = 0
     for k, p in m.named_parameters():
@@ -84,8 +84,13 @@ def test_parameter_gradients_match_oracle_autograd(name):
         assert p.grad is not None, k
         err = rel_l2(p.grad, ref_g[k])
         checked += 1
+        errs.append((err, k))
         if err > 6e-2:
             bad.append((k, round(err, 4)))
+    errs.sort()
+    # the distribution inside the 6e-2 bound (DESIGN.md §1 quotes it; run with -s to see it)
+    print(f"[grad-err] {name}: n={len(errs)} median={errs[len(errs) // 2][0]:.2e} p90={errs[int(len(errs) * 0.9)][0]:.2e} "
+          f"max={errs[-1][0]:.2e} ({errs[-1][1]})")
     assert checked > 20 and not bad, bad
 
 
