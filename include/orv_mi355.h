@@ -268,6 +268,17 @@ int orv_gaussian_sample(const void* moments, const float* eps, void* out, int B,
  * the next): output frame t reads source frames t + t_shift - (kt-1) + dt; with 0 the first frame is replicated instead. */
 int orv_vae_im2col(const void* src, void* dst, int B, int Ts, int Hs, int Ws, int C, int T, int H, int W, int kt, int kh, int kw,
                    int stride, int pad_lo, int ups_s, int ups_t, int t_shift, int Kpad, long m0, long mc, void* stream);
+/* The same convolution as ONE launch, without the patch matrix (implicit GEMM): the GEMM's A operand is gathered by the LDS-DMA
+ * from the channels-last source (geometry fields as orv_vae_im2col's), W = packed weights [N, taps*C] (column = tap*C + ci),
+ * epilogue 0 (bias) or 2 (R + acc + bias: the resnet's residual add).  g->A is ignored; g->M = B*T*H*W, g->K = taps*C.
+ * Requires C % 64 == 0 (one 64-deep K-tile = 64 channels of one tap). */
+typedef struct {
+    const void* src;
+    int B, Ts, Hs, Ws, C;        /* source [B, Ts, Hs, Ws, C] bf16 */
+    int T, H, W;                 /* output voxel grid */
+    int kt, kh, kw, stride, pad_lo, ups_s, ups_t, t_shift;
+} orv_conv_t;
+int orv_conv_gemm_bf16(const orv_gemm_t* g, const orv_conv_t* c, void* stream);
 /* GroupNorm statistics: sums[B, G, 2] = (sum, sum of squares) of x[B, N, C] per group, fp32, no atomics (bit-reproducible).
  * scratch: orv_vae_groupnorm_scratch(B, N, C, G) floats. */
 long orv_vae_groupnorm_scratch(int B, long N, int C, int G);

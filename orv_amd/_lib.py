@@ -29,6 +29,11 @@ class Gemm(Structure):
                 ("qn_eps", c_float), ("qn_premul", c_float), ("qn_heads", c_int)]
 
 
+class Conv(Structure):
+    _fields_ = [("src", c_void_p)] + [(n, c_int) for n in ("B", "Ts", "Hs", "Ws", "C", "T", "H", "W", "kt", "kh", "kw", "stride",
+                                                             "pad_lo", "ups_s", "ups_t", "t_shift")]
+
+
 # name -> (restype, argtypes); every symbol include/orv_mi355.h declares
 SIGNATURES = {
     "orv_version": (c_int, []),
@@ -85,6 +90,7 @@ SIGNATURES = {
                                c_float, c_float, c_float, c_float, c_float, c_float, c_long, c_void_p]),
     "orv_gaussian_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "orv_vae_im2col": (c_int, [c_void_p, c_void_p] + [c_int] * 17 + [c_long, c_long, c_void_p]),
+    "orv_conv_gemm_bf16": (c_int, [POINTER(Gemm), POINTER(Conv), c_void_p]),
     "orv_vae_groupnorm_scratch": (c_long, [c_int, c_long, c_int, c_int]),
     "orv_vae_groupnorm_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_void_p]),
     "orv_vae_norm_apply": (c_int, [c_void_p] * 7 + [c_int] * 9 + [c_float, c_int, c_void_p]),

@@ -446,6 +446,119 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution (VAE): gemm_kernel with the A operand GATHERED by the LDS-DMA itself from a
+// channels-last activation [B, Ts, Hs, Ws, C] - no patch matrix in HBM.  Output row m = voxel (b, t, y, x); K index = tap * C +
+// channel, so one 64-deep K-tile is 64 channels of ONE tap: a 128-byte line per voxel, and the DMA piece of a lane is the line
+// of the tap-shifted source voxel (or of a 256-byte zero page when the tap falls into the zero padding).  Folded into the source
+// index exactly like orv_vae_im2col: replicate-first-frame / conv_cache temporal context, zero spatial padding, stride 2,
+// nearest x2 upsampling of the source in H, W and T.  Requires C % 64 == 0 (the 16- and 8-channel stems keep the patch matrix).
+// ---------------------------------------------------------------------------------------------------------------
+struct ConvArgs {
+    const bf16_t* src;
+    int B, Ts, Hs, Ws, C, T, H, W, kt, kh, kw, stride, pad_lo, ups_s, ups_t, t_shift;
+};
+__device__ __attribute__((aligned(256))) uint4 orv_zero_page[16];       // 256 zero bytes: source of padded taps
+
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(512) void conv_gemm_kernel(const GemmArgs p, const ConvArgs cv) {
+    constexpr int MB = BM / 128, NB = BN / 64;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_LD = BM / 64, B_LD = BN / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tm, tn;
+    tile_of_block(p, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // per DMA piece (8 rows): this lane's output voxel and its 16-byte slot of the 128-byte channel line
+    const int srow = lane >> 3, slot = lane & 7;
+    int vb[A_LD], vt[A_LD], vy[A_LD], vx[A_LD], vchunk[A_LD];
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+        const int row = (wave * A_LD + j) * 8 + srow;
+        vchunk[j] = (slot ^ ((row >> 1) & 7)) * 8;
+        long m = min((long)m0 + row, (long)p.M - 1);
+        vx[j] = (int)(m % cv.W); m /= cv.W;
+        vy[j] = (int)(m % cv.H); m /= cv.H;
+        vt[j] = (int)(m % cv.T);
+        vb[j] = (int)(m / cv.T);
+    }
+    const bf16_t* b_src[B_LD];
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+        const int row = (wave * B_LD + j) * 8 + srow;
+        b_src[j] = p.W + (long)(n0 + row) * p.ldw + (slot ^ ((row >> 1) & 7)) * 8;
+    }
+    const int cblocks = cv.C >> 6;                                    // K-tiles per tap
+    const int Hi = cv.ups_s ? cv.Hs * 2 : cv.Hs, Wi = cv.ups_s ? cv.Ws * 2 : cv.Ws;
+    constexpr int NP = A_LD + B_LD;
+    auto issue_piece = [&](int pc, int s, int ktile) {
+        if (pc < A_LD) {
+            const int tap = ktile / cblocks, c0 = (ktile - tap * cblocks) << 6;          // wave-uniform
+            const int dx = tap % cv.kw, dy = (tap / cv.kw) % cv.kh, dt = tap / (cv.kw * cv.kh);
+            int ti = vt[pc] + cv.t_shift - (cv.kt - 1) + dt;
+            ti = max(ti, 0);
+            const int yi = vy[pc] * cv.stride - cv.pad_lo + dy, xi = vx[pc] * cv.stride - cv.pad_lo + dx;
+            const bool ok = yi >= 0 && yi < Hi && xi >= 0 && xi < Wi;
+            const int ys = cv.ups_s ? yi >> 1 : yi, xs = cv.ups_s ? xi >> 1 : xi;
+            int ts = ti;
+            if (cv.ups_t == 1) ts = ti >> 1;
+            else if (cv.ups_t == 2) ts = ti == 0 ? 0 : 1 + ((ti - 1) >> 1);
+            const bf16_t* g = cv.src + ((((long)vb[pc] * cv.Ts + ts) * cv.Hs + ys) * cv.Ws + xs) * cv.C + c0 + vchunk[pc];
+            if (!ok) g = (const bf16_t*)orv_zero_page + (lane & 7) * 8;
+            glds16(g, smem + s * STAGE + (wave * A_LD + pc) * 1024);
+        } else {
+            glds16(b_src[pc - A_LD] + (long)ktile * BK, smem + s * STAGE + A_BYTES + (wave * B_LD + (pc - A_LD)) * 1024);
+        }
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
+    const int a_row_off = (wm * (BM / 4) + l31) * 128;
+    const int b_row_off = A_BYTES + (wn * (BN / 2) + l31) * 128;
+    f32x16 acc[NB][MB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < MB; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    auto read_frags = [&](const char* sbase, int ks, bf16x8 (&af)[MB], bf16x8 (&bf)[NB]) {
+        const int coff = ((ks * 2 + hi) ^ sw) * 16;
+#pragma unroll
+        for (int j = 0; j < MB; ++j) af[j] = *(const bf16x8*)(sbase + a_row_off + j * 32 * 128 + coff);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) bf[i] = *(const bf16x8*)(sbase + b_row_off + i * 32 * 128 + coff);
+    };
+
+    const int nk = p.K / BK;
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) issue_piece(pc, 0, 0);
+    for (int t = 0; t < nk; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* sbase = smem + (t & 1) * STAGE;
+        const int ns = (t + 1) & 1;
+        const int knext = (t + 1 < nk) ? (t + 1) : 0;               // last iteration re-fetches tile 0 (never read)
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) issue_piece(pc, ns, knext);
+        bf16x8 af[MB], bf[NB];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            read_frags(sbase, ks, af, bf);
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = 0; j < MB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[i], af[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    gemm_epilogue<NB, MB, EPI>(p, acc, m0 + wm * (BM / 4), n0 + wn * (BN / 2), lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Ring kernel for the large shapes (BM = 256, persistent: one workgroup per CU walks the tile list).
 //   * Operands stream through a ring of NSLOT sub-stages of (256 + BN) rows x 32 K (64-byte rows; 16-byte chunk c of row
 //     r lives at slot c ^ ((r >> 2) & 3): conflict-free ds_read_b128), filled by global_load_lds NSLOT-1 sub-stages
@@ -1125,4 +1238,39 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
     if (best->bn == 192) return launch<128, 192>(a, g->epilogue, st);
     if (best->bn == 128) return launch<128, 128>(a, g->epilogue, st);
     return launch<128, 64>(a, g->epilogue, st);
+}
+
+// Implicit-GEMM convolution entry point: g->A is ignored (the A operand is gathered from c->src), g->M = B*T*H*W, g->K = taps * C.
+extern "C" int orv_conv_gemm_bf16(const orv_gemm_t* g, const orv_conv_t* c, void* stream) {
+    ORV_REQUIRE(g && c && c->src && g->W && g->C, "orv_conv_gemm_bf16: null operand");
+    ORV_REQUIRE(c->C % 64 == 0, "orv_conv_gemm_bf16: C=%d must be a multiple of 64 (use orv_vae_im2col + orv_gemm_bf16 otherwise)", c->C);
+    ORV_REQUIRE(c->kt >= 1 && c->kh >= 1 && c->kw >= 1 && (c->stride == 1 || c->stride == 2) && c->pad_lo >= 0 && c->ups_t >= 0 &&
+                    c->ups_t <= 2 && c->t_shift >= 0 && c->t_shift <= c->kt - 1 && (c->t_shift == 0 || c->ups_t == 0),
+                "orv_conv_gemm_bf16: bad kernel geometry");
+    ORV_REQUIRE(g->K == c->kt * c->kh * c->kw * c->C && (long)g->M == (long)c->B * c->T * c->H * c->W,
+                "orv_conv_gemm_bf16: M / K do not match the convolution geometry");
+    ORV_REQUIRE(g->N % 64 == 0 && g->ldw % 8 == 0 && g->ldc % 8 == 0 && (g->epilogue == 0 || g->epilogue == 2),
+                "orv_conv_gemm_bf16: N=%d must be a multiple of 64; epilogues 0 (bias) and 2 (residual) only", g->N);
+    ORV_REQUIRE(g->epilogue != 2 || g->R, "orv_conv_gemm_bf16: epilogue 2 needs R");
+    GemmArgs a{};
+    a.A = nullptr; a.lda = 0; a.W = (const bf16_t*)g->W; a.ldw = g->ldw; a.bias = (const bf16_t*)g->bias;
+    a.C = (bf16_t*)g->C; a.ldc = g->ldc; a.M = g->M; a.N = g->N; a.K = g->K;
+    a.R = (const bf16_t*)g->R; a.ldr = g->ldr; a.r_mod = g->r_mod; a.gate = nullptr;
+    ConvArgs cv{(const bf16_t*)c->src, c->B, c->Ts, c->Hs, c->Ws, c->C, c->T, c->H, c->W, c->kt, c->kh, c->kw, c->stride, c->pad_lo,
+                c->ups_s, c->ups_t, c->t_shift};
+    const int bn = g->N % 128 == 0 ? 128 : 64;
+    a.tiles_n = g->N / bn;
+    a.tiles_m = (g->M + 255) / 256;
+    const int smem = 2 * (256 + bn) * 128;
+    hipStream_t st = (hipStream_t)stream;
+#define ORV_CONV_CASE(BN_, E)                                                                                          \
+    {                                                                                                                  \
+        static bool done = false;                                                                                      \
+        if (!done) { (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<256, BN_, E>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); done = true; } \
+        hipLaunchKernelGGL((conv_gemm_kernel<256, BN_, E>), dim3(a.tiles_m * a.tiles_n), dim3(512), smem, st, a, cv);  \
+    }
+    if (bn == 128) { if (g->epilogue == 2) ORV_CONV_CASE(128, 2) else ORV_CONV_CASE(128, 0) }
+    else { if (g->epilogue == 2) ORV_CONV_CASE(64, 2) else ORV_CONV_CASE(64, 0) }
+#undef ORV_CONV_CASE
+    return orv_check_launch("orv_conv_gemm_bf16");
 }

@@ -334,6 +334,21 @@ def vae_im2col(src, dst, B, Ts, Hs, Ws, C, T, H, W, kt, kh, kw, stride, pad_lo, 
     return dst
 
 
+def conv_gemm(src, Wp, bias, out, B, Ts, Hs, Ws, C, T, H, W, kt, kh, kw, stride, pad_lo, ups_s, ups_t, t_shift, N, R=None, ldr=None):
+    """Implicit-GEMM convolution (no patch matrix): out[B*T*H*W, N] = conv(src) + bias (+ R)."""
+    from ._lib import Conv
+    _need(src, BF16, "src"), _need(Wp, BF16, "W"), _need(out, BF16, "out")
+    M, K = B * T * H * W, kt * kh * kw * C
+    g = Gemm()
+    g.A, g.lda, g.W, g.ldw, g.bias = None, 0, _p(Wp), K, _p(bias)
+    g.C, g.ldc, g.M, g.N, g.K, g.epilogue = _p(out), N, M, N, K, 2 if R is not None else 0
+    g.R, g.ldr, g.r_mod, g.gate = _p(R), ldr or N, 0, None
+    g.grp, g.cmap = Groups(0, 0, 0), RowMap(0, 0, 0)
+    c = Conv(_p(src), B, Ts, Hs, Ws, C, T, H, W, kt, kh, kw, stride, pad_lo, int(ups_s), int(ups_t), int(t_shift))
+    check(lib().orv_conv_gemm_bf16(g, c, _stream()), "orv_conv_gemm_bf16")
+    return out
+
+
 def vae_groupnorm_stats(x, B, N, C, G):
     """-> sums fp32 [B, G, 2] (sum, sum of squares per group), deterministic."""
     _need(x, BF16, "x")

@@ -31,6 +31,7 @@ from .cogvideox_control import FrozenConfig, _NoForward
 
 BF16 = torch.bfloat16
 _PATCH_BYTES = 2 << 30
+_IMPLICIT_GEMM = os.environ.get("ORV_VAE_IMPLICIT_GEMM", "1") != "0"     # A/B switch: 0 = patch matrix + plain GEMM everywhere
 
 
 class CogVideoXCausalConv3d(_NoForward):
@@ -282,6 +283,16 @@ class AutoencoderKLCogVideoX(nn.Module):
         M = B * T * H * W
         direct = co == npad
         out = torch.empty(M, npad, dtype=BF16, device=x.device)
+        if C % 64 == 0 and _IMPLICIT_GEMM:
+            # implicit GEMM: the LDS-DMA gathers the tap-shifted channel lines itself, no patch matrix (kpad == taps * C here)
+            res2d = residual.reshape(M, co) if (residual is not None and direct) else None
+            ops.conv_gemm(x, wp, bias, out, B, Ts, Hs, Ws, C, T, H, W, k3[0], k3[1], k3[2], stride, pad_lo, ups_s, ups_t, t_shift,
+                          npad, R=res2d, ldr=co)
+            if not direct:
+                out = out[:, :co].contiguous()
+                if residual is not None:
+                    out = out + residual.reshape(M, co)
+            return out.view(B, T, H, W, co)
         rows = max(256, min(M, (_PATCH_BYTES // (2 * kpad)) // 256 * 256))
         patch = torch.empty(min(rows, M), kpad, dtype=BF16, device=x.device)
         res2d = residual.reshape(M, co) if (residual is not None and direct) else None
