@@ -459,7 +459,10 @@ struct ConvArgs {
 };
 __device__ __attribute__((aligned(256))) uint4 orv_zero_page[16];       // 256 zero bytes: source of padded taps
 
-template <int BM, int BN, int EPI>
+// SIMPLE = stride 1, no upsampling (every resnet convolution): the conv-input grid IS the source grid, so a tap is a 32-bit
+// voxel-index offset and the per-piece address arithmetic is ~10 VALU instructions instead of ~30 (at N = 128 the loop has 16
+// MFMAs per K-tile and wave: the general form's 64-bit index math was as long as the MFMAs)
+template <int BM, int BN, int EPI, bool SIMPLE>
 __global__ __launch_bounds__(512) void conv_gemm_kernel(const GemmArgs p, const ConvArgs cv) {
     constexpr int MB = BM / 128, NB = BN / 64;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -483,6 +486,7 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(const GemmArgs p, const 
         vy[j] = (int)(m % cv.H); m /= cv.H;
         vt[j] = (int)(m % cv.T);
         vb[j] = (int)(m / cv.T);
+        if (SIMPLE) vb[j] *= cv.Ts;                                  // first source frame of this batch element
     }
     const bf16_t* b_src[B_LD];
 #pragma unroll
@@ -494,7 +498,17 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(const GemmArgs p, const 
     const int Hi = cv.ups_s ? cv.Hs * 2 : cv.Hs, Wi = cv.ups_s ? cv.Ws * 2 : cv.Ws;
     constexpr int NP = A_LD + B_LD;
     auto issue_piece = [&](int pc, int s, int ktile) {
-        if (pc < A_LD) {
+        if (pc < A_LD && SIMPLE) {
+            const int tap = ktile / cblocks, c0 = (ktile - tap * cblocks) << 6;          // wave-uniform (SALU)
+            const int dx = tap % cv.kw - cv.pad_lo, dy = (tap / cv.kw) % cv.kh - cv.pad_lo;
+            const int dt = tap / (cv.kw * cv.kh) + cv.t_shift - (cv.kt - 1);
+            const int ti = max(vt[pc] + dt, 0), yi = vy[pc] + dy, xi = vx[pc] + dx;
+            const bool ok = (unsigned)yi < (unsigned)cv.Hs && (unsigned)xi < (unsigned)cv.Ws;
+            const unsigned idx = (unsigned)((vb[pc] + ti) * cv.Hs + yi) * (unsigned)cv.Ws + (unsigned)xi;   // voxel index < 2^31 (host-checked)
+            const bf16_t* g = cv.src + (long)idx * cv.C + (c0 + vchunk[pc]);
+            if (!ok) g = (const bf16_t*)orv_zero_page + (lane & 7) * 8;
+            glds16(g, smem + s * STAGE + (wave * A_LD + pc) * 1024);
+        } else if (pc < A_LD) {
             const int tap = ktile / cblocks, c0 = (ktile - tap * cblocks) << 6;          // wave-uniform
             const int dx = tap % cv.kw, dy = (tap / cv.kw) % cv.kh, dt = tap / (cv.kw * cv.kh);
             int ti = vt[pc] + cv.t_shift - (cv.kt - 1) + dt;
@@ -541,18 +555,28 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(const GemmArgs p, const 
         const char* sbase = smem + (t & 1) * STAGE;
         const int ns = (t + 1) & 1;
         const int knext = (t + 1 < nk) ? (t + 1) : 0;               // last iteration re-fetches tile 0 (never read)
+        // k-step ks: fragments of ks + 1 are read first, this k-step's share of the next tile's DMA pieces (address arithmetic +
+        // issue) sits between its MFMAs: the LDS-DMA issue cost (~100 cycles each) hides under the matrix pipe instead of
+        // stacking up behind the barrier
+        bf16x8 af[2][MB], bf[2][NB];
+        read_frags(sbase, 0, af[0], bf[0]);
+        auto kstep = [&](auto ks_c) {
+            constexpr int ks = decltype(ks_c)::value;
+            if constexpr (ks < 3) read_frags(sbase, ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
 #pragma unroll
-        for (int pc = 0; pc < NP; ++pc) issue_piece(pc, ns, knext);
-        bf16x8 af[MB], bf[NB];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            read_frags(sbase, ks, af, bf);
+            for (int pc = 0; pc < NP; ++pc)
+                if (pc * 4 / NP == ks) issue_piece(pc, ns, knext);
 #pragma unroll
             for (int i = 0; i < NB; ++i)
 #pragma unroll
                 for (int j = 0; j < MB; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[i], af[j], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks & 1][i], af[ks & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        kstep(std::integral_constant<int, 0>{});
+        kstep(std::integral_constant<int, 1>{});
+        kstep(std::integral_constant<int, 2>{});
+        kstep(std::integral_constant<int, 3>{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     gemm_epilogue<NB, MB, EPI>(p, acc, m0 + wm * (BM / 4), n0 + wn * (BN / 2), lane);
@@ -1252,25 +1276,30 @@ extern "C" int orv_conv_gemm_bf16(const orv_gemm_t* g, const orv_conv_t* c, void
     ORV_REQUIRE(g->N % 64 == 0 && g->ldw % 8 == 0 && g->ldc % 8 == 0 && (g->epilogue == 0 || g->epilogue == 2),
                 "orv_conv_gemm_bf16: N=%d must be a multiple of 64; epilogues 0 (bias) and 2 (residual) only", g->N);
     ORV_REQUIRE(g->epilogue != 2 || g->R, "orv_conv_gemm_bf16: epilogue 2 needs R");
+    ORV_REQUIRE((long)c->B * c->Ts * c->Hs * c->Ws < (1L << 31), "orv_conv_gemm_bf16: more than 2^31 source voxels");
     GemmArgs a{};
     a.A = nullptr; a.lda = 0; a.W = (const bf16_t*)g->W; a.ldw = g->ldw; a.bias = (const bf16_t*)g->bias;
     a.C = (bf16_t*)g->C; a.ldc = g->ldc; a.M = g->M; a.N = g->N; a.K = g->K;
     a.R = (const bf16_t*)g->R; a.ldr = g->ldr; a.r_mod = g->r_mod; a.gate = nullptr;
     ConvArgs cv{(const bf16_t*)c->src, c->B, c->Ts, c->Hs, c->Ws, c->C, c->T, c->H, c->W, c->kt, c->kh, c->kw, c->stride, c->pad_lo,
                 c->ups_s, c->ups_t, c->t_shift};
-    const int bn = g->N % 128 == 0 ? 128 : 64;
+    const int bn = g->N % 256 == 0 ? 256 : (g->N % 128 == 0 ? 128 : 64);     // wider tiles gather the A lines fewer times
     a.tiles_n = g->N / bn;
     a.tiles_m = (g->M + 255) / 256;
     const int smem = 2 * (256 + bn) * 128;
     hipStream_t st = (hipStream_t)stream;
-#define ORV_CONV_CASE(BN_, E)                                                                                          \
+    const bool simple = c->stride == 1 && !c->ups_s && !c->ups_t && c->Hs == c->H && c->Ws == c->W;
+#define ORV_CONV_LAUNCH(BN_, E, S_)                                                                                    \
     {                                                                                                                  \
         static bool done = false;                                                                                      \
-        if (!done) { (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<256, BN_, E>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); done = true; } \
-        hipLaunchKernelGGL((conv_gemm_kernel<256, BN_, E>), dim3(a.tiles_m * a.tiles_n), dim3(512), smem, st, a, cv);  \
+        if (!done) { (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<256, BN_, E, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); done = true; } \
+        hipLaunchKernelGGL((conv_gemm_kernel<256, BN_, E, S_>), dim3(a.tiles_m * a.tiles_n), dim3(512), smem, st, a, cv); \
     }
-    if (bn == 128) { if (g->epilogue == 2) ORV_CONV_CASE(128, 2) else ORV_CONV_CASE(128, 0) }
+#define ORV_CONV_CASE(BN_, E) { if (simple) ORV_CONV_LAUNCH(BN_, E, true) else ORV_CONV_LAUNCH(BN_, E, false) }
+    if (bn == 256) { if (g->epilogue == 2) ORV_CONV_CASE(256, 2) else ORV_CONV_CASE(256, 0) }
+    else if (bn == 128) { if (g->epilogue == 2) ORV_CONV_CASE(128, 2) else ORV_CONV_CASE(128, 0) }
     else { if (g->epilogue == 2) ORV_CONV_CASE(64, 2) else ORV_CONV_CASE(64, 0) }
+#undef ORV_CONV_LAUNCH
 #undef ORV_CONV_CASE
     return orv_check_launch("orv_conv_gemm_bf16");
 }
