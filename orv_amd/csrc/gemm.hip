@@ -915,13 +915,13 @@ __global__ __launch_bounds__(512) void gemm_ph_kernel(const GemmArgs p) {
     {                                                                                                                \
         _Pragma("unroll") for (int i = 0; i < APH; ++i)                                                              \
             ORV_PH_GLDS(ARR[i] + (long)KC * BK, smem + (S) * STAGE + ((H) * 128 + (wave + 8 * i) * 8) * 128);        \
-        if (++KC == nk) { KC = 0; TC += gridDim.x; ORV_PH_SETUP_A(H, ARR, TC) }                                      \
+        if (__builtin_expect(++KC == nk, 0)) { KC = 0; TC += gridDim.x; ORV_PH_SETUP_A(H, ARR, TC) }                                      \
     }
 #define ORV_PH_ISSUE_B(H, ARR, KC, TC, S)                                                                            \
     {                                                                                                                \
         _Pragma("unroll") for (int i = 0; i < BPH; ++i)                                                              \
             ORV_PH_GLDS(ARR[i] + (long)KC * BK, smem + (S) * STAGE + A_BYTES + ((H) * HB + (wave + 8 * i) * 8) * 128); \
-        if (++KC == nk) { KC = 0; TC += gridDim.x; ORV_PH_SETUP_B(H, ARR, TC) }                                      \
+        if (__builtin_expect(++KC == nk, 0)) { KC = 0; TC += gridDim.x; ORV_PH_SETUP_B(H, ARR, TC) }                                      \
     }
     ORV_PH_SETUP_A(0, sA0, tA0)
     ORV_PH_SETUP_A(1, sA1, tA1)
