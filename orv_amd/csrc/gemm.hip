@@ -321,10 +321,18 @@ __device__ __forceinline__ void tile_of_index(const GemmArgs& p, int b, int nb, 
 }
 __device__ __forceinline__ void tile_of_block(const GemmArgs& p, int& tm, int& tn) { tile_of_index(p, blockIdx.x, gridDim.x, tm, tn); }
 
-template <int BM, int BN, int EPI>
+// WM = waves along M (4 or 2), 8 / WM along N.  WM = 2 exists for the 192-row tile: 3226 rows (one clip) are 16.8 tiles of
+// 192, so every N = 1920 GEMM of a B = 1 step is 255 tiles - one full round of the 256 CUs.
+// NS = LDS stages (K-tiles NS-1 ahead in flight).  Only NS = 2 is instantiated: three and four stages were measured on the
+// 192x128 tile (profiles/r2_gemm_b1_tiles.log) - no gain on single-round launches (they are not latency bound) and a 12 % loss
+// on multi-round ones, where two 80 KB workgroups per CU overlap each other's barriers and a 120+ KB one runs alone.
+template <int BM, int BN, int EPI, int WM = 4, int NS = 2>
 __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs p) {
-    constexpr int MB = BM / 128;       // 32-row blocks per wave along M (4 M-waves)
-    constexpr int NB = BN / 64;        // 32-col blocks per wave along N (2 N-waves)
+    constexpr int WN = 8 / WM;
+    constexpr int D = NS - 1;            // prefetch distance in K-tiles
+    constexpr int MB = BM / (32 * WM);   // 32-row blocks per wave along M
+    constexpr int NB = BN / (32 * WN);   // 32-col blocks per wave along N
+    static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0 && BM % 64 == 0 && BN % 64 == 0, "tile / wave grid mismatch");
     constexpr int A_BYTES = BM * 128;  // one stage of A: BM rows x 64 bf16
     constexpr int B_BYTES = BN * 128;
     constexpr int STAGE = A_BYTES + B_BYTES;
@@ -376,10 +384,10 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs p) {
     };
 
     // ---- fragment read offsets ----
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
-    const int a_row_off = (wm * (BM / 4) + l31) * 128;
-    const int b_row_off = A_BYTES + (wn * (BN / 2) + l31) * 128;
+    const int a_row_off = (wm * (BM / WM) + l31) * 128;
+    const int b_row_off = A_BYTES + (wn * (BN / WN) + l31) * 128;
 
     f32x16 acc[NB][MB];
 #pragma unroll
@@ -399,15 +407,17 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs p) {
 
     const int nk = p.K / BK;
 #pragma unroll
-    for (int pc = 0; pc < NP; ++pc) issue_piece(pc, 0, 0);
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) issue_piece(pc, d, (long)(d < nk ? d : 0) * BK);
+    int cs = 0, ns = D;                  // stage read this iteration / stage filled this iteration (tile t + D)
     for (int t = 0; t < nk; ++t) {
-        // tile t has landed for this wave; after the barrier it has landed for all waves and nobody still
-        // reads stage (t+1)&1 (those reads were consumed by the MFMAs of iteration t-1).
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // tile t has landed for this wave (D - 1 younger tiles may still be in flight); after the barrier it has landed for
+        // all waves and nobody still reads stage ns (those reads were consumed by the MFMAs of iteration t-1).
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NP) : "memory");
         __syncthreads();
-        const char* sbase = smem + (t & 1) * STAGE;
-        const int ns = (t + 1) & 1;
-        const long koff = (long)((t + 1 < nk) ? (t + 1) : 0) * BK;   // last iteration re-fetches tile 0 (never read)
+        const char* sbase = smem + cs * STAGE;
+        const long koff = (long)((t + D < nk) ? (t + D) : 0) * BK;   // the last iterations re-fetch tile 0 (never read)
         bf16x8 af[2][MB], bf[2][NB];
         read_frags(sbase, 0, af[0], bf[0]);
         auto kstep = [&](auto ks_c) {
@@ -417,13 +427,12 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs p) {
             if constexpr (ks < 3) read_frags(sbase, ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc)
-                if (pc * 3 / NP == ks) { if (p.dbg != 1) issue_piece(pc, ns, koff); }
+                if (pc * 3 / NP == ks) issue_piece(pc, ns, koff);
 #pragma unroll
             for (int i = 0; i < NB; ++i)
 #pragma unroll
                 for (int j = 0; j < MB; ++j)
-                    if (p.dbg != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks & 1][i], af[ks & 1][j], acc[i][j], 0, 0, 0);
-                    else { asm volatile("" :: "v"(bf[ks & 1][i]), "v"(af[ks & 1][j])); }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks & 1][i], af[ks & 1][j], acc[i][j], 0, 0, 0);
             // schedule: next k-step's LDS reads first, then MFMAs with the DMA issues spread between them
             if constexpr (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, MB + NB, 0);
             constexpr int PER = NPC > 0 ? (NM / (NPC + 1) > 0 ? NM / (NPC + 1) : 1) : NM;
@@ -439,10 +448,12 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs p) {
         kstep(std::integral_constant<int, 1>{});
         kstep(std::integral_constant<int, 2>{});
         kstep(std::integral_constant<int, 3>{});
+        cs = cs + 1 == NS ? 0 : cs + 1;
+        ns = ns + 1 == NS ? 0 : ns + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    gemm_epilogue<NB, MB, EPI>(p, acc, m0 + wm * (BM / 4), n0 + wn * (BN / 2), lane);
+    gemm_epilogue<NB, MB, EPI>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1108,19 +1119,19 @@ int launch_pp(const GemmArgs& a, int epi, hipStream_t st) {
     return orv_check_launch("orv_gemm_bf16");
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WM = 4, int NS = 2>
 int launch(const GemmArgs& a, int epi, hipStream_t st) {
-    const int smem = 2 * (BM + BN) * 128;
+    const int smem = NS * (BM + BN) * 128;
     const int grid = a.tiles_m * a.tiles_n;
 #define ORV_GEMM_CASE(E)                                                                                    \
     case E: {                                                                                               \
         static bool attr_done = false;                                                                      \
         if (!attr_done) {                                                                                   \
-            (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, E>,                                  \
+            (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, E, WM, NS>,                              \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);                    \
             attr_done = true;                                                                               \
         }                                                                                                   \
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, E>), dim3(grid), dim3(512), smem, st, a);                   \
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, E, WM, NS>), dim3(grid), dim3(512), smem, st, a);               \
         break;                                                                                              \
     }
     switch (epi) {
@@ -1129,13 +1140,13 @@ int launch(const GemmArgs& a, int epi, hipStream_t st) {
         ORV_GEMM_CASE(2)
         ORV_GEMM_CASE(3)
         case 4:
-            if constexpr ((BN / 2) % 64 == 0) {
+            if constexpr ((BN / (8 / WM)) % 64 == 0) {
                 static bool attr_done4 = false;
                 if (!attr_done4) {
-                    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+                    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, 4, WM, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
                     attr_done4 = true;
                 }
-                hipLaunchKernelGGL((gemm_kernel<BM, BN, 4>), dim3(grid), dim3(512), smem, st, a);
+                hipLaunchKernelGGL((gemm_kernel<BM, BN, 4, WM, NS>), dim3(grid), dim3(512), smem, st, a);
                 break;
             }
             [[fallthrough]];
@@ -1164,6 +1175,8 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
         {1, 256, 384, 1.075f, 2}, {1, 256, 256, 1.060f, 0}, {1, 256, 192, 1.000f, 0}, {1, 256, 128, 0.885f, 0},
         {0, 256, 192, 0.975f, 0}, {0, 256, 128, 0.935f, 0}, {0, 256, 64, 0.855f, 0},
         {0, 128, 192, 0.965f, 0}, {0, 128, 128, 0.855f, 0}, {0, 128, 64, 0.760f, 0},
+        // 192 rows (2 x 4 wave grid): M = 3226 (one clip) is 17 tiles, 17 x 15 = 255 tiles for N = 1920
+        {0, 192, 128, 0.920f, 0},
     };
     static int force_ring = -1, force_bm = 0, force_bn = 0;   // ORV_GEMM_TILE="ring,bm,bn" pins one candidate (sweeps / A-B)
     if (force_ring < 0) {
@@ -1182,7 +1195,7 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
         if (N % c.bn) continue;
         if (c.ring == 2 && (K % 128 != 0 || no_phased)) continue;
         // epilogue 4 normalises whole 64-wide heads inside a wave (BN / 2 columns) that must not straddle q | k | v
-        if (epilogue == 4 && ((c.bn / 2) % 64 != 0 || (heads * 64) % (c.bn / 2) != 0)) continue;
+        if (epilogue == 4 && (c.bm == 192 || (c.bn / 2) % 64 != 0 || (heads * 64) % (c.bn / 2) != 0)) continue;
         if (force_bm && (c.ring != force_ring || c.bm != force_bm || c.bn != force_bn)) continue;
         if (!force_bm && force_ring == 0 && c.ring) continue;
         const long tiles = (long)((M + c.bm - 1) / c.bm) * (N / c.bn);
@@ -1206,7 +1219,8 @@ extern "C" int orv_gemm_kernel_name(int M, int N, int K, int epilogue, char* buf
     ORV_REQUIRE(c, "orv_gemm_kernel_name: no tile configuration for N=%d", N);
     if (c->ring == 2) snprintf(buf, len, "gemm_ph_kernel<%d, %d>", c->bn, epilogue);
     else if (c->ring) snprintf(buf, len, "gemm_pp_kernel<%d, %d, %d>", c->bn, c->bn == 384 ? 4 : 5, epilogue);
-    else snprintf(buf, len, "gemm_kernel<%d, %d, %d>", c->bm, c->bn, epilogue);
+    else if (c->bm == 192) snprintf(buf, len, "gemm_kernel<%d, %d, %d, 2, 2>", c->bm, c->bn, epilogue);
+    else snprintf(buf, len, "gemm_kernel<%d, %d, %d, 4, 2>", c->bm, c->bn, epilogue);
     return ORV_OK;
 }
 
@@ -1254,6 +1268,7 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
         if (best->bn == 192) return launch_pp<192, 5>(a, g->epilogue, st);
         return launch_pp<128, 5>(a, g->epilogue, st);
     }
+    if (best->bm == 192) return launch<192, 128, 2>(a, g->epilogue, st);
     if (best->bm == 256) {
         if (best->bn == 192) return launch<256, 192>(a, g->epilogue, st);
         if (best->bn == 128) return launch<256, 128>(a, g->epilogue, st);
