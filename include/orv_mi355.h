@@ -288,7 +288,7 @@ int orv_vae_groupnorm_stats(const void* x, float* sums, float* scratch, int B, l
  * (first frame of an odd-length clip apart), optional SiLU.  zy == zb == NULL: plain GroupNorm. */
 int orv_vae_norm_apply(const void* x, void* out, const float* sums, const void* gamma, const void* beta, const void* zy,
                        const void* zb, int B, int T, int H, int W, int C, int G, int Tz, int hz, int wz, float eps, int silu_act,
-                       void* stream);
+                       int out_lead, void* stream);
 
 #ifdef __cplusplus
 }

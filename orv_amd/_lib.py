@@ -93,7 +93,7 @@ SIGNATURES = {
     "orv_conv_gemm_bf16": (c_int, [POINTER(Gemm), POINTER(Conv), c_void_p]),
     "orv_vae_groupnorm_scratch": (c_long, [c_int, c_long, c_int, c_int]),
     "orv_vae_groupnorm_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_void_p]),
-    "orv_vae_norm_apply": (c_int, [c_void_p] * 7 + [c_int] * 9 + [c_float, c_int, c_void_p]),
+    "orv_vae_norm_apply": (c_int, [c_void_p] * 7 + [c_int] * 9 + [c_float, c_int, c_int, c_void_p]),
 }
 
 _lib = None

@@ -80,8 +80,7 @@ __global__ __launch_bounds__(256) void vae_gn_stats_kernel(const bf16_t* __restr
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
     const long v0 = (long)blockIdx.x * vox_per_block, v1 = min(N, v0 + vox_per_block);
-    for (long v = v0 + vl; v < v1; v += vstep) {
-        const uint4 u = *(const uint4*)(x + ((long)b * N + v) * C + chunk * 8);
+    auto add = [&](const uint4& u) {
         const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -89,7 +88,15 @@ __global__ __launch_bounds__(256) void vae_gn_stats_kernel(const bf16_t* __restr
             s[2 * e] += a; q[2 * e] += a * a;
             s[2 * e + 1] += c2; q[2 * e + 1] += c2 * c2;
         }
+    };
+    const bf16_t* xb = x + (long)b * N * C + chunk * 8;
+    long v = v0 + vl;
+    for (; v + 3 * vstep < v1; v += 4 * vstep) {       // four independent 16-byte loads in flight; summed in voxel order
+        const uint4 u0 = *(const uint4*)(xb + v * C), u1 = *(const uint4*)(xb + (v + vstep) * C);
+        const uint4 u2 = *(const uint4*)(xb + (v + 2 * vstep) * C), u3 = *(const uint4*)(xb + (v + 3 * vstep) * C);
+        add(u0); add(u1); add(u2); add(u3);
     }
+    for (; v < v1; v += vstep) add(*(const uint4*)(xb + v * C));
 #pragma unroll
     for (int e = 0; e < 8; ++e) { part[threadIdx.x][e] = s[e]; part[threadIdx.x][8 + e] = q[e]; }
     __syncthreads();
@@ -128,31 +135,31 @@ struct NormArgs {
     int Tz, hz, wz;
     float eps;
     int silu;
+    int out_lead;                      // out is [B, out_lead + T, H, W, C]: frames [0, out_lead) are left for the caller (conv_cache)
 };
 
+// grid = (ceil(W * C/8 / 256), H, B * T): the frame / row indices are block-uniform, a thread divides once (x position |
+// 8-channel chunk) - the first version decomposed a flat 64-bit index per thread and spent its time in integer division.
 __global__ __launch_bounds__(256) void vae_norm_apply_kernel(const NormArgs p) {
-    const int cc = p.C >> 3;
-    const long N = (long)p.T * p.H * p.W;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)p.B * N * cc) return;
-    const int chunk = (int)(i % cc);
-    const long bv = i / cc;
-    const int b = (int)(bv / N);
-    long v = bv % N;
-    const int c0 = chunk * 8, cpg = p.C / p.G;
-    const float inv_n = 1.f / ((float)N * (float)cpg);
+    const unsigned cc = (unsigned)p.C >> 3;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (unsigned)p.W * cc) return;
+    const unsigned xw = idx / cc, chunk = idx - xw * cc;
+    const int yh = blockIdx.y;
+    const int b = (int)blockIdx.z / p.T, t = (int)blockIdx.z - b * p.T;
+    const int c0 = (int)chunk * 8, cpg = p.C / p.G;
+    const float inv_n = 1.f / ((float)p.T * (float)p.H * (float)p.W * (float)cpg);
+    const long bv = (((long)b * p.T + t) * p.H + yh) * p.W + xw;
     const uint4 u = *(const uint4*)(p.x + bv * p.C + c0);
     const uint4 ug = *(const uint4*)(p.gamma + c0), ub = *(const uint4*)(p.beta + c0);
     uint4 uy = make_uint4(0, 0, 0, 0), uz = make_uint4(0, 0, 0, 0);
     if (p.zy) {
-        const int xw = (int)(v % p.W); v /= p.W;
-        const int yh = (int)(v % p.H);
-        const int t = (int)(v / p.H);
         // F.interpolate(nearest): src = floor(dst * in / out); SpatialNorm resizes the first frame of an odd-length clip apart
         int tz;
-        if (p.T > 1 && (p.T & 1)) tz = t == 0 ? 0 : 1 + (int)(((long)(t - 1) * (p.Tz - 1)) / (p.T - 1));
-        else tz = (int)(((long)t * p.Tz) / p.T);
-        const int yz = (int)(((long)yh * p.hz) / p.H), xz = (int)(((long)xw * p.wz) / p.W);
+        if (p.T > 1 && (p.T & 1)) tz = t == 0 ? 0 : 1 + ((t - 1) * (p.Tz - 1)) / (p.T - 1);
+        else tz = (t * p.Tz) / p.T;
+        const int yz = (yh * p.hz) / p.H;
+        const unsigned xz = (xw * (unsigned)p.wz) / (unsigned)p.W;
         const long zi = ((((long)b * p.Tz + tz) * p.hz + yz) * p.wz + xz) * p.C + c0;
         uy = *(const uint4*)(p.zy + zi);
         uz = *(const uint4*)(p.zb + zi);
@@ -160,19 +167,24 @@ __global__ __launch_bounds__(256) void vae_norm_apply_kernel(const NormArgs p) {
     const uint32_t wx[4] = {u.x, u.y, u.z, u.w}, wg[4] = {ug.x, ug.y, ug.z, ug.w}, wb[4] = {ub.x, ub.y, ub.z, ub.w};
     const uint32_t wy[4] = {uy.x, uy.y, uy.z, uy.w}, wz[4] = {uz.x, uz.y, uz.z, uz.w};
     float o[8];
+    int g = c0 / cpg, r = c0 - g * cpg;       // group of channel c0 and the position inside it; statistics reloaded when it changes
+    float mean = 0.f, rstd = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int g = (c0 + e) / cpg;
-        const float s = p.sums[((long)b * p.G + g) * 2], q = p.sums[((long)b * p.G + g) * 2 + 1];
-        const float mean = s * inv_n;
-        const float rstd = rsqrtf(fmaxf(q * inv_n - mean * mean, 0.f) + p.eps);
+        if (e == 0 || r == 0) {
+            const float2 sq = *(const float2*)(p.sums + ((long)b * p.G + g) * 2);
+            mean = sq.x * inv_n;
+            rstd = rsqrtf(fmaxf(sq.y * inv_n - mean * mean, 0.f) + p.eps);
+        }
         auto pick = [&](const uint32_t (&w)[4]) { return bf2f((e & 1) ? w[e >> 1] >> 16 : w[e >> 1] & 0xffff); };
         float val = (pick(wx) - mean) * rstd * pick(wg) + pick(wb);
         if (p.zy) val = val * pick(wy) + pick(wz);
         if (p.silu) val = silu(val);
         o[e] = val;
+        if (++r == cpg) { r = 0; ++g; }
     }
-    *(uint4*)(p.out + bv * p.C + c0) = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+    const long ov = (((long)b * (p.T + p.out_lead) + t + p.out_lead) * p.H + yh) * p.W + xw;
+    *(uint4*)(p.out + ov * p.C + c0) = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
 }
 
 }  // namespace
@@ -214,15 +226,20 @@ extern "C" int orv_vae_groupnorm_stats(const void* x, float* sums, float* scratc
 
 // out = act(GroupNorm(x; sums) [* zy[zmap] + zb[zmap]]): GroupNorm affine, SpatialNorm modulation by the latent-resolution
 // tensors zy / zb (nearest-neighbour lookup) and SiLU in one pass.  Algorithmic bytes: B*N*C*2 read + written.
+// out is [B, out_lead + T, H, W, C]; the first out_lead frames of every clip are not written (the caller puts the causal
+// context of the next convolution there: its conv_cache frames or copies of the first frame).
 extern "C" int orv_vae_norm_apply(const void* x, void* out, const float* sums, const void* gamma, const void* beta,
                                   const void* zy, const void* zb, int B, int T, int H, int W, int C, int G, int Tz, int hz,
-                                  int wz, float eps, int silu_act, void* stream) {
+                                  int wz, float eps, int silu_act, int out_lead, void* stream) {
     ORV_REQUIRE(x && out && sums && gamma && beta && B > 0 && T > 0 && H > 0 && W > 0 && C % 8 == 0 && G > 0 && C % G == 0,
                 "orv_vae_norm_apply: bad arguments");
+    ORV_REQUIRE(out_lead >= 0 && out_lead <= 8, "orv_vae_norm_apply: out_lead=%d outside [0, 8]", out_lead);
     ORV_REQUIRE((zy == nullptr) == (zb == nullptr) && (!zy || (Tz > 0 && hz > 0 && wz > 0)), "orv_vae_norm_apply: zy / zb go together");
     NormArgs a{(const bf16_t*)x, (bf16_t*)out, sums, (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)zy,
-               (const bf16_t*)zb, B, T, H, W, C, G, Tz, hz, wz, eps, silu_act};
-    const long total = (long)B * T * H * W * (C >> 3);
-    hipLaunchKernelGGL(vae_norm_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+               (const bf16_t*)zb, B, T, H, W, C, G, Tz, hz, wz, eps, silu_act, out_lead};
+    ORV_REQUIRE(H <= 65535 && (long)B * T <= 65535 && (long)W * (C >> 3) < (1L << 31) && (long)T * Tz < (1L << 31) &&
+                    (long)H * hz < (1L << 31) && (long)W * wz < (1L << 31), "orv_vae_norm_apply: clip too large for one launch");
+    hipLaunchKernelGGL(vae_norm_apply_kernel, dim3((unsigned)(((long)W * (C >> 3) + 255) / 256), H, B * T), dim3(256), 0,
+                       (hipStream_t)stream, a);
     return orv_check_launch("orv_vae_norm_apply");
 }

@@ -358,8 +358,9 @@ def vae_groupnorm_stats(x, B, N, C, G):
     return sums
 
 
-def vae_norm_apply(x, out, sums, gamma, beta, zy, zb, B, T, H, W, C, G, Tz, hz, wz, eps, silu):
+def vae_norm_apply(x, out, sums, gamma, beta, zy, zb, B, T, H, W, C, G, Tz, hz, wz, eps, silu, out_lead=0):
+    """``out`` is [B, out_lead + T, H, W, C]; frames [0, out_lead) of each clip are left untouched."""
     _need(x, BF16, "x"), _need(out, BF16, "out"), _need(gamma, BF16, "gamma"), _need(beta, BF16, "beta")
     check(lib().orv_vae_norm_apply(_p(x), _p(out), _p(sums), _p(gamma), _p(beta), _p(zy), _p(zb), B, T, H, W, C, G, Tz, hz, wz,
-                                   float(eps), int(bool(silu)), _stream()), "orv_vae_norm_apply")
+                                   float(eps), int(bool(silu)), int(out_lead), _stream()), "orv_vae_norm_apply")
     return out

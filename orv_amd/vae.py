@@ -262,12 +262,19 @@ class AutoencoderKLCogVideoX(nn.Module):
         return hit[1:]
 
     # ---- building blocks on channels-last tensors [B, T, H, W, C] ----
-    def _conv(self, x, conv, k3, out_thw, stride=1, pad_lo=1, ups_s=0, ups_t=0, residual=None, cc=None):
+    def _conv(self, x, conv, k3, out_thw, stride=1, pad_lo=1, ups_s=0, ups_t=0, residual=None, cc=None, lead=0):
         """Causal / per-frame convolution as im2col slabs + GEMM.  ``k3`` = (kt, kh, kw); ``residual`` [.., Cout] is added in the
         GEMM epilogue.  ``cc`` = (prev, new) conv_cache dicts of the frame batching: with an entry for this convolution the last
-        kt-1 input frames of the previous batch stand in front of ``x`` instead of copies of its first frame."""
+        kt-1 input frames of the previous batch stand in front of ``x`` instead of copies of its first frame.  ``lead`` = kt-1
+        says ``x`` already has that many free frames in front (``_norm(..., lead=)``): the context is written there, the
+        activation itself is not copied."""
         t_shift = 0
-        if k3[0] > 1 and cc is not None:
+        if lead:
+            prev, new = cc
+            x[:, :lead] = prev[id(conv)] if id(conv) in prev else x[:, lead:lead + 1]
+            t_shift = lead
+            new[id(conv)] = x[:, -lead:].clone()
+        elif k3[0] > 1 and cc is not None:
             prev, new = cc
             if id(conv) in prev:
                 x = torch.cat([prev[id(conv)], x], dim=1)
@@ -321,8 +328,9 @@ class AutoencoderKLCogVideoX(nn.Module):
         ops.gemm(x2d.contiguous(), wp, bias, out, M, npad, kpad)
         return out if co == npad else out[:, :co].contiguous()
 
-    def _norm(self, x, norm, zq, silu=True):
-        """GroupNorm (+ SpatialNorm modulation by the latent ``zq`` [B, Tz, hz, wz, Cz]) (+ SiLU)."""
+    def _norm(self, x, norm, zq, silu=True, lead=0):
+        """GroupNorm (+ SpatialNorm modulation by the latent ``zq`` [B, Tz, hz, wz, Cz]) (+ SiLU).  The result has ``lead`` extra
+        frames in front, not written here (room for the next convolution's causal context)."""
         B, T, H, W, C = x.shape
         spatial = isinstance(norm, CogVideoXSpatialNorm3D)
         gn = norm.norm_layer if spatial else norm
@@ -333,19 +341,20 @@ class AutoencoderKLCogVideoX(nn.Module):
             _, Tz, hz, wz, cz = zq.shape
             z2 = zq.reshape(-1, cz)
             zy, zb = self._pointwise(z2, norm.conv_y.conv), self._pointwise(z2, norm.conv_b.conv)
-        out = torch.empty_like(x)
-        ops.vae_norm_apply(x, out, sums, gn.weight, gn.bias, zy, zb, B, T, H, W, C, gn.num_groups, Tz, hz, wz, gn.eps, silu)
+        out = torch.empty(B, lead + T, H, W, C, dtype=x.dtype, device=x.device)
+        ops.vae_norm_apply(x, out, sums, gn.weight, gn.bias, zy, zb, B, T, H, W, C, gn.num_groups, Tz, hz, wz, gn.eps, silu, lead)
         return out
 
     def _resnet(self, x, blk, zq, cc):
         B, T, H, W, C = x.shape
-        h = self._norm(x, blk.norm1, zq)
-        h = self._conv(h, blk.conv1.conv, (3, 3, 3), (T, H, W), cc=cc)
-        h = self._norm(h, blk.norm2, zq)
+        lead = 2 if cc is not None else 0
+        h = self._norm(x, blk.norm1, zq, lead=lead)
+        h = self._conv(h, blk.conv1.conv, (3, 3, 3), (T, H, W), cc=cc, lead=lead)
+        h = self._norm(h, blk.norm2, zq, lead=lead)
         sc = x
         if blk.in_channels != blk.out_channels:
             sc = self._pointwise(x.reshape(-1, C), blk.conv_shortcut).view(B, T, H, W, blk.out_channels)
-        return self._conv(h, blk.conv2.conv, (3, 3, 3), (T, H, W), residual=sc, cc=cc)
+        return self._conv(h, blk.conv2.conv, (3, 3, 3), (T, H, W), residual=sc, cc=cc, lead=lead)
 
     def _upsample(self, x, up):
         B, T, H, W, C = x.shape
@@ -401,9 +410,10 @@ class AutoencoderKLCogVideoX(nn.Module):
                 x = self._resnet(x, r, zq, cc)
             if up.upsamplers is not None:
                 x = self._upsample(x, up.upsamplers[0])
-        x = self._norm(x, d.norm_out, zq)
         _, T, H, W, _ = x.shape
-        return self._conv(x, d.conv_out.conv, (3, 3, 3), (T, H, W), cc=cc)
+        lead = 2 if cc is not None else 0
+        x = self._norm(x, d.norm_out, zq, lead=lead)
+        return self._conv(x, d.conv_out.conv, (3, 3, 3), (T, H, W), cc=cc, lead=lead)
 
     def _encode_batch(self, h, cc):
         e = self.encoder
@@ -416,9 +426,10 @@ class AutoencoderKLCogVideoX(nn.Module):
                 h = self._downsample(h, blk.downsamplers[0])
         for r in e.mid_block.resnets:
             h = self._resnet(h, r, None, cc)
-        h = self._norm(h, e.norm_out, None)
         _, T, H, W, _ = h.shape
-        return self._conv(h, e.conv_out.conv, (3, 3, 3), (T, H, W), cc=cc)
+        lead = 2 if cc is not None else 0
+        h = self._norm(h, e.norm_out, None, lead=lead)
+        return self._conv(h, e.conv_out.conv, (3, 3, 3), (T, H, W), cc=cc, lead=lead)
 
     def _batched(self, fn, x, size):
         outs, prev = [], {}
