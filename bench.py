@@ -160,7 +160,7 @@ def vae_decode_leg(latents, dev, loop_wall, steps, world, B, barrier):
             p.data.normal_(0, 1.0 / (p[0].numel() ** 0.5), generator=g)
     vae = vae.to(torch.bfloat16).eval()
     z = (latents.permute(0, 2, 1, 3, 4) / 1.15258426).contiguous()            # decode_latents layout (:1476-1479)
-    vae.decode(z[:1])
+    vae.decode(z)                          # untimed: weight packing, allocator growth and code-object loads at THIS batch size
     barrier()
     t0 = time.perf_counter()
     out = vae.decode(z).sample

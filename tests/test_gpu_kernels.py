@@ -430,3 +430,49 @@ def test_gemm_shape_fuzz_against_torch():
         err = (out.float() - ref).abs()
         tol = 1.6e-2 * ref.abs() + 2e-2
         assert bool((err <= tol).all()), (M, N, K, epi, err.max().item())
+
+
+_TILE_CHECK = r"""
+import sys, torch
+from orv_amd import ops
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(11)
+bad = []
+for M, N, K in [(3226, 1920 if int(sys.argv[1]) % 192 == 0 or int(sys.argv[1]) in (64, 128) else 1536, 1920), (700, 768, 256), (257, 768, 128)]:
+    if N % int(sys.argv[1]):
+        continue
+    for epi in (0, 1, 2, 3):
+        A = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
+        W = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(torch.bfloat16)
+        bias = torch.randn(N, device=dev, generator=g).to(torch.bfloat16)
+        R = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16)
+        ref = A.float() @ W.float().t() + bias.float()
+        if epi == 1:
+            ref = torch.nn.functional.gelu(ref, approximate="tanh")
+        if epi == 2:
+            ref = R.float() + ref
+        if epi == 3:      # acc * GELU_tanh'(R), no bias (dgrad of FeedForward net.2 fused with the GELU adjoint)
+            x = R.float().requires_grad_(True)
+            (dg,) = torch.autograd.grad(torch.nn.functional.gelu(x, approximate="tanh").sum(), x)
+            ref = (A.float() @ W.float().t()) * dg
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.gemm(A, W, None if epi == 3 else bias, out, M, N, K, epilogue=epi, **(dict(R=R, ldr=N) if epi >= 2 else {}))
+        err = (out.float() - ref).abs()
+        if not bool((err <= 1.6e-2 * ref.abs() + 2e-2).all()):
+            bad.append((M, N, K, epi, float(err.max())))
+print("BAD", bad) if bad else print("TILE-OK")
+"""
+
+
+@pytest.mark.parametrize("tile", ["2,256,256", "2,256,128", "1,256,384", "1,256,256", "1,256,192", "1,256,128", "0,256,192",
+                                  "0,256,128", "0,256,64", "0,128,192", "0,128,128", "0,128,64", "0,192,128"])
+def test_every_gemm_tile_instantiation_forced(tile):
+    """The tile chooser only ever picks what its cost model prefers; here every candidate (phased / ring / simple, every tile
+    shape) is pinned with ORV_GEMM_TILE in a fresh process and checked on ragged M, single- and multi-round grids, epilogues
+    0-3 against torch fp32."""
+    import os, subprocess, sys
+    env = dict(os.environ, ORV_GEMM_TILE=tile)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _TILE_CHECK, tile.split(",")[2]], cwd=root, env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "TILE-OK" in r.stdout, (tile, r.stdout[-2000:], r.stderr[-2000:])
