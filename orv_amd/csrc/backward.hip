@@ -595,8 +595,10 @@ extern "C" int orv_colsum(const void* src, int ld, float* out, int R, int C, voi
     ORV_REQUIRE(src && out && R > 0 && C > 0, "orv_colsum: bad arguments");
     ORV_REQUIRE(C % 8 == 0 && ld % 8 == 0 && ((uintptr_t)src & 15) == 0, "orv_colsum: C / ld must be multiples of 8, src 16-byte aligned");
     const int cblocks = (C + 511) / 512;
-    int rpb = 256;
-    while (rpb > 32 && (long)cblocks * ((R + rpb - 1) / rpb) < 512) rpb >>= 1;   // enough workgroups for 256 CUs
+    // about one workgroup per CU: fewer, longer slabs mean fewer fp32 atomics on the same C addresses (measured at R = 12904:
+    // C = 1920 46 -> 20 us with 204 instead of 808 workgroups, C = 5760 / 7680 32 / 35 -> 27 / 32 us)
+    int rpb = 512;
+    while (rpb > 32 && (long)cblocks * ((R + rpb - 1) / rpb) < 200) rpb >>= 1;
     dim3 grid(cblocks, (R + rpb - 1) / rpb);
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (long)ld, out, R, C, rpb);
     return orv_check_launch("orv_colsum");
