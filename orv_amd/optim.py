@@ -54,6 +54,7 @@ class FusedAdamW:
             p.data = v                                   # the module keeps its Parameter objects; only their storage moves
             views_p.append(v)
             views_g.append(flat_g[off:off + p.numel()].view(p.shape))
+        _state.register_grad_views(self.params, views_g)
         self._flat = dict(
             p=flat_p, g=flat_g, m=torch.zeros(total, dtype=torch.float32, device=dev),
             v=torch.zeros(total, dtype=torch.float32, device=dev), views_g=views_g,
@@ -85,10 +86,13 @@ class FusedAdamW:
                 i, g = index.get(id(p)), grads.get(id(p))
                 if i is None or g is None or i in filled:
                     continue
-                idx.append(i); srcs.append(g); dsts.append(f["views_g"][i])
+                idx.append(i)
+                if g.data_ptr() != f["views_g"][i].data_ptr():      # else: the backward wrote it in place (_state.grad_view)
+                    srcs.append(g); dsts.append(f["views_g"][i])
             if not idx:
                 return
-            torch._foreach_copy_(dsts, srcs)
+            if srcs:
+                torch._foreach_copy_(dsts, srcs)
             filled.update(idx)
             red.ready(idx)
 
@@ -123,8 +127,9 @@ class FusedAdamW:
             if missing:
                 torch._foreach_zero_(missing)
         live_src = has_grad
-        srcs = [p.grad for i, (p, a) in enumerate(zip(self.params, live_src)) if a and i not in done]
-        dsts = [v for i, (v, a) in enumerate(zip(f["views_g"], live_src)) if a and i not in done]
+        pairs = [(p.grad, v) for i, (p, v, a) in enumerate(zip(self.params, f["views_g"], live_src))
+                 if a and i not in done and p.grad.data_ptr() != v.data_ptr()]     # in-place gradients need no copy
+        srcs, dsts = [s_ for s_, _ in pairs], [d_ for _, d_ in pairs]
         if srcs:
             torch._foreach_copy_(dsts, srcs)
         if live != f["active_host"]:

@@ -19,7 +19,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from . import ops
+from . import _state, ops
 
 BF16 = torch.bfloat16
 LOG2E = 1.4426950408889634
@@ -448,7 +448,9 @@ def backward(model, sv, dout, drecon=None, grad_hook=None) -> Dict[int, torch.Te
         if id(param) in grads:
             _wgrad(dY2d, X2d, grads[id(param)], M_, N_, K_)
         else:                                   # first (normally only) contribution: plain store, no zero-fill + re-read
-            g = torch.empty_like(param, dtype=BF16)
+            g = _state.grad_view(param)         # straight into the fused optimizer's flat gradient buffer when there is one
+            if g is None:
+                g = torch.empty_like(param, dtype=BF16)
             grads[id(param)] = g
             _wgrad(dY2d, X2d, g, M_, N_, K_, accumulate=False)
 
