@@ -418,14 +418,17 @@ def main():
         if dom:
             dom["avg_ms"] = round(dom["total_ms"] / dom["launches"], 4)
             dom["tflops"] = round(dom["flop"] / dom["total_ms"] / 1e9, 1)
-        traffic = None
+        # PMC figures of the dominant symbol come from the committed profile of this same command (tools/pmc_bench.sh: separate
+        # rocprofv3 --pmc passes); they are not re-measured live
+        traffic = mfma_busy = clock = None
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if dom and os.path.exists(prof):
             try:
                 ent = json.load(open(prof)).get(dom["kernel"])
-                traffic = None if ent is None else int(ent.get("total_bytes"))
+                if ent is not None:
+                    traffic, mfma_busy, clock = int(ent.get("total_bytes")), ent.get("mfma_busy"), ent.get("clock_ghz")
             except Exception:
-                traffic = None
+                traffic = mfma_busy = clock = None
         line = {
             "metric": "denoise-steps/sec", "value": round(value, 3), "unit": "steps/s (clips x denoise steps per second)",
             "n_gpus": world, "ranks_seen": seen, "steps": args.steps, "warmup": args.warmup,
@@ -442,7 +445,7 @@ def main():
                 "bound": "mfma", "kernel": dom["kernel"], "shapes": dom["shapes"], "achieved": dom["tflops"],
                 "peak": MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "launches": dom["launches"], "avg_ms": dom["avg_ms"]},
+                "mfma_busy": mfma_busy, "clock_ghz_under_pmc": clock, "launches": dom["launches"], "avg_ms": dom["avg_ms"]},
             "kernels": kernels[:8],
             "vae_decode": vae_leg,
         }

@@ -43,7 +43,12 @@ for k in sorted(dur, key=lambda k: -sum(dur[k])):
     # traffic per launch = MEAN over the symbol's launches (all its shapes together), like bench.py's avg_ms for the symbol
     fb = 2 * 1024 * mean(fe[k]["FETCH_SIZE"]) if k in fe else None
     wb = (cal or 1.0) * 1024 * mean(wr[k]["WRITE_SIZE"]) if k in wr else None
-    traffic[k] = {"launches": len(dur[k]), "fetch_bytes": fb, "write_bytes": wb, "total_bytes": (fb or 0) + (wb or 0)}
+    # launch-weighted MFMA-busy fraction and clock of the symbol (sum over launches / sum over launches), for bench.py's roofline
+    gsum = sum(sq1[k].get("GRBM_GUI_ACTIVE", [])) / 8
+    bsum = sum(sq1[k].get("SQ_VALU_MFMA_BUSY_CYCLES", []))
+    traffic[k] = {"launches": len(dur[k]), "fetch_bytes": fb, "write_bytes": wb, "total_bytes": (fb or 0) + (wb or 0),
+                  "mfma_busy": round(bsum / (1024 * gsum), 4) if gsum else None,
+                  "clock_ghz": round(gsum / sum(dur[k]), 3) if dur[k] else None, "avg_us_under_pmc": round(sum(dur[k]) / len(dur[k]) / 1e3, 2)}
     rows.append(dict(kernel=k, n=len(dur[k]), us=d / 1e3, total_ms=sum(dur[k]) / 1e6, clk=gui / d if d else 0,
                      mfma=a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024 * gui) if gui else 0,
                      wait=a.get("SQ_WAIT_ANY", 0) / wc, stall=a.get("SQ_WAIT_INST_ANY", 0) / wc, act=a.get("SQ_ACTIVE_INST_ANY", 0) / wc,

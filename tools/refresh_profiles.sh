@@ -21,5 +21,7 @@ cp gpurun_out/prof_vae_r2/r2_vae_kernel_stats_summary.txt $O/vae_kernel_stats_su
 python tools/vae_bench.py 1 5 2>/dev/null | tail -1 > $O/vae_bench.txt; python tools/vae_bench.py 4 3 2>/dev/null | tail -1 >> $O/vae_bench.txt
 bash tools/pmc_bench.sh r2 --no-vae > $O/pmc_bench.log 2>&1 < /dev/null
 cp gpurun_out/pmc_bench_r2/summary.txt $O/pmc_summary_inference.txt; cp gpurun_out/pmc_bench_r2/hbm_traffic.json $O/hbm_traffic.json
+bash tools/pmc_bench.sh r2tr --mode train > $O/pmc_bench_train.log 2>&1 < /dev/null
+cp gpurun_out/pmc_bench_r2tr/summary.txt $O/pmc_summary_train.txt; cp gpurun_out/pmc_bench_r2tr/hbm_traffic.json $O/hbm_traffic_train.json
 find gpurun_out -name "*.csv" -size +1M -delete
 ls -la $O
