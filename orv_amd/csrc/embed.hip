@@ -25,31 +25,31 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 // Block = 256 threads (4 waves), handles MT=16 rows x NPB output columns. x tile staged once in LDS as fp32.
 constexpr int SK_MT = 16;
-constexpr int SK_NPW = 8;   // output columns per wave
+constexpr int SK_NPW = 8;   // output columns per wave at most (the launcher lowers it until the grid covers the CUs)
 __global__ __launch_bounds__(256) void skinny_linear_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ xb,
                                                             int xb_rep, const bf16_t* __restrict__ W,
                                                             const bf16_t* __restrict__ bias, void* __restrict__ out,
                                                             int M, int N, int K, int act_in, int act_out, int out_f32,
-                                                            long ldo, orv_rowmap_t omap) {
+                                                            long ldo, orv_rowmap_t omap, int npw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* xs = (bf16_t*)smem;  // [SK_MT][K] bf16, act_in applied
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * SK_MT;
     const int mt = min(SK_MT, M - m0);
-    for (int i = tid; i < SK_MT * K; i += 256) {
-        const int r = i / K, k = i % K;
-        float v = 0.f;
-        if (r < mt) {
-            v = bf2f(x[(long)(m0 + r) * K + k]);
-            if (xb) v = bf2f(f2bf(v + bf2f(xb[(long)((m0 + r) / xb_rep) * K + k])));  // the reference adds in the model dtype
-            v = apply_act(v, act_in);
+    for (int r = 0; r < SK_MT; ++r)
+        for (int k = tid; k < K; k += 256) {
+            float v = 0.f;
+            if (r < mt) {
+                v = bf2f(x[(long)(m0 + r) * K + k]);
+                if (xb) v = bf2f(f2bf(v + bf2f(xb[(long)((m0 + r) / xb_rep) * K + k])));  // the reference adds in the model dtype
+                v = apply_act(v, act_in);
+            }
+            xs[r * K + k] = f2bf(v);
         }
-        xs[r * K + k] = f2bf(v);
-    }
     __syncthreads();
     const int nchunk = (K % 8 == 0) ? (K >> 3) : 0;  // rows are 16-byte aligned only when K % 8 == 0
-    for (int j = 0; j < SK_NPW; ++j) {
-        const int n = (blockIdx.x * 4 + wave) * SK_NPW + j;
+    for (int j = 0; j < npw; ++j) {
+        const int n = (blockIdx.x * 4 + wave) * npw + j;
         if (n >= N) break;
         float acc[SK_MT];
 #pragma unroll
@@ -267,10 +267,14 @@ extern "C" int orv_skinny_linear(const void* x, const void* xb, int xb_rep, cons
         smem_max = smem;
     }
     // rows of W must be 16-byte aligned for the vector path: K % 8 == 0; otherwise the scalar tail handles K < 64
-    dim3 grid((N + 4 * SK_NPW - 1) / (4 * SK_NPW), (M + SK_MT - 1) / SK_MT);
+    // columns per wave: as many as keep >= 256 workgroups in flight (N = 512: one column per wave, 128 workgroups instead of 16)
+    const int mblocks = (M + SK_MT - 1) / SK_MT;
+    int npw = SK_NPW;
+    while (npw > 1 && (long)((N + 4 * npw - 1) / (4 * npw)) * mblocks < 256) npw >>= 1;
+    dim3 grid((N + 4 * npw - 1) / (4 * npw), mblocks);
     hipLaunchKernelGGL(skinny_linear_kernel, grid, dim3(256), smem, (hipStream_t)stream, (const bf16_t*)x,
                        (const bf16_t*)xb, xb_rep, (const bf16_t*)W, (const bf16_t*)bias, out, M, N, K, act_in, act_out,
-                       out_f32, (long)ldo, omap);
+                       out_f32, (long)ldo, omap, npw);
     return orv_check_launch("orv_skinny_linear");
 }
 
