@@ -285,7 +285,9 @@ long orv_vae_groupnorm_scratch(int B, long N, int C, int G);
 int orv_vae_groupnorm_stats(const void* x, float* sums, float* scratch, int B, long N, int C, int G, void* stream);
 /* out = act(GroupNorm(x) [* zy[z(v)] + zb[z(v)]]): affine GroupNorm from `sums`, CogVideoXSpatialNorm3D modulation by
  * conv_y(zq) / conv_b(zq) given at LATENT resolution [B,Tz,hz,wz,C] and looked up by F.interpolate(nearest) index rules
- * (first frame of an odd-length clip apart), optional SiLU.  zy == zb == NULL: plain GroupNorm. */
+ * (first frame of an odd-length clip apart), optional SiLU.  zy == zb == NULL: plain GroupNorm.
+ * out is [B, out_lead + T, H, W, C]: the first out_lead (0..8) frames of every clip are left untouched - the caller puts the
+ * causal context of the NEXT convolution there (conv_cache frames or copies of the first frame; orv_conv_t.t_shift = out_lead). */
 int orv_vae_norm_apply(const void* x, void* out, const float* sums, const void* gamma, const void* beta, const void* zy,
                        const void* zb, int B, int T, int H, int W, int C, int G, int Tz, int hz, int wz, float eps, int silu_act,
                        int out_lead, void* stream);
