@@ -47,7 +47,14 @@ def _wgrad(dY2d, X2d, dW, M, N, K, accumulate=True):
     """dW[N,K] (+)= dY[M,N]^T . X[M,K]  through two transposes and the NT GEMM (contraction over the M rows)."""
     dYT = ops.transpose(dY2d, M, N)           # [N, M_pad]
     XT = ops.transpose(X2d, M, K)             # [K, M_pad]
-    if K % 64 == 0 and not accumulate:
+    if not accumulate and N % 256 == 0 and K % 256 != 0 and K % 64 == 0 and N >= 2 * K:
+        # tall gradient whose long side only is a multiple of 256 (FeedForward net.0: [7680, 1920]): compute dW^T = X^T . dY with
+        # the long side as the GEMM's N, where the 256 x 256 phased kernel applies, and transpose the 30 MB result
+        # (0.47 -> 0.39 + 0.03 ms at M = 12904)
+        dWT = torch.empty(K, N, dtype=BF16, device=dW.device)
+        ops.gemm(XT, dYT, None, dWT, K, N, dYT.shape[1])
+        ops.transpose(dWT, K, N, out=dW.view(N, K))
+    elif K % 64 == 0 and not accumulate:
         ops.gemm(dYT, XT, None, dW, N, K, dYT.shape[1])
     elif K % 64 == 0:
         ops.gemm(dYT, XT, None, dW, N, K, dYT.shape[1], epilogue=2, R=dW, ldr=K)
