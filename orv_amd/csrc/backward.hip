@@ -170,8 +170,10 @@ __global__ __launch_bounds__(256) void gated_bwd_kernel(const bf16_t* __restrict
 //      the two dx means) go wave_sum -> LDS -> all threads, one barrier each for the four rows together.  Column sums stay
 //      private to a thread: no cross-wave reduction.  dscale/dshift: fp32 atomics (~38 blocks per table row);
 //      dgamma/dbeta: per-block partials + reduce kernel (every block would hit the same D addresses otherwise).
-constexpr int LNB_RB = 16;   // rows per workgroup
-constexpr int LNB_R = 4;     // rows in flight
+// rows per workgroup / rows in flight per pass, from a sweep at the 2B training shape (whole call incl. the two reductions):
+// (16, 4) 105-117 us, (16, 2) 76 us, (16, 1) 76 us, (12, 1) 77 us, (20, 2) 78 us, (24, 2) 84 us, (8, 2) 108 us, (32, 4) 105 us
+constexpr int LNB_RB = 16;
+constexpr int LNB_R = 2;
 
 struct LnBwdArgs {
     const bf16_t *dy, *x, *dres; bf16_t* dx;
@@ -352,11 +354,12 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const LnBwdArgs p) {
 }
 
 // out0[j] += sum_blocks part[blk][0][j] ; out1[j] += sum_blocks part[blk][1][j]   (grid: D/256 x slabs of 64 blocks)
+constexpr int LNP_SLICE = 16;   // workgroup partials one thread adds before its atomic (64: 104 workgroups, 20 us; 16: 408)
 __global__ __launch_bounds__(256) void ln_partials_reduce_kernel(const float* __restrict__ part, int nblk, int D,
                                                                  float* __restrict__ out0, float* __restrict__ out1) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= D) return;
-    const int b0 = blockIdx.y * 64, b1 = min(nblk, b0 + 64);
+    const int b0 = blockIdx.y * LNP_SLICE, b1 = min(nblk, b0 + LNP_SLICE);
     float s0 = 0.f, s1 = 0.f;
     for (int b = b0; b < b1; ++b) { s0 += part[(long)b * 4 * D + j]; s1 += part[(long)b * 4 * D + D + j]; }
     if (out0) atomicAdd(out0 + j, s0);
@@ -669,7 +672,7 @@ extern "C" int orv_layernorm_modulate_bwd(const void* dy, const void* x, orv_row
     if (D <= 2048) hipLaunchKernelGGL(ln_mod_bwd_kernel<1>, dim3(nblk), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(ln_mod_bwd_kernel<2>, dim3(nblk), dim3(256), 0, st, a);
     if (a.want_gb)
-        hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((D + 255) / 256, (nblk + 63) / 64), dim3(256), 0, st, scratch, nblk, D,
+        hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((D + 255) / 256, (nblk + LNP_SLICE - 1) / LNP_SLICE), dim3(256), 0, st, scratch, nblk, D,
                            dgamma, dbeta);
     if (scale) {
         const int ngroups = a.bg > 0 ? (a.bpb - a.bt) / a.bg : 0;
