@@ -263,6 +263,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_v2_kernel(const AttnArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 1 < nt) stage_load((t + 1) & 1, (t + 1) * KV);
+        // a wave whose 32 query rows all lie past S (the last 256-row block of a head: 3226 = 12 x 256 + 154) only stages K / V
+        // and meets the barriers: its MFMA / softmax work would be thrown away, and its issue slots go to the other waves
+        if (q0 >= p.S) continue;
         const char* sK = smem + (t & 1) * SLOT_BYTES;
         const char* sV = sK + TILE_BYTES;
 

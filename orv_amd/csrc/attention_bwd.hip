@@ -134,6 +134,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const BwdArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 1 < nt) stage_load((t + 1) & 1, (t + 1) * 64);
+        if (q0 >= p.S) continue;      // all 32 query rows of this wave are past S: stage and synchronise only
         const char* sK = smem + (t & 1) * 3 * TILE;
         const char* sV = sK + TILE;
         const char* sKT = sK + 2 * TILE;
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const BwdArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 1 < nt) stage_load((t + 1) & 1, (t + 1) * 64);
+        if (k0 >= p.S) continue;      // all 32 key rows of this wave are past S: stage and synchronise only
         const char* sQ = smem + (t & 1) * STG;
         const char* sDO = sQ + TILE;
         const char* sQT = sQ + 2 * TILE;
