@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liborv_mi355.so")
+# ORV_LIB: another build of the same library (developer A/B runs: tools/*.sh); the default is the in-tree build
+LIB_PATH = os.environ.get("ORV_LIB") or os.path.join(_HERE, "liborv_mi355.so")
 
 
 class Groups(Structure):
