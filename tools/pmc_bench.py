@@ -28,7 +28,7 @@ lnk = next((k for k in wr if k.startswith("ln_mod_kernel")), None)
 if lnk:
     known = 4 * 3226 * 1920 * 2
     meas = med(wr[lnk]["WRITE_SIZE"]) * 1024
-    if meas > 0 and 0.2 < known / meas < 5:
+    if meas > 0 and 0.9 < known / meas < 1.1:      # only meaningful on the headline shape (B=4, 2B); other runs keep 1.0
         cal = known / meas
 rows, traffic = [], {"_units": "bytes per launch", "_fetch_correction": 2.0, "_write_calibration": cal}
 for k in sorted(dur, key=lambda k: -sum(dur[k])):

@@ -5,7 +5,8 @@ TAG=${1:-r2}; shift
 cd /tmp && export TMPDIR=/tmp
 OUT=/root/repo/gpurun_out/pmc_bench_$TAG
 rm -rf $OUT; mkdir -p $OUT
-run() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT -o $name -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline $BENCH_ARGS > $OUT/log_$name.txt 2>&1; }
+# PMC_CMD overrides the profiled command (default: two steps of bench.py with the given arguments)
+run() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT -o $name -- ${PMC_CMD:-python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline $BENCH_ARGS} > $OUT/log_$name.txt 2>&1 < /dev/null; }
 BENCH_ARGS="$@"
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
 run sq2 SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS
