@@ -72,19 +72,27 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 __global__ __launch_bounds__(256) void groups_reduce_kernel(const float* __restrict__ part, long stride, int sel0, int sel1,
                                                             int D, float* __restrict__ out0, float* __restrict__ out1,
                                                             long mod_b, long mod_g, int bt, int bg, int bpb, int ngroups) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= D) return;
+    // 64 columns x 4 slices of the workgroup list per block; the slices are combined through LDS in a fixed order
+    // (deterministic, and four loads in flight per column instead of one thread walking ~38 partials alone)
+    __shared__ float red[2][3][64];
+    const int jl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + jl;
     const int b = blockIdx.y / (1 + ngroups), g = blockIdx.y % (1 + ngroups);
     const int first = b * bpb + (g == 0 ? 0 : bt + (g - 1) * bg), count = g == 0 ? bt : bg;
     if (count == 0) return;
     float s0 = 0.f, s1 = 0.f;
-    for (int k = 0; k < count; ++k) {
-        s0 += part[(long)(first + k) * stride + (long)sel0 * D + j];
-        if (out1) s1 += part[(long)(first + k) * stride + (long)sel1 * D + j];
+    if (j < D)
+        for (int k = sl; k < count; k += 4) {
+            s0 += part[(long)(first + k) * stride + (long)sel0 * D + j];
+            if (out1) s1 += part[(long)(first + k) * stride + (long)sel1 * D + j];
+        }
+    if (sl > 0) { red[0][sl - 1][jl] = s0; red[1][sl - 1][jl] = s1; }
+    __syncthreads();
+    if (sl == 0 && j < D) {
+        const long off = b * mod_b + g * mod_g + j;
+        out0[off] += s0 + red[0][0][jl] + red[0][1][jl] + red[0][2][jl];
+        if (out1) out1[off] += s1 + red[1][0][jl] + red[1][1][jl] + red[1][2][jl];
     }
-    const long off = b * mod_b + g * mod_g + j;
-    out0[off] += s0;
-    if (out1) out1[off] += s1;
 }
 
 // ---- gated residual backward (cogvideox_control.py:419-421,442-443):  out = x + gate[b,g] * y
@@ -637,7 +645,7 @@ extern "C" int orv_gated_residual_bwd(const void* dout, const void* y, const flo
     if (D <= 2048) ORV_CASE(1); else ORV_CASE(2);
 #undef ORV_CASE
     const int ngroups = bg > 0 ? (bpb - bt) / bg : 0;
-    hipLaunchKernelGGL(groups_reduce_kernel, dim3((D + 255) / 256, batch * (1 + ngroups)), dim3(256), 0, st, scratch, (long)D, 0, 0, D,
+    hipLaunchKernelGGL(groups_reduce_kernel, dim3((D + 63) / 64, batch * (1 + ngroups)), dim3(256), 0, st, scratch, (long)D, 0, 0, D,
                        dgate, (float*)nullptr, mod_b, mod_g, bt, bg, bpb, ngroups);
     return orv_check_launch("orv_gated_residual_bwd");
 }
@@ -676,7 +684,7 @@ extern "C" int orv_layernorm_modulate_bwd(const void* dy, const void* x, orv_row
                            dgamma, dbeta);
     if (scale) {
         const int ngroups = a.bg > 0 ? (a.bpb - a.bt) / a.bg : 0;
-        hipLaunchKernelGGL(groups_reduce_kernel, dim3((D + 255) / 256, batch * (1 + ngroups)), dim3(256), 0, st, scratch, 4L * D, 2,
+        hipLaunchKernelGGL(groups_reduce_kernel, dim3((D + 63) / 64, batch * (1 + ngroups)), dim3(256), 0, st, scratch, 4L * D, 2,
                            3, D, dscale, dshift, mod_b, mod_g, a.bt, a.bg, a.bpb, ngroups);
     }
     return orv_check_launch("orv_layernorm_modulate_bwd");
