@@ -394,3 +394,51 @@ def test_gradient_checkpointing_flag_is_accepted_and_changes_nothing():
     assert grads[0].keys() == grads[1].keys()
     for n in grads[0]:
         assert rel_l2(grads[1][n], grads[0][n]) <= 2e-3, n
+
+
+def test_inplace_gradient_views_equal_the_copied_path():
+    """After the fused optimizer has built its flat buffers, the backward writes weight gradients straight into the parameter's
+    segment (`_state.grad_view`).  Three optimizer steps (the second and third with the in-place path live), the last one as a
+    window of two accumulated micro-batches, must leave the parameters where the copy path leaves them, the big weights'
+    p.grad must alias the flat buffer, and an accumulated micro-batch must not clobber the gradient already there."""
+    from orv_amd import _state, schedulers, sft
+    from orv_amd.cogvideox_control import CogVideoXTransformer3DModelTraj
+    from orv_amd.optim import FusedAdamW
+    dev = torch.device("cuda:0")
+    cfg, extra, ins, w, outs = load_golden("fwd_actions")
+    sched = schedulers.CogVideoXDDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012,
+                                              beta_schedule="scaled_linear", prediction_type="v_prediction",
+                                              rescale_betas_zero_snr=True, snr_shift_scale=3.0, timestep_spacing="trailing")
+    g0 = torch.Generator().manual_seed(9)
+    x0 = torch.randn(2, 3, 16, 8, 12, generator=g0).to(dev, BF)
+    batch = sft.Batch(x0, torch.zeros_like(x0), ins["encoder_hidden_states"].to(dev, BF), ins["actions"].to(dev), None, None,
+                      torch.ones(3, dtype=torch.bool, device=dev), 1)
+    results, aliased = [], []
+    saved = _state._INPLACE_GRADS
+    try:
+        for inplace in (False, True):
+            _state._INPLACE_GRADS = inplace
+            m = CogVideoXTransformer3DModelTraj(**cfg)
+            m.load_state_dict(w)
+            m = m.to(dev, BF).train()
+            m.action_embed.forced_mask = torch.zeros(2, dtype=torch.bool)
+            opt = FusedAdamW(m.parameters(), lr=1e-3, betas=(0.9, 0.95), weight_decay=1e-3, max_grad_norm=1.0)
+            wt = m.transformer_blocks[1].ff.net[0].proj.weight
+            for step in range(2):
+                sft.sft_step(m, sched, opt, batch, generator=torch.Generator(device=dev).manual_seed(100 + step))
+            idx = [i for i, p in enumerate(opt.params) if p is wt][0]
+            # window of two micro-batches: look at p.grad between them
+            sft.sft_step(m, sched, opt, batch, generator=torch.Generator(device=dev).manual_seed(200), gradient_accumulation_steps=2,
+                         micro_step=0)
+            g_first = wt.grad.detach().clone()
+            aliased.append(wt.grad.data_ptr() == opt._flat["views_g"][idx].data_ptr())
+            sft.sft_step(m, sched, opt, batch, generator=torch.Generator(device=dev).manual_seed(200), gradient_accumulation_steps=2,
+                         micro_step=1)
+            results.append(({k: v.detach().float().clone() for k, v in m.state_dict().items()}, g_first.float()))
+    finally:
+        _state._INPLACE_GRADS = saved
+    assert aliased == [False, True], aliased
+    (sd0, g0_), (sd1, g1_) = results
+    assert ((g0_ - g1_).norm() / g0_.norm()).item() <= 2e-3            # same gradient either way (fp32-atomic column sums aside)
+    worst = max(((sd0[k] - sd1[k]).abs().max() / (sd0[k].abs().max() + 1e-6)).item() for k in sd0)
+    assert worst <= 1e-2, worst
