@@ -594,6 +594,145 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(const GemmArgs p, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Strip form of the stride-1 3x3(x3) convolution: the three taps dx = -1, 0, +1 of one (dt, dy, 64-channel block) read the SAME
+// 256 + 2 voxel lines, so they are staged once as a strip (row r = flattened voxel m0 - 1 + r) and the three K-tiles read it at
+// row offsets 0, 1, 2.  The LDS-DMA moves 33 KB of activations + 3 W tiles per three K-tiles instead of 3 x 32 KB + 3 W tiles: at
+// N = 128 (the full-resolution stage of the decoder, DMA-rate bound: 48 KB per K-tile against 1024 MFMA cycles) that is 27 KB per
+// K-tile.  A flattened strip crosses image rows: where x + dx leaves the row the neighbouring line belongs to another row, and
+// the A fragment of that output voxel is zeroed instead (the tap falls into the zero padding there).  Lines whose own (y + dy)
+// is outside the image come from the zero page, t + dt < 0 replicates frame 0 (or reads the conv_cache frames), as in
+// conv_gemm_kernel.  K-tile order: (dt, dy) major, channel block, dx minor; the weight column is ((dt*kh + dy)*3 + dx)*C + c.
+// ---------------------------------------------------------------------------------------------------------------
+template <int BN, int EPI>
+__global__ __launch_bounds__(512) void conv_strip_kernel(const GemmArgs p, const ConvArgs cv) {
+    constexpr int BM = 256, MB = 2, NB = BN / 64;
+    constexpr int SP = 33;                         // DMA pieces (8 lines each) of one strip: 264 >= 258 lines
+    constexpr int STRIP = SP * 1024, WT = BN * 128;
+    constexpr int B_LD = BN / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // strip 0 | strip 1 | W 0 | W 1
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tm, tn;
+    tile_of_block(p, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int srow = lane >> 3, slot = lane & 7;
+
+    // strip pieces of this wave: q = wave + 8 j (j < 4), wave 0 also q = 32; lane -> strip line r = 8 q + srow = voxel m0 - 1 + r
+    constexpr int SJ = 5;
+    int vbs[SJ], vt[SJ], vy[SJ], vx[SJ], vchunk[SJ];   // first source frame of the batch element, t, y, x of the line's voxel
+#pragma unroll
+    for (int j = 0; j < SJ; ++j) {
+        const int q = j < 4 ? wave + 8 * j : 32;
+        const int r = q * 8 + srow;
+        vchunk[j] = (slot ^ ((r >> 1) & 7)) * 8;
+        long m = min(max((long)m0 - 1 + r, 0L), (long)p.M - 1);
+        vx[j] = (int)(m % cv.W); m /= cv.W;
+        vy[j] = (int)(m % cv.H); m /= cv.H;
+        vt[j] = (int)(m % cv.T);
+        vbs[j] = (int)(m / cv.T) * cv.Ts;
+    }
+    const bf16_t* b_src[B_LD];
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+        const int row = (wave * B_LD + j) * 8 + srow;
+        b_src[j] = p.W + (long)(n0 + row) * p.ldw + (slot ^ ((row >> 1) & 7)) * 8;
+    }
+    const int cblocks = cv.C >> 6;
+    const int ngrp = cv.kt * cv.kh * cblocks;      // (dt, dy, channel block) groups of three K-tiles
+    auto issue_strip = [&](int j, int sb, int grp) {           // piece j of this wave for group grp -> strip buffer sb
+        const int tdy = grp / cblocks, c0 = (grp - tdy * cblocks) << 6;            // wave-uniform
+        const int dy = tdy % cv.kh - cv.pad_lo, dt = tdy / cv.kh + cv.t_shift - (cv.kt - 1);
+        const int ti = max(vt[j] + dt, 0), yi = vy[j] + dy;
+        const bool ok = (unsigned)yi < (unsigned)cv.Hs;
+        const unsigned idx = (unsigned)((vbs[j] + ti) * cv.Hs + yi) * (unsigned)cv.Ws + (unsigned)vx[j];
+        const bf16_t* g = cv.src + (long)idx * cv.C + (c0 + vchunk[j]);
+        if (!ok) g = (const bf16_t*)orv_zero_page + (lane & 7) * 8;
+        const int q = j < 4 ? wave + 8 * j : 32;
+        glds16(g, smem + sb * STRIP + q * 1024);
+    };
+    auto issue_w = [&](int j, int wb, int grp, int dx) {
+        const int tdy = grp / cblocks, cb = grp - tdy * cblocks;
+        const long kcol = ((long)(tdy * 3 + dx) * cblocks + cb) * BK;
+        glds16(b_src[j] + kcol, smem + 2 * STRIP + wb * WT + (wave * B_LD + j) * 1024);
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
+    const int b_row_off = (wn * (BN / 2) + l31) * 128;
+    // output rows of this lane's two A fragments and their x coordinate (for the dx = -1 / +1 edge masks)
+    int arow[MB];
+    bool edge_lo[MB], edge_hi[MB];
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+        arow[j] = wm * 64 + j * 32 + l31;
+        const int x = (int)(((long)m0 + arow[j]) % cv.W);
+        edge_lo[j] = x == 0;
+        edge_hi[j] = x == cv.W - 1;
+    }
+    f32x16 acc[NB][MB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < MB; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // prologue: strip of group 0 and W of K-tile 0
+#pragma unroll
+    for (int j = 0; j < SJ; ++j)
+        if (j < 4 || wave == 0) issue_strip(j, 0, 0);
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) issue_w(j, 0, 0, 0);
+
+    int wb = 0;
+    for (int grp = 0; grp < ngrp; ++grp) {
+        const int sb = grp & 1;
+        const bool more = grp + 1 < ngrp;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // DMA of the next K-tile's W (the last K-tile re-fetches W of K-tile 0, never read: uniform issue count) and this
+            // K-tile's share of the next group's strip.  The k-step loop is left to the compiler's scheduler: the hand-placed
+            // form of conv_gemm_kernel (fragments one k-step ahead, DMA issues pinned between the MFMAs) measured 3.5 % slower
+            // here (71.2 vs 68.7 ms per decode, same box, three interleaved rounds)
+            const int ng = dx == 2 ? (more ? grp + 1 : 0) : grp, ndx = dx == 2 ? 0 : dx + 1;
+            const char* sA = smem + sb * STRIP;
+            const char* sW = smem + 2 * STRIP + wb * WT;
+            auto read_frags = [&](int ks, bf16x8 (&af)[MB], bf16x8 (&bf)[NB]) {
+#pragma unroll
+                for (int j = 0; j < MB; ++j) {
+                    const int r = arow[j] + dx;                                   // strip line of tap dx for this output voxel
+                    af[j] = *(const bf16x8*)(sA + r * 128 + (((ks * 2 + hi) ^ ((r >> 1) & 7)) * 16));
+                    if ((dx == 0 && edge_lo[j]) || (dx == 2 && edge_hi[j])) af[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int i = 0; i < NB; ++i) bf[i] = *(const bf16x8*)(sW + b_row_off + i * 32 * 128 + (((ks * 2 + hi) ^ sw) * 16));
+            };
+#pragma unroll
+            for (int j = 0; j < B_LD; ++j) issue_w(j, wb ^ 1, ng, ndx);
+            if (more) {
+                if (dx < 2) { issue_strip(2 * dx, sb ^ 1, grp + 1); issue_strip(2 * dx + 1, sb ^ 1, grp + 1); }
+                else if (wave == 0) issue_strip(4, sb ^ 1, grp + 1);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 af1[MB], bf1[NB];
+                read_frags(ks, af1, bf1);
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+#pragma unroll
+                    for (int j = 0; j < MB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf1[i], af1[j], acc[i][j], 0, 0, 0);
+            }
+            wb ^= 1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    gemm_epilogue<NB, MB, EPI>(p, acc, m0 + wm * 64, n0 + wn * (BN / 2), lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Ring kernel for the large shapes (BM = 256, persistent: one workgroup per CU walks the tile list).
 //   * Operands stream through a ring of NSLOT sub-stages of (256 + BN) rows x 32 K (64-byte rows; 16-byte chunk c of row
 //     r lives at slot c ^ ((r >> 2) & 3): conflict-free ds_read_b128), filled by global_load_lds NSLOT-1 sub-stages
@@ -1298,6 +1437,26 @@ extern "C" int orv_conv_gemm_bf16(const orv_gemm_t* g, const orv_conv_t* c, void
     a.R = (const bf16_t*)g->R; a.ldr = g->ldr; a.r_mod = g->r_mod; a.gate = nullptr;
     ConvArgs cv{(const bf16_t*)c->src, c->B, c->Ts, c->Hs, c->Ws, c->C, c->T, c->H, c->W, c->kt, c->kh, c->kw, c->stride, c->pad_lo,
                 c->ups_s, c->ups_t, c->t_shift};
+    hipStream_t st0 = (hipStream_t)stream;
+    static int use_strip = -1;       // ORV_CONV_STRIP=0: A/B switch
+    if (use_strip < 0) { const char* e = getenv("ORV_CONV_STRIP"); use_strip = (e && atoi(e) == 0) ? 0 : 1; }
+    if (use_strip && c->stride == 1 && !c->ups_s && !c->ups_t && c->Hs == c->H && c->Ws == c->W && c->kw == 3 && c->pad_lo == 1 &&
+        c->W >= 2 && g->N % 128 == 0 && g->r_mod == 0) {
+        const int bn = g->N % 256 == 0 ? 256 : 128;
+        a.tiles_n = g->N / bn;
+        a.tiles_m = (g->M + 255) / 256;
+        const int smem = 2 * 33 * 1024 + 2 * bn * 128;
+#define ORV_STRIP_LAUNCH(BN_, E)                                                                                       \
+    {                                                                                                                  \
+        static bool done = false;                                                                                      \
+        if (!done) { (void)hipFuncSetAttribute((const void*)conv_strip_kernel<BN_, E>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); done = true; } \
+        hipLaunchKernelGGL((conv_strip_kernel<BN_, E>), dim3(a.tiles_m * a.tiles_n), dim3(512), smem, st0, a, cv);     \
+    }
+        if (bn == 256) { if (g->epilogue == 2) ORV_STRIP_LAUNCH(256, 2) else ORV_STRIP_LAUNCH(256, 0) }
+        else { if (g->epilogue == 2) ORV_STRIP_LAUNCH(128, 2) else ORV_STRIP_LAUNCH(128, 0) }
+#undef ORV_STRIP_LAUNCH
+        return orv_check_launch("orv_conv_gemm_bf16");
+    }
     const int bn = g->N % 256 == 0 ? 256 : (g->N % 128 == 0 ? 128 : 64);     // wider tiles gather the A lines fewer times
     a.tiles_n = g->N / bn;
     a.tiles_m = (g->M + 255) / 256;

@@ -164,3 +164,38 @@ def test_pipeline_end_to_end_with_the_mi355x_vae(tmp_path):
     got = pipe(**args, generator=torch.Generator().manual_seed(3), output_type="pt").frames          # [B, F, C, H, W] in [0, 1]
     want01 = (want / 2 + 0.5).clamp(0, 1).permute(0, 2, 1, 3, 4)
     assert rel_l2(got, want01) <= 3e-2
+
+
+@pytest.mark.parametrize("B,T,H,W,Cin,Cout,kt,t_shift,residual", [
+    (2, 3, 5, 7, 64, 128, 3, 0, False),      # tiles cross image rows, frames and batch elements; replicate-first-frame padding
+    (1, 4, 9, 2, 128, 128, 3, 2, True),      # W = 2: every voxel is an x edge; conv_cache frames in front (t_shift); residual epilogue
+    (1, 2, 20, 33, 64, 256, 1, 0, False),    # per-frame 3x3 (kt = 1), 256-wide tile, M = 1320 (ragged last tile)
+    (3, 1, 16, 16, 192, 128, 3, 0, True),    # C = 3 channel blocks per tap, single frame
+])
+def test_conv_kernels_against_torch_conv3d(B, T, H, W, Cin, Cout, kt, t_shift, residual):
+    """orv_conv_gemm_bf16 (strip kernel for the stride-1 3x3 taps) against torch.nn.functional.conv3d in fp32 on the same
+    bf16-rounded operands: causal temporal context (copies of frame 0, or the t_shift leading frames), zero spatial padding,
+    weight column = ((dt * 3 + dy) * 3 + dx) * Cin + ci.  Tolerance: bf16 output rounding + fp32 accumulation order."""
+    from orv_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 1000 + W)
+    Ts = T + t_shift
+    x = torch.randn(B, Ts, H, W, Cin, generator=g).to(BF)                       # channels-last source, leading context frames first
+    w = (torch.randn(Cout, Cin, kt, 3, 3, generator=g) / (Cin * kt * 9) ** 0.5).to(BF)
+    bias = torch.randn(Cout, generator=g).to(BF)
+    res = torch.randn(B * T * H * W, Cout, generator=g).to(BF) if residual else None
+    # reference: frames [t_shift - (kt-1) + t .. t_shift + t] with negative indices clamped to frame 0
+    xf = x.float().permute(0, 4, 1, 2, 3)                                       # [B, C, Ts, H, W]
+    pad_t = (kt - 1) - t_shift
+    if pad_t > 0:
+        xf = torch.cat([xf[:, :, :1]] * pad_t + [xf], dim=2)
+    ref = torch.nn.functional.conv3d(xf, w.float(), bias.float(), padding=(0, 1, 1))   # [B, Cout, T, H, W]
+    ref = ref.permute(0, 2, 3, 4, 1).reshape(B * T * H * W, Cout)
+    if residual:
+        ref = ref + res.float()
+    wp = w.permute(0, 2, 3, 4, 1).reshape(Cout, kt * 9 * Cin).contiguous()      # column = tap * Cin + ci
+    out = torch.full((B * T * H * W, Cout), float("nan"), dtype=BF, device=dev)
+    ops.conv_gemm(x.to(dev), wp.to(dev), bias.to(dev), out, B, Ts, H, W, Cin, T, H, W, kt, 3, 3, 1, 1, 0, 0, t_shift, Cout,
+                  R=None if res is None else res.to(dev), ldr=Cout)
+    err = (out.float().cpu() - ref).abs()
+    assert bool((err <= 1.6e-2 * ref.abs() + 2e-2).all()), err.max().item()
