@@ -603,10 +603,13 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(const GemmArgs p, const 
 // is outside the image come from the zero page, t + dt < 0 replicates frame 0 (or reads the conv_cache frames), as in
 // conv_gemm_kernel.  K-tile order: (dt, dy) major, channel block, dx minor; the weight column is ((dt*kh + dy)*3 + dx)*C + c.
 // ---------------------------------------------------------------------------------------------------------------
-template <int BN, int EPI>
+// BM = 384 (N = 128 only: 96 accumulator registers) moves a third less W per FLOP than BM = 256.
+template <int BM, int BN, int EPI>
 __global__ __launch_bounds__(512) void conv_strip_kernel(const GemmArgs p, const ConvArgs cv) {
-    constexpr int BM = 256, MB = 2, NB = BN / 64;
-    constexpr int SP = 33;                         // DMA pieces (8 lines each) of one strip: 264 >= 258 lines
+    constexpr int MB = BM / 128, NB = BN / 64;
+    constexpr int SP = BM / 8 + 1;                 // DMA pieces (8 lines each) of one strip: BM + 8 >= BM + 2 lines
+    constexpr int SQ = BM / 64;                    // pieces every wave moves; wave 0 moves one more
+    static_assert(SQ % 2 == 0, "the strip pieces of a wave are split over the dx = 0 and dx = 1 K-tiles");
     constexpr int STRIP = SP * 1024, WT = BN * 128;
     constexpr int B_LD = BN / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];     // strip 0 | strip 1 | W 0 | W 1
@@ -617,12 +620,12 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(const GemmArgs p, const
     const int m0 = tm * BM, n0 = tn * BN;
     const int srow = lane >> 3, slot = lane & 7;
 
-    // strip pieces of this wave: q = wave + 8 j (j < 4), wave 0 also q = 32; lane -> strip line r = 8 q + srow = voxel m0 - 1 + r
-    constexpr int SJ = 5;
+    // strip pieces of this wave: q = wave + 8 j (j < SQ), wave 0 also q = 8 SQ; lane -> strip line r = 8 q + srow = voxel m0 - 1 + r
+    constexpr int SJ = SQ + 1;
     int vbs[SJ], vt[SJ], vy[SJ], vx[SJ], vchunk[SJ];   // first source frame of the batch element, t, y, x of the line's voxel
 #pragma unroll
     for (int j = 0; j < SJ; ++j) {
-        const int q = j < 4 ? wave + 8 * j : 32;
+        const int q = j < SQ ? wave + 8 * j : 8 * SQ;
         const int r = q * 8 + srow;
         vchunk[j] = (slot ^ ((r >> 1) & 7)) * 8;
         long m = min(max((long)m0 - 1 + r, 0L), (long)p.M - 1);
@@ -647,7 +650,7 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(const GemmArgs p, const
         const unsigned idx = (unsigned)((vbs[j] + ti) * cv.Hs + yi) * (unsigned)cv.Ws + (unsigned)vx[j];
         const bf16_t* g = cv.src + (long)idx * cv.C + (c0 + vchunk[j]);
         if (!ok) g = (const bf16_t*)orv_zero_page + (lane & 7) * 8;
-        const int q = j < 4 ? wave + 8 * j : 32;
+        const int q = j < SQ ? wave + 8 * j : 8 * SQ;
         glds16(g, smem + sb * STRIP + q * 1024);
     };
     auto issue_w = [&](int j, int wb, int grp, int dx) {
@@ -664,7 +667,7 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(const GemmArgs p, const
     bool edge_lo[MB], edge_hi[MB];
 #pragma unroll
     for (int j = 0; j < MB; ++j) {
-        arow[j] = wm * 64 + j * 32 + l31;
+        arow[j] = wm * (BM / 4) + j * 32 + l31;
         const int x = (int)(((long)m0 + arow[j]) % cv.W);
         edge_lo[j] = x == 0;
         edge_hi[j] = x == cv.W - 1;
@@ -680,7 +683,7 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(const GemmArgs p, const
     // prologue: strip of group 0 and W of K-tile 0
 #pragma unroll
     for (int j = 0; j < SJ; ++j)
-        if (j < 4 || wave == 0) issue_strip(j, 0, 0);
+        if (j < SQ || wave == 0) issue_strip(j, 0, 0);
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) issue_w(j, 0, 0, 0);
 
@@ -712,8 +715,10 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(const GemmArgs p, const
 #pragma unroll
             for (int j = 0; j < B_LD; ++j) issue_w(j, wb ^ 1, ng, ndx);
             if (more) {
-                if (dx < 2) { issue_strip(2 * dx, sb ^ 1, grp + 1); issue_strip(2 * dx + 1, sb ^ 1, grp + 1); }
-                else if (wave == 0) issue_strip(4, sb ^ 1, grp + 1);
+                if (dx < 2) {
+#pragma unroll
+                    for (int j = 0; j < SQ / 2; ++j) issue_strip(dx * (SQ / 2) + j, sb ^ 1, grp + 1);
+                } else if (wave == 0) issue_strip(SQ, sb ^ 1, grp + 1);
             }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -729,7 +734,7 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(const GemmArgs p, const
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    gemm_epilogue<NB, MB, EPI>(p, acc, m0 + wm * 64, n0 + wn * (BN / 2), lane);
+    gemm_epilogue<NB, MB, EPI>(p, acc, m0 + wm * (BM / 4), n0 + wn * (BN / 2), lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1443,17 +1448,21 @@ extern "C" int orv_conv_gemm_bf16(const orv_gemm_t* g, const orv_conv_t* c, void
     if (use_strip && c->stride == 1 && !c->ups_s && !c->ups_t && c->Hs == c->H && c->Ws == c->W && c->kw == 3 && c->pad_lo == 1 &&
         c->W >= 2 && g->N % 128 == 0 && g->r_mod == 0) {
         const int bn = g->N % 256 == 0 ? 256 : 128;
+        static int bm384 = -1;       // ORV_CONV_BM384=0: A/B switch for the 384-row tile of the 128-wide convolutions
+        if (bm384 < 0) { const char* e = getenv("ORV_CONV_BM384"); bm384 = (e && atoi(e) == 0) ? 0 : 1; }
+        const int bm = (bn == 128 && bm384 && g->M >= 384 * 256) ? 384 : 256;
         a.tiles_n = g->N / bn;
-        a.tiles_m = (g->M + 255) / 256;
-        const int smem = 2 * 33 * 1024 + 2 * bn * 128;
-#define ORV_STRIP_LAUNCH(BN_, E)                                                                                       \
+        a.tiles_m = (g->M + bm - 1) / bm;
+        const int smem = 2 * (bm / 8 + 1) * 1024 + 2 * bn * 128;
+#define ORV_STRIP_LAUNCH(BM_, BN_, E)                                                                                  \
     {                                                                                                                  \
         static bool done = false;                                                                                      \
-        if (!done) { (void)hipFuncSetAttribute((const void*)conv_strip_kernel<BN_, E>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); done = true; } \
-        hipLaunchKernelGGL((conv_strip_kernel<BN_, E>), dim3(a.tiles_m * a.tiles_n), dim3(512), smem, st0, a, cv);     \
+        if (!done) { (void)hipFuncSetAttribute((const void*)conv_strip_kernel<BM_, BN_, E>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); done = true; } \
+        hipLaunchKernelGGL((conv_strip_kernel<BM_, BN_, E>), dim3(a.tiles_m * a.tiles_n), dim3(512), smem, st0, a, cv); \
     }
-        if (bn == 256) { if (g->epilogue == 2) ORV_STRIP_LAUNCH(256, 2) else ORV_STRIP_LAUNCH(256, 0) }
-        else { if (g->epilogue == 2) ORV_STRIP_LAUNCH(128, 2) else ORV_STRIP_LAUNCH(128, 0) }
+        if (bn == 256) { if (g->epilogue == 2) ORV_STRIP_LAUNCH(256, 256, 2) else ORV_STRIP_LAUNCH(256, 256, 0) }
+        else if (bm == 384) { if (g->epilogue == 2) ORV_STRIP_LAUNCH(384, 128, 2) else ORV_STRIP_LAUNCH(384, 128, 0) }
+        else { if (g->epilogue == 2) ORV_STRIP_LAUNCH(256, 128, 2) else ORV_STRIP_LAUNCH(256, 128, 0) }
 #undef ORV_STRIP_LAUNCH
         return orv_check_launch("orv_conv_gemm_bf16");
     }
