@@ -1447,10 +1447,17 @@ extern "C" int orv_conv_gemm_bf16(const orv_gemm_t* g, const orv_conv_t* c, void
     if (use_strip < 0) { const char* e = getenv("ORV_CONV_STRIP"); use_strip = (e && atoi(e) == 0) ? 0 : 1; }
     if (use_strip && c->stride == 1 && !c->ups_s && !c->ups_t && c->Hs == c->H && c->Ws == c->W && c->kw == 3 && c->pad_lo == 1 &&
         c->W >= 2 && g->N % 128 == 0 && g->r_mod == 0) {
-        const int bn = g->N % 256 == 0 ? 256 : 128;
         static int bm384 = -1;       // ORV_CONV_BM384=0: A/B switch for the 384-row tile of the 128-wide convolutions
         if (bm384 < 0) { const char* e = getenv("ORV_CONV_BM384"); bm384 = (e && atoi(e) == 0) ? 0 : 1; }
-        const int bm = (bn == 128 && bm384 && g->M >= 384 * 256) ? 384 : 256;
+        static int small = -1;       // ORV_CONV_SMALL=0: A/B switch for the small-grid tiles
+        if (small < 0) { const char* e = getenv("ORV_CONV_SMALL"); small = (e && atoi(e) == 0) ? 0 : 1; }
+        // tile: 256 x 256 where it fills the chip; the low-resolution stages of the decoder (7200 voxels x 512 channels: 58 tiles
+        // of 256 x 256 on 256 CUs) take 256 x 128, then 128 x 128 tiles while the grid covers less than half of the CUs
+        const int ncu = orv_num_cus();
+        int bm = 256, bn = g->N % 256 == 0 ? 256 : 128;
+        if (small && bn == 256 && (long)((g->M + 255) / 256) * (g->N / 256) < ncu / 2) bn = 128;      // (at 150-190 of 256 tiles
+        if (small && bn == 128 && (long)((g->M + 255) / 256) * (g->N / 128) < ncu / 2) bm = 128;      //  the big tile still wins)
+        if (bm == 256 && bn == 128 && bm384 && g->M >= 384 * 256) bm = 384;
         a.tiles_n = g->N / bn;
         a.tiles_m = (g->M + bm - 1) / bm;
         const int smem = 2 * (bm / 8 + 1) * 1024 + 2 * bn * 128;
@@ -1462,6 +1469,7 @@ extern "C" int orv_conv_gemm_bf16(const orv_gemm_t* g, const orv_conv_t* c, void
     }
         if (bn == 256) { if (g->epilogue == 2) ORV_STRIP_LAUNCH(256, 256, 2) else ORV_STRIP_LAUNCH(256, 256, 0) }
         else if (bm == 384) { if (g->epilogue == 2) ORV_STRIP_LAUNCH(384, 128, 2) else ORV_STRIP_LAUNCH(384, 128, 0) }
+        else if (bm == 128) { if (g->epilogue == 2) ORV_STRIP_LAUNCH(128, 128, 2) else ORV_STRIP_LAUNCH(128, 128, 0) }
         else { if (g->epilogue == 2) ORV_STRIP_LAUNCH(256, 128, 2) else ORV_STRIP_LAUNCH(256, 128, 0) }
 #undef ORV_STRIP_LAUNCH
         return orv_check_launch("orv_conv_gemm_bf16");

@@ -172,6 +172,8 @@ def test_pipeline_end_to_end_with_the_mi355x_vae(tmp_path):
     (1, 2, 20, 33, 64, 256, 1, 0, False),    # per-frame 3x3 (kt = 1), 256-wide tile, M = 1320 (ragged last tile)
     (3, 1, 16, 16, 192, 128, 3, 0, True),    # C = 3 channel blocks per tap, single frame
     (1, 1, 320, 322, 64, 128, 3, 0, True),   # M = 103040 >= 384 x 256: the 384-row strip tile of the 128-wide convolutions
+    (1, 2, 128, 130, 64, 256, 3, 1, False),  # M = 33280: 130 tiles of 256 x 256 (small shapes above run the 128 x 128 tile)
+    (1, 2, 128, 130, 64, 128, 3, 0, True),   # 256 x 128 tile
 ])
 def test_conv_kernels_against_torch_conv3d(B, T, H, W, Cin, Cout, kt, t_shift, residual):
     """orv_conv_gemm_bf16 (strip kernel for the stride-1 3x3 taps) against torch.nn.functional.conv3d in fp32 on the same
