@@ -12,26 +12,43 @@ def bump_weights_epoch() -> None:
 # Gradient destinations registered by the fused optimizer (id(parameter) -> its segment of the flat bf16 gradient buffer, viewed in
 # the parameter's shape): the hand-written backward writes a weight gradient straight into its segment instead of into a
 # temporary the optimizer copies later (3.4 GB less traffic and memory per 2B step).
+import os
 import weakref
 
-import os
-
+# id(parameter) -> (weakref(parameter), weakref(owning optimizer), segment index).  Only weak references: a deleted optimizer
+# (resume, re-creation, tests) releases its flat buffers, and its entries die with it.
 _grad_views = {}
 _INPLACE_GRADS = os.environ.get("ORV_INPLACE_GRADS", "1") != "0"      # A/B switch
 
 
-def register_grad_views(params, views) -> None:
-    for p, v in zip(params, views):
-        _grad_views[id(p)] = (weakref.ref(p), v)
+def register_grad_views(params, owner) -> None:
+    """``owner`` (the fused optimizer) exposes ``_grad_segment(i)`` (the i-th view of its flat gradient buffer) and a set
+    ``_handed`` of segment indices handed out for in-place writing since its last ``step()`` / ``zero_grad()``."""
+    for k in [k for k, (pr, orf, _) in _grad_views.items() if pr() is None or orf() is None]:
+        del _grad_views[k]                               # dead parameters / optimizers
+    oref = weakref.ref(owner)
+    for i, p in enumerate(params):
+        _grad_views[id(p)] = (weakref.ref(p), oref, i)
 
 
 def grad_view(param):
     """A FRESH view object on the parameter's gradient segment (autograd keeps an incoming gradient without copying only if
-    nobody else holds the tensor object), or None when no optimizer registered one or the parameter already holds a gradient
-    (gradient accumulation: the segment IS the accumulated gradient then and must not be overwritten)."""
+    nobody else holds the tensor object), or None - the caller then allocates a temporary and autograd accumulates - when
+      * no live optimizer registered one,
+      * the parameter already holds a gradient (gradient accumulation: the segment IS the accumulated gradient), or
+      * the segment was already handed out since the optimizer's last ``step()`` / ``zero_grad()``: a second backward node in
+        the same graph (the model called twice, or ``torch.autograd.grad`` followed by ``backward``) would overwrite the first
+        node's gradient and autograd would then sum two aliases of one tensor (2 g_B instead of g_A + g_B)."""
     if not _INPLACE_GRADS:
         return None
     hit = _grad_views.get(id(param))
     if hit is None or hit[0]() is not param or param.grad is not None:
         return None
-    return hit[1].view(param.shape)
+    owner = hit[1]()
+    if owner is None:
+        del _grad_views[id(param)]
+        return None
+    if hit[2] in owner._handed:
+        return None
+    owner._handed.add(hit[2])
+    return owner._grad_segment(hit[2]).view(param.shape)

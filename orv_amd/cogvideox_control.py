@@ -817,7 +817,13 @@ class GraphedTransformer:
         return out
 
     def _weights_version(self):
-        return sum(p._version for p in self.tr.parameters())
+        """In-place edits bump ``_version``; storage moves (``p.data = ...``: FusedAdamW's flat layout, ``.to()``) change
+        ``data_ptr``.  The parameter list is collected once (the module walk is the expensive part of this key on the B = 1
+        path the graph exists to speed up)."""
+        ps = getattr(self, "_plist", None)
+        if ps is None:
+            ps = self._plist = list(self.tr.parameters())
+        return sum(p._version for p in ps), sum(p.data_ptr() for p in ps[::8]) & 0xFFFFFFFFFFFF
 
     def __call__(self, hidden_states, encoder_hidden_states, timestep, **kw):
         kw = dict(kw, hidden_states=hidden_states, encoder_hidden_states=encoder_hidden_states, timestep=timestep)

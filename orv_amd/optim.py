@@ -8,9 +8,9 @@ is then: gather the autograd gradients into the flat buffer (multi-tensor copy) 
 buffer in 256 MB pieces -> ONE ``orv_sumsq`` -> clip coefficient on the device (no host sync before the update) -> ONE
 ``orv_adamw_flat`` (clip + moments + decoupled decay + bf16 write, 16-byte accesses).  Parameters that received no gradient
 in a step are skipped exactly as ``torch.optim.AdamW`` skips them (segment activity mask) and every parameter carries its
-OWN step count for the bias correction (``state[p]["step"]`` in torch).  Under data parallel every trainable parameter is
-active on every rank (a rank without a gradient contributes zeros: DDP's ``find_unused_parameters`` behaviour, which the
-reference enables, base_train.yaml:181), so the collective schedule and the update are identical on all ranks.  Moments
+OWN step count for the bias correction (``state[p]["step"]`` in torch).  Under data parallel a parameter is active iff it has a gradient on ANY rank (one tiny MAX all-reduce of the usage mask: DDP's
+``find_unused_parameters`` bookkeeping, which the reference enables, base_train.yaml:181); a rank without one contributes zeros,
+so the collective schedule and the update are identical on all ranks and equal to the single-GPU trajectory.  Moments
 are fp32 (the reference keeps them in the parameter dtype)."""
 from __future__ import annotations
 
@@ -33,6 +33,11 @@ class FusedAdamW:
         self.step_count = 0
         self.param_groups = [{"lr": lr, "params": self.params}]      # lr schedulers poke param_groups[0]["lr"]
         self._flat = None
+        self._handed = set()      # segments handed to the backward for in-place writing since the last step() / zero_grad()
+        self._dirty = set()       # segments that hold data (written in place or copied into) and were not zeroed since
+
+    def _grad_segment(self, i: int) -> torch.Tensor:
+        return self._flat["views_g"][i]
 
     # ---- flat storage ----
     def _build(self):
@@ -54,13 +59,14 @@ class FusedAdamW:
             p.data = v                                   # the module keeps its Parameter objects; only their storage moves
             views_p.append(v)
             views_g.append(flat_g[off:off + p.numel()].view(p.shape))
-        _state.register_grad_views(self.params, views_g)
         self._flat = dict(
             p=flat_p, g=flat_g, m=torch.zeros(total, dtype=torch.float32, device=dev),
             v=torch.zeros(total, dtype=torch.float32, device=dev), views_g=views_g,
             seg_start=torch.tensor(offs + [total], dtype=torch.int64, device=dev),
             active=torch.zeros(len(self.params), dtype=torch.uint8, device=dev), active_host=[False] * len(self.params),
             seg_step=torch.zeros(len(self.params), dtype=torch.int32, device=dev))
+        _state.register_grad_views(self.params, self)
+        _state.bump_weights_epoch()      # parameter storage moved (p.data = view): captured graphs / derived-weight caches are stale
 
     # ---- data parallel: exchange overlapped with the backward ----
     def begin_overlapped_allreduce(self):
@@ -102,6 +108,10 @@ class FusedAdamW:
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
             p.grad = None
+        # a segment written in place whose gradient is dropped here (skipped / overflow step) keeps its data: remember it so
+        # the next step() zeroes it unless a new gradient overwrites it
+        self._dirty |= self._handed
+        self._handed.clear()
 
     @torch.no_grad()
     def step(self, average_over: Optional[int] = None) -> float:
@@ -117,33 +127,46 @@ class FusedAdamW:
         self._overlap = None
         distributed = overlap is not None or bool(average_over and average_over > 1)
         has_grad = [p.grad is not None for p in self.params]
-        # data parallel: every trainable parameter takes part on every rank (zeros where this rank has no gradient)
-        live = [True] * len(self.params) if distributed else has_grad
-        if not any(live):
+        dev = f["p"].device
+        if not distributed and not any(has_grad):
             return 0.0
         done = overlap[1] if overlap else ()
-        if distributed:
-            missing = [v for i, (v, h) in enumerate(zip(f["views_g"], has_grad)) if not h and i not in done]
-            if missing:
-                torch._foreach_zero_(missing)
-        live_src = has_grad
-        pairs = [(p.grad, v) for i, (p, v, a) in enumerate(zip(self.params, f["views_g"], live_src))
+        self._dirty |= self._handed          # segments the backward wrote in place since the last step
+        self._handed.clear()
+        self._dirty.update(done)
+        # A segment without a gradient this step must read as zeros for the global norm (and, under data parallel, for the
+        # exchange): zero every one that holds data - a parameter that lost its gradient (zero_grad on a skipped step,
+        # torch.autograd.grad, a branch not taken this step) - not only the active -> inactive transitions.
+        stale = [i for i in self._dirty if not has_grad[i] and i not in done]
+        if stale:
+            torch._foreach_zero_([f["views_g"][i] for i in stale])
+            self._dirty.difference_update(stale)
+        pairs = [(p.grad, v) for i, (p, v, a) in enumerate(zip(self.params, f["views_g"], has_grad))
                  if a and i not in done and p.grad.data_ptr() != v.data_ptr()]     # in-place gradients need no copy
         srcs, dsts = [s_ for s_, _ in pairs], [d_ for _, d_ in pairs]
         if srcs:
             torch._foreach_copy_(dsts, srcs)
-        if live != f["active_host"]:
-            for v, was, now in zip(f["views_g"], f["active_host"], live):
-                if was and not now:
-                    v.zero_()                            # stale gradient of a parameter that got none this step
-            f["active"].copy_(torch.tensor(live, dtype=torch.uint8))
-            f["active_host"] = live
+        self._dirty.update(i for i, h in enumerate(has_grad) if h)
+        if distributed:
+            # Data parallel: a parameter is updated iff it has a gradient on ANY rank (DDP's local_used_map with
+            # find_unused_parameters, /root/reference/config/base_train.yaml:181): a rank without one contributes zeros, and
+            # a parameter unused on every rank is skipped as torch.optim.AdamW skips grad-None parameters (no decay, no
+            # moment decay, no step-count increment) - the same trajectory as the single-GPU run.  The mask travels as one
+            # tiny MAX all-reduce issued at the same point on every rank; it stays on the device.
+            import torch.distributed as dist
+            used = torch.tensor(has_grad, dtype=torch.uint8, device=dev)
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dist.all_reduce(used, op=dist.ReduceOp.MAX)
+            f["active"].copy_(used)
+            f["active_host"] = None                      # device-side mask: the host copy is unknown
+        elif has_grad != f["active_host"]:
+            f["active"].copy_(torch.tensor(has_grad, dtype=torch.uint8))
+            f["active_host"] = has_grad
         if overlap is not None:
             overlap[0].finish()                          # the rest of the buffer, wait, average
         elif average_over and average_over > 1:
             from .sharding import allreduce_flat_
             allreduce_flat_(f["g"], _AR_CHUNK)
-        dev = f["p"].device
         ss = torch.zeros(1, dtype=torch.float32, device=dev)
         ops.sumsq(f["g"], ss)
         norm = ss.sqrt()
