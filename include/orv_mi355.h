@@ -162,6 +162,10 @@ int orv_gemm_bf16(const orv_gemm_t* g, void* stream);
 /* Kernel symbol (as rocprofv3 prints it, e.g. "gemm_pp_kernel<192, 5, 1>") that orv_gemm_bf16 launches for this shape on this
  * device: the tile is chosen by a cost model over all candidates, so callers that label timings ask. */
 int orv_gemm_kernel_name(int M, int N, int K, int epilogue, char* buf, int len);
+/* Developer switch (sweeps, same-process A/B, per-instantiation tests): pin the tile candidate (kernel family `ring`: 0 simple,
+ * 1 ring, 2 phased, 3 t8; tile bm x bn) for all later orv_gemm_bf16 calls of this process; bm = 0 returns to the cost model.
+ * Same effect as the environment variable ORV_GEMM_TILE="ring,bm,bn" read at the first call. */
+int orv_gemm_force_tile(int ring, int bm, int bn);
 
 /* -- backward (training) ------------------------------------------------------------------------------ */
 /* dst[c, r] = src[r, c] ([R, C] bf16 -> [C, ld_dst], columns [R, ld_dst) zero-filled).  Feeds the NT GEMM with the
@@ -291,6 +295,12 @@ int orv_vae_groupnorm_stats(const void* x, float* sums, float* scratch, int B, l
 int orv_vae_norm_apply(const void* x, void* out, const float* sums, const void* gamma, const void* beta, const void* zy,
                        const void* zb, int B, int T, int H, int W, int C, int G, int Tz, int hz, int wz, float eps, int silu_act,
                        int out_lead, void* stream);
+/* Seam blend of the tiled decode / encode (diffusers AutoencoderKLCogVideoX.blend_v / blend_h, enabled by the reference at
+ * /root/reference/orv/pipeline/inference_control_to_video.py:98-99): channels-last tiles a [outer, Ha, Wa, C], b [outer, Hb, Wb, C]
+ * bf16; in place on b: vertical (horizontal = 0): b[.., y, :] = a[.., Ha - extent + y, :] (1 - y / extent) + b[.., y, :] y / extent
+ * for y < extent (Wa == Wb); horizontal: the same along x with a = the tile to the left (Ha == Hb). */
+int orv_vae_blend(const void* a, void* b, int outer, int Ha, int Wa, int Hb, int Wb, int C, int extent, int horizontal,
+                  void* stream);
 
 #ifdef __cplusplus
 }

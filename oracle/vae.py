@@ -24,6 +24,19 @@ diffusers algorithm restated from its structure (module names == diffusers attri
 * Decoder: conv_in -> mid (2 resnets) -> 4 up blocks (4 resnets each, upsample on all but the last; time doubled in the
   first two) -> norm_out -> SiLU -> conv_out.  Encoder mirrors it with plain GroupNorm resnets and no latent conditioning.
 
+* Tiling (``enable_tiling()``, which both reference entry points call: /root/reference/orv/pipeline/
+  inference_control_to_video.py:98-99, evaluation_control_to_video.py:274-275) is ARITHMETIC, not a memory knob - restated
+  here FROM MEMORY of diffusers >= 0.32, unpinned like the rest: tile size in sample space = (sample_height / 2, sample_width / 2)
+  of the VAE config (480 x 720 -> 240 x 360), in latent space that / 2^(len(block_out_channels) - 1) (30 x 45); overlap factors
+  1/6 (height) and 1/5 (width).  ``decode`` of a latent larger than one latent tile in either direction runs the frame-batched
+  decoder on every tile z[.., i : i + 30, j : j + 45] with i, j stepping by int(30 * 5/6) = 25, int(45 * 4/5) = 36 - every tile
+  with its OWN GroupNorm statistics and conv caches - then blends each tile, in raster order and IN PLACE, with the
+  (already blended) tile above (``blend_v``, extent int(240 / 6) = 40 rows) and to the left (``blend_h``, int(360 / 5) = 72
+  columns): b[y] = a[-extent + y] (1 - y / extent) + b[y] (y / extent); crops it to (240 - 40) x (360 - 72) and concatenates.
+  ``encode`` mirrors it with sample tiles 240 x 360 stepping 200 / 288, latent blend extents 5 / 9 and crop 25 x 36.  A 40 x 60
+  latent (320 x 480 video) is 4 tiles - 30x45, 30x24, 15x45, 15x24 - i.e. 1.29 x the voxels of the untiled decode.
+  ``enable_slicing()`` (one batch element at a time) changes nothing: every statistic is per batch element already.
+
 THUDM/CogVideoX-2b VAE config: block_out_channels (128, 256, 256, 512), layers_per_block 3, latent_channels 16,
 norm_num_groups 32, temporal_compression_ratio 4, scaling_factor 1.15258426, no quant / post-quant conv.
 """
@@ -260,8 +273,13 @@ class AutoencoderKLCogVideoX(nn.Module):
 
     def __init__(self, in_channels=3, out_channels=3, block_out_channels=(128, 256, 256, 512), latent_channels=16,
                  layers_per_block=3, norm_eps=1e-6, norm_num_groups=32, temporal_compression_ratio=4,
-                 scaling_factor=1.15258426, invert_scale_latents=False):
+                 scaling_factor=1.15258426, invert_scale_latents=False, sample_height=480, sample_width=720):
         super().__init__()
+        self.use_tiling = self.use_slicing = False
+        self.tile_sample_min_height, self.tile_sample_min_width = sample_height // 2, sample_width // 2
+        self.tile_latent_min_height = int(self.tile_sample_min_height / (2 ** (len(block_out_channels) - 1)))
+        self.tile_latent_min_width = int(self.tile_sample_min_width / (2 ** (len(block_out_channels) - 1)))
+        self.tile_overlap_factor_height, self.tile_overlap_factor_width = 1 / 6, 1 / 5
         self.encoder = CogVideoXEncoder3D(in_channels, latent_channels, block_out_channels, layers_per_block, norm_eps,
                                           norm_num_groups, temporal_compression_ratio)
         self.decoder = CogVideoXDecoder3D(latent_channels, out_channels, block_out_channels, layers_per_block, norm_eps,
@@ -269,7 +287,8 @@ class AutoencoderKLCogVideoX(nn.Module):
         self.config = dict(in_channels=in_channels, out_channels=out_channels, block_out_channels=tuple(block_out_channels),
                            latent_channels=latent_channels, layers_per_block=layers_per_block, norm_eps=norm_eps,
                            norm_num_groups=norm_num_groups, temporal_compression_ratio=temporal_compression_ratio,
-                           scaling_factor=scaling_factor, invert_scale_latents=invert_scale_latents)
+                           scaling_factor=scaling_factor, invert_scale_latents=invert_scale_latents, sample_height=sample_height,
+                           sample_width=sample_width)
 
     num_latent_frames_batch_size = 2
     num_sample_frames_batch_size = 8
@@ -288,8 +307,80 @@ class AutoencoderKLCogVideoX(nn.Module):
             prev = cc.new
         return torch.cat(outs, dim=2)
 
+    # ---- tiling (from memory of diffusers >= 0.32; see the module header) ----
+    def enable_tiling(self, tile_sample_min_height=None, tile_sample_min_width=None, tile_overlap_factor_height=None,
+                      tile_overlap_factor_width=None):
+        self.use_tiling = True
+        self.tile_sample_min_height = tile_sample_min_height or self.tile_sample_min_height
+        self.tile_sample_min_width = tile_sample_min_width or self.tile_sample_min_width
+        down = 2 ** (len(self.config["block_out_channels"]) - 1)
+        self.tile_latent_min_height = int(self.tile_sample_min_height / down)
+        self.tile_latent_min_width = int(self.tile_sample_min_width / down)
+        self.tile_overlap_factor_height = tile_overlap_factor_height or self.tile_overlap_factor_height
+        self.tile_overlap_factor_width = tile_overlap_factor_width or self.tile_overlap_factor_width
+
+    def disable_tiling(self):
+        self.use_tiling = False
+
+    def enable_slicing(self):
+        self.use_slicing = True
+
+    def disable_slicing(self):
+        self.use_slicing = False
+
+    @staticmethod
+    def blend_v(a, b, blend_extent):
+        blend_extent = min(a.shape[3], b.shape[3], blend_extent)
+        for y in range(blend_extent):
+            b[:, :, :, y, :] = a[:, :, :, -blend_extent + y, :] * (1 - y / blend_extent) + b[:, :, :, y, :] * (y / blend_extent)
+        return b
+
+    @staticmethod
+    def blend_h(a, b, blend_extent):
+        blend_extent = min(a.shape[4], b.shape[4], blend_extent)
+        for x in range(blend_extent):
+            b[:, :, :, :, x] = a[:, :, :, :, -blend_extent + x] * (1 - x / blend_extent) + b[:, :, :, :, x] * (x / blend_extent)
+        return b
+
+    def _tiled(self, net, x, frame_batch, tile_h, tile_w, blend_h_ext, blend_w_ext, limit_h, limit_w):
+        """Shared body of tiled_encode / tiled_decode: ``net`` on overlapping tiles (own frame batching, own conv caches), then
+        the raster-order in-place seam blend, crop and concatenation."""
+        height, width = x.shape[3], x.shape[4]
+        step_h = int(tile_h * (1 - self.tile_overlap_factor_height))
+        step_w = int(tile_w * (1 - self.tile_overlap_factor_width))
+        rows = []
+        for i in range(0, height, step_h):
+            rows.append([self._batched(net, x[:, :, :, i:i + tile_h, j:j + tile_w], frame_batch) for j in range(0, width, step_w)])
+        result_rows = []
+        for i, row in enumerate(rows):
+            result_row = []
+            for j, tile in enumerate(row):
+                if i > 0:
+                    tile = self.blend_v(rows[i - 1][j], tile, blend_h_ext)
+                if j > 0:
+                    tile = self.blend_h(row[j - 1], tile, blend_w_ext)
+                result_row.append(tile[:, :, :, :limit_h, :limit_w])
+            result_rows.append(torch.cat(result_row, dim=4))
+        return torch.cat(result_rows, dim=3)
+
+    def tiled_encode(self, x):
+        bh = int(self.tile_latent_min_height * self.tile_overlap_factor_height)
+        bw = int(self.tile_latent_min_width * self.tile_overlap_factor_width)
+        return self._tiled(self.encoder, x, self.num_sample_frames_batch_size, self.tile_sample_min_height, self.tile_sample_min_width,
+                           bh, bw, self.tile_latent_min_height - bh, self.tile_latent_min_width - bw)
+
+    def tiled_decode(self, z):
+        bh = int(self.tile_sample_min_height * self.tile_overlap_factor_height)
+        bw = int(self.tile_sample_min_width * self.tile_overlap_factor_width)
+        return self._tiled(self.decoder, z, self.num_latent_frames_batch_size, self.tile_latent_min_height, self.tile_latent_min_width,
+                           bh, bw, self.tile_sample_min_height - bh, self.tile_sample_min_width - bw)
+
     def encode(self, x):
+        if self.use_tiling and (x.shape[-1] > self.tile_sample_min_width or x.shape[-2] > self.tile_sample_min_height):
+            return DiagonalGaussianDistribution(self.tiled_encode(x))
         return DiagonalGaussianDistribution(self._batched(self.encoder, x, self.num_sample_frames_batch_size))
 
     def decode(self, z):
+        if self.use_tiling and (z.shape[-1] > self.tile_latent_min_width or z.shape[-2] > self.tile_latent_min_height):
+            return self.tiled_decode(z)
         return self._batched(self.decoder, z, self.num_latent_frames_batch_size)

@@ -59,6 +59,7 @@ SIGNATURES = {
     "orv_qkv_prep_from": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
     "orv_gemm_kernel_name": (c_int, [c_int, c_int, c_int, c_int, ctypes.c_char_p, c_int]),
+    "orv_gemm_force_tile": (c_int, [c_int, c_int, c_int]),
     "orv_gemm_bf16": (c_int, [POINTER(Gemm), c_void_p]),
     "orv_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                   c_float, c_void_p]),
@@ -95,6 +96,7 @@ SIGNATURES = {
     "orv_vae_groupnorm_scratch": (c_long, [c_int, c_long, c_int, c_int]),
     "orv_vae_groupnorm_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_void_p]),
     "orv_vae_norm_apply": (c_int, [c_void_p] * 7 + [c_int] * 9 + [c_float, c_int, c_int, c_void_p]),
+    "orv_vae_blend": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
 }
 
 _lib = None

@@ -14,42 +14,14 @@
 //     lane&31 = output row m, register quad = 4 consecutive output columns n  -> 8-byte epilogue stores.
 //   * workgroup -> tile map is XCD-aware (block b runs on XCD b % 8): each XCD gets a contiguous chunk of the
 //     tile list, ordered in GM x 8 super-tiles so the 32 CUs of an XCD share A row-panels and W column-panels in L2.
-#include "common.hpp"
+#include "gemm_common.hpp"
 #include <type_traits>
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
-int orv_num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
-
-struct GemmArgs {
-    const bf16_t* A; long lda;
-    const bf16_t* W; long ldw;
-    const bf16_t* bias;
-    bf16_t* C; long ldc;
-    int M, N, K;
-    const bf16_t* R; long ldr; int r_mod;
-    const float* gate; long gate_b, gate_g;
-    int seq, n_text, per_group;
-    int c_rows, c_bstride, c_off;
-    bf16_t* Y; long ldy;   // optional second output: the pre-epilogue value acc + bias (saved for backward)
-    // epilogue 4 (fused qk LayerNorm of the QKV projection): norm_q / norm_k affine [64], eps, q pre-multiplier, heads
-    const bf16_t *qn_gq, *qn_bq, *qn_gk, *qn_bk; float qn_eps, qn_premul; int qn_heads;
-    int tiles_m, tiles_n;
-    int dbg;  // ORV_GEMM_DBG: 1 = skip main-loop loads, 2 = skip MFMAs (ablation only)
-};
-
-constexpr int BK = 64;
-constexpr int GM = 4;  // super-tile height in tiles
+using namespace orv_gemm;
 
 // Epilogue shared by both kernels.  acc[i][j][4q+e] = C[m][n] with m = mbase + j*32 + (lane&31),
 // n = nbase + i*32 + 8q + 4*(lane>>5) + e  (C^T accumulator layout: 4 consecutive columns per register quad).
@@ -306,20 +278,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[N
         }
     }
 }
-
-// XCD-aware tile mapping (bijective for any grid size): block b runs on XCD b % 8; each XCD gets a contiguous chunk of the
-// tile list, ordered in GM x (tiles_n) groups walked m-fastest so concurrent CUs of an XCD share A and W panels in L2.
-__device__ __forceinline__ void tile_of_index(const GemmArgs& p, int b, int nb, int& tm, int& tn) {
-    const int q = nb >> 3, r = nb & 7, xcd = b & 7, j = b >> 3;
-    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    const int per = GM * p.tiles_n;
-    const int gid = L / per, rem = L % per;
-    const int first_m = gid * GM;
-    const int gsize = min(p.tiles_m - first_m, GM);
-    tm = first_m + rem % gsize;
-    tn = rem / gsize;
-}
-__device__ __forceinline__ void tile_of_block(const GemmArgs& p, int& tm, int& tn) { tile_of_index(p, blockIdx.x, gridDim.x, tm, tn); }
 
 // WM = waves along M (4 or 2), 8 / WM along N.  WM = 2 exists for the 192-row tile: 3226 rows (one clip) are 16.8 tiles of
 // 192, so every N = 1920 GEMM of a B = 1 step is 255 tiles - one full round of the 256 CUs.
@@ -1303,6 +1261,14 @@ int launch(const GemmArgs& a, int epi, hipStream_t st) {
 }  // namespace
 
 struct GemmCand { int ring, bm, bn; float rate; int min_rounds; };
+// ORV_GEMM_TILE="ring,bm,bn" / orv_gemm_force_tile() pin one candidate (sweeps, same-process A/B, the per-instantiation tests)
+static int g_force_ring = -1, g_force_bm = 0, g_force_bn = 0;
+extern "C" int orv_gemm_force_tile(int ring, int bm, int bn) {
+    if (g_force_ring < 0) g_force_ring = 2;
+    if (bm > 0) { g_force_ring = ring; g_force_bm = bm; g_force_bn = bn; }
+    else { g_force_ring = 2; g_force_bm = 0; g_force_bn = 0; }
+    return ORV_OK;
+}
 
 // Tile / kernel choice: every candidate whose BN divides N is priced as
 //     rounds(tiles over the CUs) x BM x BN / relative_rate(candidate)
@@ -1311,6 +1277,8 @@ struct GemmCand { int ring, bm, bn; float rate; int min_rounds; };
 // fills the chip (B = 1: N = 1920 GEMMs take 195 tiles of 256x128 instead of 260 of 128x192).
 static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int heads = 0) {
     static const GemmCand cands[] = {
+        // ring = 3: the 16x16x32 8-phase kernel of gemm_t8.hip (persistent, BK = 64; needs an even number of K-tiles)
+        {3, 256, 256, 1.29f, 0}, {3, 256, 192, 1.21f, 0},
         // ring = 2: the phased (8-phase, BK = 64) persistent kernel; needs an even number of K-tiles
         // (256x384 does not fit: 192 accumulator + 64 fragment registers of the 256 a wave gets at two waves per SIMD)
         {2, 256, 256, 1.10f, 0}, {2, 256, 128, 0.80f, 0},
@@ -1322,14 +1290,16 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
         // 192 rows (2 x 4 wave grid): M = 3226 (one clip) is 17 tiles, 17 x 15 = 255 tiles for N = 1920
         {0, 192, 128, 0.920f, 0},
     };
-    static int force_ring = -1, force_bm = 0, force_bn = 0;   // ORV_GEMM_TILE="ring,bm,bn" pins one candidate (sweeps / A-B)
-    if (force_ring < 0) {
-        force_ring = 2;
-        if (const char* e = getenv("ORV_GEMM_TILE")) sscanf(e, "%d,%d,%d", &force_ring, &force_bm, &force_bn);
-        if (const char* e = getenv("ORV_GEMM_ALGO")) { if (atoi(e) == 0) force_ring = 0; }   // legacy switch: simple kernel only
+    if (g_force_ring < 0) {
+        g_force_ring = 2;
+        if (const char* e = getenv("ORV_GEMM_TILE")) sscanf(e, "%d,%d,%d", &g_force_ring, &g_force_bm, &g_force_bn);
+        if (const char* e = getenv("ORV_GEMM_ALGO")) { if (atoi(e) == 0) g_force_ring = 0; }   // legacy switch: simple kernel only
     }
+    const int force_ring = g_force_ring, force_bm = g_force_bm, force_bn = g_force_bn;
     static int no_phased = -1;   // ORV_GEMM_PHASED=0: A/B switch for the phased kernel
     if (no_phased < 0) { const char* e = getenv("ORV_GEMM_PHASED"); no_phased = (e && atoi(e) == 0) ? 1 : 0; }
+    static int no_t8 = -1;       // ORV_GEMM_T8=0: A/B switch for the t8 kernel
+    if (no_t8 < 0) { const char* e = getenv("ORV_GEMM_T8"); no_t8 = (e && atoi(e) == 0) ? 1 : 0; }
     static int no384 = -1;   // ORV_GEMM_BN384=0: A/B switch for the 384-wide variant
     if (no384 < 0) { const char* e = getenv("ORV_GEMM_BN384"); no384 = (e && atoi(e) == 0) ? 1 : 0; }
     const int ncu = orv_num_cus();
@@ -1338,6 +1308,7 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
     for (const GemmCand& c : cands) {
         if (N % c.bn) continue;
         if (c.ring == 2 && (K % 128 != 0 || no_phased)) continue;
+        if (c.ring == 3 && (K % 128 != 0 || no_t8 || (epilogue == 4 && c.bn != 256))) continue;
         // epilogue 4 normalises whole 64-wide heads inside a wave (BN / 2 columns) that must not straddle q | k | v
         if (epilogue == 4 && (c.bm == 192 || (c.bn / 2) % 64 != 0 || (heads * 64) % (c.bn / 2) != 0)) continue;
         if (force_bm && (c.ring != force_ring || c.bm != force_bm || c.bn != force_bn)) continue;
@@ -1359,16 +1330,68 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
     return best;
 }
 
-// the kernel symbol orv_gemm_bf16 launches for a shape, as rocprofv3 prints it (bench.py labels its timings with it)
-extern "C" int orv_gemm_kernel_name(int M, int N, int K, int epilogue, char* buf, int len) {
-    ORV_REQUIRE(buf && len > 0 && M > 0 && N > 0 && N % 64 == 0, "orv_gemm_kernel_name: bad arguments");
-    const GemmCand* c = choose_tile(M, N, K, epilogue, epilogue == 4 ? N / 192 : 0);
-    ORV_REQUIRE(c, "orv_gemm_kernel_name: no tile configuration for N=%d", N);
-    if (c->ring == 2) snprintf(buf, len, "gemm_ph_kernel<%d, %d>", c->bn, epilogue);
+// Launch plan of one orv_gemm_bf16 call: one candidate, or - fused-qk-LayerNorm projection whose width is not a multiple of
+// 256 (2B: N = 5760) - two: the t8 kernel normalises whole heads per wave only at BN = 256, so the call is split into q | k
+// (N = 2 H 64 = 3840 = 15 x 256, epilogue 4) and v (N = H 64 = 1920, plain bias epilogue into the same packed buffer) whenever the
+// cost model puts the q | k part on the t8 kernel: 0.247 vs 0.286 ms per layer at B = 4 (profiles/r3_gemm_t8_ab.txt).  The A
+// operand is read by both launches (L2 / Infinity Cache).  ORV_GEMM_QKV_SPLIT=0: A/B switch.
+static bool plan_gemm(int M, int N, int K, int epilogue, int heads, const GemmCand*& first, const GemmCand*& second) {
+    static int qkv_split = -1;
+    if (qkv_split < 0) { const char* e = getenv("ORV_GEMM_QKV_SPLIT"); qkv_split = (e && atoi(e) == 0) ? 0 : 1; }
+    second = nullptr;
+    first = choose_tile(M, N, K, epilogue, heads);
+    if (epilogue == 4 && qkv_split && heads > 0 && N == 3 * heads * 64 && !(first && first->ring == 3)) {
+        const GemmCand* qk = choose_tile(M, 2 * heads * 64, K, 4, heads);
+        const GemmCand* vv = choose_tile(M, heads * 64, K, 0, 0);
+        if (qk && qk->ring == 3 && vv) { first = qk; second = vv; }
+    }
+    return first != nullptr;
+}
+static void cand_name(const GemmCand* c, int epilogue, char* buf, int len) {
+    if (c->ring == 3) snprintf(buf, len, "gemm_t8_kernel<%d, %d>", c->bn, epilogue);
+    else if (c->ring == 2) snprintf(buf, len, "gemm_ph_kernel<%d, %d>", c->bn, epilogue);
     else if (c->ring) snprintf(buf, len, "gemm_pp_kernel<%d, %d, %d>", c->bn, c->bn == 384 ? 4 : 5, epilogue);
     else if (c->bm == 192) snprintf(buf, len, "gemm_kernel<%d, %d, %d, 2, 2>", c->bm, c->bn, epilogue);
     else snprintf(buf, len, "gemm_kernel<%d, %d, %d, 4, 2>", c->bm, c->bn, epilogue);
+}
+
+// the kernel symbol orv_gemm_bf16 launches for a shape, as rocprofv3 prints it (bench.py labels its timings with it)
+extern "C" int orv_gemm_kernel_name(int M, int N, int K, int epilogue, char* buf, int len) {
+    ORV_REQUIRE(buf && len > 0 && M > 0 && N > 0 && N % 64 == 0, "orv_gemm_kernel_name: bad arguments");
+    const GemmCand *c = nullptr, *c2 = nullptr;
+    ORV_REQUIRE(plan_gemm(M, N, K, epilogue, epilogue == 4 ? N / 192 : 0, c, c2), "orv_gemm_kernel_name: no tile configuration for N=%d", N);
+    cand_name(c, epilogue, buf, len);
+    if (c2) {                     // split q | k + v launch: both symbols
+        const int n = (int)strlen(buf);
+        if (n + 4 < len) { snprintf(buf + n, len - n, " + "); cand_name(c2, 0, buf + n + 3, len - n - 3); }
+    }
     return ORV_OK;
+}
+
+// launch the chosen candidate
+static int gemm_dispatch(GemmArgs a, const GemmCand* best, int epilogue, hipStream_t st) {
+    a.tiles_n = a.N / best->bn;
+    a.tiles_m = (a.M + best->bm - 1) / best->bm;
+    if (best->ring == 3) return launch_t8(a, best->bn, epilogue, st);
+    if (best->ring == 2) {
+        if (best->bn == 256) return launch_ph<256>(a, epilogue, st);
+        return launch_ph<128>(a, epilogue, st);
+    }
+    if (best->ring) {
+        if (best->bn == 384) return launch_pp<384, 4>(a, epilogue, st);
+        if (best->bn == 256) return launch_pp<256, 5>(a, epilogue, st);
+        if (best->bn == 192) return launch_pp<192, 5>(a, epilogue, st);
+        return launch_pp<128, 5>(a, epilogue, st);
+    }
+    if (best->bm == 192) return launch<192, 128, 2>(a, epilogue, st);
+    if (best->bm == 256) {
+        if (best->bn == 192) return launch<256, 192>(a, epilogue, st);
+        if (best->bn == 128) return launch<256, 128>(a, epilogue, st);
+        return launch<256, 64>(a, epilogue, st);
+    }
+    if (best->bn == 192) return launch<128, 192>(a, epilogue, st);
+    if (best->bn == 128) return launch<128, 128>(a, epilogue, st);
+    return launch<128, 64>(a, epilogue, st);
 }
 
 // BN must divide N: 192 divides 1920/5760/7680 (the 2B model) exactly, 128/256 cover 3072-wide (5B) and the tiny test
@@ -1396,34 +1419,26 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
     a.qn_gq = (const bf16_t*)g->qn_gamma_q; a.qn_bq = (const bf16_t*)g->qn_beta_q; a.qn_gk = (const bf16_t*)g->qn_gamma_k;
     a.qn_bk = (const bf16_t*)g->qn_beta_k; a.qn_eps = g->qn_eps; a.qn_premul = g->qn_premul; a.qn_heads = g->qn_heads;
     if (g->epilogue == 4) {
-        ORV_REQUIRE(g->qn_heads > 0 && g->N == 3 * g->qn_heads * 64, "orv_gemm_bf16: epilogue 4 needs N = 3 * heads * 64 (N=%d heads=%d)", g->N, g->qn_heads);
+        ORV_REQUIRE(g->qn_heads > 0 && (g->N == 3 * g->qn_heads * 64 || g->N == 2 * g->qn_heads * 64),
+                    "orv_gemm_bf16: epilogue 4 needs N = 3 * heads * 64 (q | k | v) or 2 * heads * 64 (q | k) (N=%d heads=%d)", g->N, g->qn_heads);
         ORV_REQUIRE(g->cmap.rows == 0, "orv_gemm_bf16: epilogue 4 writes rows in place (no cmap)");
     }
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("ORV_GEMM_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     hipStream_t st = (hipStream_t)stream;
-    const GemmCand* best = choose_tile(g->M, g->N, g->K, g->epilogue, g->qn_heads);
-    ORV_REQUIRE(best, "orv_gemm_bf16: no tile configuration for N=%d (ORV_GEMM_TILE override?)", g->N);
-    a.tiles_n = g->N / best->bn;
-    a.tiles_m = (g->M + best->bm - 1) / best->bm;
-    if (best->ring == 2) {
-        if (best->bn == 256) return launch_ph<256>(a, g->epilogue, st);
-        return launch_ph<128>(a, g->epilogue, st);
-    }
-    if (best->ring) {
-        if (best->bn == 384) return launch_pp<384, 4>(a, g->epilogue, st);
-        if (best->bn == 256) return launch_pp<256, 5>(a, g->epilogue, st);
-        if (best->bn == 192) return launch_pp<192, 5>(a, g->epilogue, st);
-        return launch_pp<128, 5>(a, g->epilogue, st);
-    }
-    if (best->bm == 192) return launch<192, 128, 2>(a, g->epilogue, st);
-    if (best->bm == 256) {
-        if (best->bn == 192) return launch<256, 192>(a, g->epilogue, st);
-        if (best->bn == 128) return launch<256, 128>(a, g->epilogue, st);
-        return launch<256, 64>(a, g->epilogue, st);
-    }
-    if (best->bn == 192) return launch<128, 192>(a, g->epilogue, st);
-    if (best->bn == 128) return launch<128, 128>(a, g->epilogue, st);
-    return launch<128, 64>(a, g->epilogue, st);
+    const GemmCand *first = nullptr, *second = nullptr;
+    ORV_REQUIRE(plan_gemm(g->M, g->N, g->K, g->epilogue, g->qn_heads, first, second),
+                "orv_gemm_bf16: no tile configuration for N=%d (ORV_GEMM_TILE override?)", g->N);
+    if (!second) return gemm_dispatch(a, first, g->epilogue, st);
+    const int nqk = 2 * g->qn_heads * 64;
+    GemmArgs q = a;
+    q.N = nqk;
+    const int rc = gemm_dispatch(q, first, 4, st);
+    if (rc != ORV_OK) return rc;
+    GemmArgs v = a;
+    v.N = g->N - nqk; v.W = a.W + (long)nqk * a.ldw; v.C = a.C + nqk;
+    if (a.bias) v.bias = a.bias + nqk;
+    if (a.Y) v.Y = a.Y + nqk;
+    return gemm_dispatch(v, second, 0, st);
 }
 
 // Implicit-GEMM convolution entry point: g->A is ignored (the A operand is gathered from c->src), g->M = B*T*H*W, g->K = taps * C.

@@ -1,0 +1,57 @@
+// Shared by the GEMM translation units (gemm.hip: simple / ring / phased / convolution kernels; gemm_t8.hip: the 16x16x32
+// 8-phase kernel): argument block, tile -> workgroup map, device query.
+#pragma once
+#include "common.hpp"
+
+namespace orv_gemm {
+
+inline int orv_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+struct GemmArgs {
+    const bf16_t* A; long lda;
+    const bf16_t* W; long ldw;
+    const bf16_t* bias;
+    bf16_t* C; long ldc;
+    int M, N, K;
+    const bf16_t* R; long ldr; int r_mod;
+    const float* gate; long gate_b, gate_g;
+    int seq, n_text, per_group;
+    int c_rows, c_bstride, c_off;
+    bf16_t* Y; long ldy;   // optional second output: the pre-epilogue value acc + bias (saved for backward)
+    // epilogue 4 (fused qk LayerNorm of the QKV projection): norm_q / norm_k affine [64], eps, q pre-multiplier, heads
+    const bf16_t *qn_gq, *qn_bq, *qn_gk, *qn_bk; float qn_eps, qn_premul; int qn_heads;
+    int tiles_m, tiles_n;
+    int dbg;  // ORV_GEMM_DBG: 1 = skip main-loop loads, 2 = skip MFMAs (ablation only)
+};
+
+constexpr int BK = 64;
+constexpr int GM = 4;  // super-tile height in tiles
+
+// XCD-aware tile mapping (bijective for any grid size): block b runs on XCD b % 8; each XCD gets a contiguous chunk of the
+// tile list, ordered in GM x (tiles_n) groups walked m-fastest so concurrent CUs of an XCD share A and W panels in L2.
+__device__ __forceinline__ void tile_of_index(const GemmArgs& p, int b, int nb, int& tm, int& tn) {
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7, j = b >> 3;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    const int per = GM * p.tiles_n;
+    const int gid = L / per, rem = L % per;
+    const int first_m = gid * GM;
+    const int gsize = min(p.tiles_m - first_m, GM);
+    tm = first_m + rem % gsize;
+    tn = rem / gsize;
+}
+__device__ __forceinline__ void tile_of_block(const GemmArgs& p, int& tm, int& tn) { tile_of_index(p, blockIdx.x, gridDim.x, tm, tn); }
+
+
+// gemm_t8.hip: launches gemm_t8_kernel<BN, EPI> (BN = 256 or 192); a.tiles_m / a.tiles_n must be set for BM = 256, BN
+int launch_t8(const GemmArgs& a, int bn, int epi, hipStream_t st);
+
+}  // namespace orv_gemm

@@ -1,0 +1,480 @@
+// bf16 GEMM  C = epilogue(A[M,K] . W[N,K]^T + bias), the 256-row "t8" kernel: the 8-phase schedule of
+// /opt/skills/guides/cdna_hip_programming.md 5 ("The 256^2 8-phase template") in the form the control probe
+// (tools/probe_gemm_template.cpp, profiles/r3_gemm_template_control_ab.txt) measured 11-18 % ahead of gemm_ph_kernel on the
+// same box: v_mfma_f32_16x16x32_bf16, 8 waves as 2 (M) x 4 (N), a wave owns 128 rows x BN/4 columns, BK = 64, operands staged by
+// global_load_lds into st_16x32 subtiles (16 rows x 32 k = 1 KiB = one DMA instruction of a wave; byte ^= ((byte >> 9) & 1) << 5
+// applied to the DMA SOURCE lane map and to the ds_read address), two LDS buffers, the second half of the workgroup (waves 4-7: the
+// second wave of every SIMD) one barrier behind the first, ONE counted vmcnt per K-tile.  On top of the template:
+//   * persistent: one workgroup per CU walks the XCD-aware tile list; every half-tile DMA stream keeps its own (tile, K-tile)
+//     cursor and simply continues into the next output tile, so a tile's first two K-tiles land under the previous epilogue
+//     (K = 1920 is only 30 K-tiles: the exposed prologue was ~10 % of such a tile).
+//   * C^T accumulators (W fragment as the MFMA A operand): a lane holds 4 consecutive output columns of one row per 16x16 block.
+//     Which W row sits in which LDS row is free (the DMA source address is per lane), so the W rows of a wave are PERMUTED on the
+//     way in such that lane group g = lane >> 4 ends up with 8 CONTIGUOUS columns per block pair: 16-byte stores / residual
+//     loads, 64 contiguous bytes per row and instruction, no cross-lane exchange in the epilogue.
+//   * BN = 256: 4 phases per K-tile exactly as the template (quadrants (m0,n0) (m1,n0) (m1,n1) (m0,n1), loads 12 / 8 / 4 / 0
+//     ds_read_b128 + one half-tile of DMA per phase, vmcnt(6)).
+//     BN = 192 (N = 1920 / 5760 of the 2B model: 510 / 1530 tiles): a wave owns 128 x 48 = 8 x 3 blocks; 3 phases per K-tile of
+//     16 MFMAs each - (m0, n01) | (m0, n2) + (m1, n2) | (m1, n01) - with loads 12 / 10 / 0 and DMA 3 / 2 / 2 instructions, vmcnt(4).
+//   * epilogues 0-3 as gemm.hip (bias, GELU, gated residual, GELU adjoint; optional Y = acc + bias; row scatter); epilogue 4
+//     (fused qk LayerNorm) for BN = 256, where a wave's 64 columns are exactly one head.
+// Requires K % 128 == 0 and N % BN == 0 (the tile chooser checks).
+#include "gemm_common.hpp"
+
+namespace {
+using namespace orv_gemm;
+
+__device__ __forceinline__ float sum_xor16(float v) {      // v(lane) + v(lane ^ 16)
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float sum_xor32(float v) {      // v(lane) + v(lane ^ 32)
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void unpack8(const uint4 u, float (&f)[8]) {
+    f[0] = bf2f(u.x & 0xffff); f[1] = bf2f(u.x >> 16); f[2] = bf2f(u.y & 0xffff); f[3] = bf2f(u.y >> 16);
+    f[4] = bf2f(u.z & 0xffff); f[5] = bf2f(u.z >> 16); f[6] = bf2f(u.w & 0xffff); f[7] = bf2f(u.w >> 16);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+}
+
+// Column layout of a wave's BN/4 columns (relative to nbase = tn * BN + wc * BN/4), lane group g = lane >> 4, register e:
+//   BN = 256: block blk = 2 P + t (pair P = 0, 1):  column 32 P + 8 g + 4 t + e      -> 8-column pieces at 32 P + 8 g
+//   BN = 192: blocks 0, 1 (pair 0):                 column 8 g + 4 blk + e           -> one 8-column piece at 8 g
+//             block 2:                              column 32 + 4 g + e              -> one 4-column piece
+template <int BN, int EPI>
+__device__ __forceinline__ void t8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][4][BN / 64], const int mbase, const int nbase, const int lane) {
+    constexpr int NP = BN == 256 ? 2 : 1;            // 8-column pieces per row
+    constexpr bool TAIL = BN == 192;                 // plus one 4-column piece
+    const int g = lane >> 4, r16 = lane & 15;
+    int col8[NP];
+#pragma unroll
+    for (int P = 0; P < NP; ++P) col8[P] = nbase + 32 * P + 8 * g;
+    const int col4 = nbase + 32 + 4 * g;
+
+    // bias of this lane's columns (vector loads: the column depends on the lane group)
+    float b8[NP][8], b4[4];
+#pragma unroll
+    for (int P = 0; P < NP; ++P)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b8[P][e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b4[e] = 0.f;
+    if (p.bias) {
+#pragma unroll
+        for (int P = 0; P < NP; ++P) unpack8(*(const uint4*)(p.bias + col8[P]), b8[P]);
+        if (TAIL) {
+            const uint2 u = *(const uint2*)(p.bias + col4);
+            b4[0] = bf2f(u.x & 0xffff); b4[1] = bf2f(u.x >> 16); b4[2] = bf2f(u.y & 0xffff); b4[3] = bf2f(u.y >> 16);
+        }
+    }
+
+    if constexpr (EPI == 4) {
+        // fused qk LayerNorm(64) (diffusers Attention.norm_q / norm_k as called at cogvideox_control.py:243-247) + the softmax
+        // pre-multiplier of q: BN = 256, the wave's 64 columns are ONE head of q | k | v; a row's 64 values sit in the four lanes
+        // r16 + 16 g (16 each): statistics = lane-local sums + two half-swaps.
+        static_assert(BN == 256 || EPI != 4, "epilogue 4 needs whole heads per wave");
+        const int region = __builtin_amdgcn_readfirstlane(nbase / (p.qn_heads * 64));     // 0 = q, 1 = k, 2 = v
+        const bf16_t* gam = region == 0 ? p.qn_gq : p.qn_gk;
+        const bf16_t* bet = region == 0 ? p.qn_bq : p.qn_bk;
+        const float post = region == 0 ? p.qn_premul : 1.f;
+        float ga[NP][8], be[NP][8];
+#pragma unroll
+        for (int P = 0; P < NP; ++P) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ga[P][e] = 1.f; be[P][e] = 0.f; }
+            if (region < 2 && gam) unpack8(*(const uint4*)(gam + 32 * P + 8 * g), ga[P]);
+            if (region < 2 && bet) unpack8(*(const uint4*)(bet + 32 * P + 8 * g), be[P]);
+        }
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const int m = mbase + mh * 64 + mb * 16 + r16;
+                const bool valid = m < p.M;              // the four lanes of a row agree
+                const long orow = min(m, p.M - 1);
+                float v[NP][8];
+                float s = 0.f;
+#pragma unroll
+                for (int P = 0; P < NP; ++P)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { v[P][e] = acc[mh][mb][2 * P + (e >> 2)][e & 3] + b8[P][e]; s += v[P][e]; }
+                if (p.Y && valid) {
+#pragma unroll
+                    for (int P = 0; P < NP; ++P) *(uint4*)(p.Y + orow * p.ldy + col8[P]) = pack8(v[P]);
+                }
+                if (region < 2) {
+                    const float mean = sum_xor32(sum_xor16(s)) * (1.f / 64.f);
+                    float sq = 0.f;
+#pragma unroll
+                    for (int P = 0; P < NP; ++P)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { v[P][e] -= mean; sq += v[P][e] * v[P][e]; }
+                    const float rstd = rsqrtf(sum_xor32(sum_xor16(sq)) * (1.f / 64.f) + p.qn_eps);
+#pragma unroll
+                    for (int P = 0; P < NP; ++P)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[P][e] = (v[P][e] * rstd * ga[P][e] + be[P][e]) * post;
+                }
+                if (valid) {
+#pragma unroll
+                    for (int P = 0; P < NP; ++P) *(uint4*)(p.C + orow * p.ldc + col8[P]) = pack8(v[P]);
+                }
+            }
+        return;
+    } else {
+        // gate row cache (EPI 2): 16-row blocks almost always lie inside one (batch element, token group) and consecutive blocks
+        // share it - the fp32 gate values of this lane's columns are reloaded only when the block's gate row changes
+        float g8[NP][8], g4[4];
+        const float* g_cached = nullptr;
+#pragma unroll
+        for (int P = 0; P < NP; ++P)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g8[P][e] = 1.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g4[e] = 1.f;
+
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh) {
+            // row operands of the four 16-row blocks of this half are requested together
+            long orow[4], rr[4];
+            bool valid[4];
+            uint4 r8[4][NP];
+            uint2 r4[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const int m = mbase + mh * 64 + mb * 16 + r16;
+                valid[mb] = m < p.M;
+                const int mc = min(m, p.M - 1);
+                orow[mb] = mc;
+                if (p.c_rows > 0) orow[mb] = (long)(mc / p.c_rows) * p.c_bstride + p.c_off + mc % p.c_rows;
+                rr[mb] = p.r_mod > 0 ? mc % p.r_mod : orow[mb];
+                if (EPI == 2 || EPI == 3) {
+#pragma unroll
+                    for (int P = 0; P < NP; ++P) r8[mb][P] = *(const uint4*)(p.R + rr[mb] * p.ldr + col8[P]);
+                    if (TAIL) r4[mb] = *(const uint2*)(p.R + rr[mb] * p.ldr + col4);
+                }
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                bool g_lane = false;             // block straddles a frame / text boundary: per-lane gate rows
+                const float* grow = nullptr;
+                if (EPI == 2 && p.gate) {
+                    const int mf = __builtin_amdgcn_readfirstlane(mbase + mh * 64 + mb * 16), ml = min(mf + 15, p.M - 1);
+                    long of = min(mf, p.M - 1), ol = ml;
+                    if (p.c_rows > 0) {
+                        of = (long)(of / p.c_rows) * p.c_bstride + p.c_off + of % p.c_rows;
+                        ol = (long)(ml / p.c_rows) * p.c_bstride + p.c_off + ml % p.c_rows;
+                    }
+                    const int bf_ = (int)(of / p.seq), bl_ = (int)(ol / p.seq);
+                    const int gf_ = orv_group_of((int)(of % p.seq), p.n_text, p.per_group);
+                    const int gl_ = orv_group_of((int)(ol % p.seq), p.n_text, p.per_group);
+                    if (bf_ == bl_ && gf_ == gl_) {
+                        const float* gr = p.gate + bf_ * p.gate_b + gf_ * p.gate_g;
+                        if (gr != g_cached) {
+                            g_cached = gr;
+#pragma unroll
+                            for (int P = 0; P < NP; ++P) {
+                                const float4 a = *(const float4*)(gr + col8[P]), b = *(const float4*)(gr + col8[P] + 4);
+                                g8[P][0] = a.x; g8[P][1] = a.y; g8[P][2] = a.z; g8[P][3] = a.w;
+                                g8[P][4] = b.x; g8[P][5] = b.y; g8[P][6] = b.z; g8[P][7] = b.w;
+                            }
+                            if (TAIL) { const float4 a = *(const float4*)(gr + col4); g4[0] = a.x; g4[1] = a.y; g4[2] = a.z; g4[3] = a.w; }
+                        }
+                    } else {
+                        g_lane = true;
+                        const int bidx = (int)(orow[mb] / p.seq), s = (int)(orow[mb] % p.seq);
+                        grow = p.gate + bidx * p.gate_b + orv_group_of(s, p.n_text, p.per_group) * p.gate_g;
+                    }
+                }
+                bf16_t* crow = p.C + orow[mb] * p.ldc;
+                bf16_t* yrow = p.Y ? p.Y + orow[mb] * p.ldy : nullptr;
+#pragma unroll
+                for (int P = 0; P < NP; ++P) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = acc[mh][mb][2 * P + (e >> 2)][e & 3] + b8[P][e];
+                    if (yrow && valid[mb]) *(uint4*)(yrow + col8[P]) = pack8(v);
+                    if (EPI == 1) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+                    }
+                    if (EPI == 2) {
+                        float rv[8], gg[8];
+                        unpack8(r8[mb][P], rv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) gg[e] = g8[P][e];
+                        if (g_lane) {
+                            const float4 a = *(const float4*)(grow + col8[P]), b = *(const float4*)(grow + col8[P] + 4);
+                            gg[0] = a.x; gg[1] = a.y; gg[2] = a.z; gg[3] = a.w; gg[4] = b.x; gg[5] = b.y; gg[6] = b.z; gg[7] = b.w;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = rv[e] + gg[e] * v[e];
+                    }
+                    if (EPI == 3) {
+                        float rv[8];
+                        unpack8(r8[mb][P], rv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= gelu_tanh_grad(rv[e]);
+                    }
+                    if (valid[mb]) *(uint4*)(crow + col8[P]) = pack8(v);
+                }
+                if (TAIL) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[mh][mb][BN / 64 - 1][e] + b4[e];
+                    if (yrow && valid[mb]) *(uint2*)(yrow + col4) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                    if (EPI == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+                    }
+                    if (EPI == 2 || EPI == 3) {
+                        const float rv[4] = {bf2f(r4[mb].x & 0xffff), bf2f(r4[mb].x >> 16), bf2f(r4[mb].y & 0xffff), bf2f(r4[mb].y >> 16)};
+                        if (EPI == 2) {
+                            float gg[4] = {g4[0], g4[1], g4[2], g4[3]};
+                            if (g_lane) { const float4 a = *(const float4*)(grow + col4); gg[0] = a.x; gg[1] = a.y; gg[2] = a.z; gg[3] = a.w; }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = rv[e] + gg[e] * v[e];
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] *= gelu_tanh_grad(rv[e]);
+                        }
+                    }
+                    if (valid[mb]) *(uint2*)(crow + col4) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                }
+            }
+        }
+    }
+}
+
+template <int BN, int EPI>
+__global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
+    constexpr int NBW = BN / 64;                      // 16-column blocks per wave
+    constexpr int HALF = 16384;                       // A0 | A1 | B region 0 | B region 1
+    constexpr int BUF = BN == 256 ? 65536 : 57344;    // BN = 192: the second B region (block 2 of every wave) is 64 rows = 8 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int nk = p.K / BK;                          // even (chooser-checked)
+
+    // ---- DMA side.  One wave instruction fills one 1-KiB subtile; lane l writes physical bytes [16 l, 16 l + 16), which hold logical
+    // byte 16 (l ^ ((l >> 5) << 1)) of the subtile: row (of 16) = that >> 2, 16-byte k-chunk (of 4) = that & 3.
+    const int lsw = lane ^ ((lane >> 5) << 1);
+    const int srow = lsw >> 2, schunk = lsw & 3;
+    const int q = wave * 16 + srow;                   // row of a 128-row half-tile this lane feeds (k halves 0 / 1: two instructions)
+    const int arow0 = (q >> 6) * 128 + (q & 63);      // + h * 64: tile row held by row q of A half h
+    int brow0, brow1;                                 // tile column held by row q of B region 0 / by this lane's row of region 1
+    {
+        const int wc_ = q >> 5, nb_ = (q >> 4) & 1, r = q & 15;
+        if (BN == 256) {
+            brow0 = wc_ * 64 + 8 * (r >> 2) + 4 * nb_ + (r & 3);      // + h * 32
+            brow1 = brow0 + 32;
+        } else {
+            brow0 = wc_ * 48 + 8 * (r >> 2) + 4 * nb_ + (r & 3);
+            brow1 = (wave >> 1) * 48 + 32 + srow;                     // region 1: 64 rows, wave w fills subtile (row block w >> 1, k half w & 1)
+        }
+    }
+    const int koff1 = BN == 256 ? schunk * 8 : (wave & 1) * 32 + schunk * 8;
+    char* const dst2 = smem + wave * 2048;            // two-instruction streams: + S * BUF + region * HALF (+ 1024 for k half 1)
+    char* const dst1 = smem + 3 * HALF + wave * 1024; // BN = 192 region 1: + S * BUF
+
+    const bf16_t *pA0, *pA1, *pB0, *pB1;
+    int kA0 = 0, kA1 = 0, kB0 = 0, kB1 = 0;
+    int tA0 = blockIdx.x, tA1 = blockIdx.x, tB0 = blockIdx.x, tB1 = blockIdx.x;
+#define T8_SETUP_A(PTR, H, TILE)                                                                                     \
+    {                                                                                                                \
+        int tm_, tn_;                                                                                                \
+        tile_of_index(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                                                 \
+        PTR = p.A + (long)min(tm_ * 256 + arow0 + (H) * 64, p.M - 1) * p.lda + schunk * 8;                           \
+    }
+#define T8_SETUP_B(PTR, H, TILE)                                                                                     \
+    {                                                                                                                \
+        int tm_, tn_;                                                                                                \
+        tile_of_index(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                                                 \
+        if ((H) == 0) PTR = p.W + (long)(tn_ * BN + brow0) * p.ldw + schunk * 8;                                     \
+        else PTR = p.W + (long)(tn_ * BN + brow1) * p.ldw + koff1;                                                   \
+    }
+    // advance a stream by one K-tile; past its tile's last K-tile it moves to the workgroup's next tile (past the last tile: the
+    // final tile again - uniform instruction counts, data never read)
+#define T8_NEXT_A(PTR, KC, TC, H)                                                                                    \
+    PTR += BK;                                                                                                       \
+    if (__builtin_expect(++KC == nk, 0)) { KC = 0; TC += gridDim.x; T8_SETUP_A(PTR, H, TC) }
+#define T8_NEXT_B(PTR, KC, TC, H)                                                                                    \
+    PTR += BK;                                                                                                       \
+    if (__builtin_expect(++KC == nk, 0)) { KC = 0; TC += gridDim.x; T8_SETUP_B(PTR, H, TC) }
+#define T8_ISSUE_A0(S) { glds16(pA0, dst2 + (S) * BUF); glds16(pA0 + 32, dst2 + (S) * BUF + 1024); T8_NEXT_A(pA0, kA0, tA0, 0) }
+#define T8_ISSUE_A1(S) { glds16(pA1, dst2 + (S) * BUF + HALF); glds16(pA1 + 32, dst2 + (S) * BUF + HALF + 1024); T8_NEXT_A(pA1, kA1, tA1, 1) }
+#define T8_ISSUE_B0(S) { glds16(pB0, dst2 + (S) * BUF + 2 * HALF); glds16(pB0 + 32, dst2 + (S) * BUF + 2 * HALF + 1024); T8_NEXT_B(pB0, kB0, tB0, 0) }
+#define T8_ISSUE_B1(S)                                                                                               \
+    {                                                                                                                \
+        if constexpr (BN == 256) { glds16(pB1, dst2 + (S) * BUF + 3 * HALF); glds16(pB1 + 32, dst2 + (S) * BUF + 3 * HALF + 1024); } \
+        else { glds16(pB1, dst1 + (S) * BUF); }                                                                      \
+        T8_NEXT_B(pB1, kB1, tB1, 1)                                                                                  \
+    }
+    T8_SETUP_A(pA0, 0, tA0)
+    T8_SETUP_A(pA1, 1, tA1)
+    T8_SETUP_B(pB0, 0, tB0)
+    T8_SETUP_B(pB1, 1, tB1)
+
+    // ---- fragment reads: logical byte (l & 15) * 64 + (l >> 4) * 16 of a subtile, bit 5 flipped for rows 8-15
+    const int fro = ((lane & 15) * 64 + (lane >> 4) * 16) ^ (((lane >> 3) & 1) << 5);
+    const char* const rdA = smem + (wr * 4) * 2048 + fro;             // + S * BUF + mh * HALF + mb * 2048 + kh * 1024
+    const char* const rdB = smem + 2 * HALF + (wc * 2) * 2048 + fro;  // region 0 (two blocks per wave): + S * BUF + t * 2048 + kh * 1024
+    const char* const rdB1 = BN == 256 ? rdB + HALF : smem + 3 * HALF + wc * 2048 + fro;
+
+    f32x4 acc[2][4][NBW];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int c = 0; c < NBW; ++c) acc[a][b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[2][4][2], fb[NBW][2];
+
+#define T8_READ_A(MH, S)                                                                                             \
+    _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                                 \
+        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
+            fa[MH][mb][kh] = *(const bf16x8*)(rdA + (S) * BUF + (MH) * HALF + mb * 2048 + kh * 1024);
+#define T8_READ_B01(S)                                                                                               \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                    \
+        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
+            fb[t][kh] = *(const bf16x8*)(rdB + (S) * BUF + t * 2048 + kh * 1024);
+#define T8_READ_B23(S)                                                                                               \
+    _Pragma("unroll") for (int t = 0; t < NBW - 2; ++t)                                                              \
+        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
+            fb[2 + t][kh] = *(const bf16x8*)(rdB1 + (S) * BUF + t * 2048 + kh * 1024);
+    // (m half MH) x (blocks B0 .. B0 + NBK - 1), both k halves
+#define T8_MFMA(MH, B0, NBK)                                                                                         \
+    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                                 \
+        _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                             \
+            _Pragma("unroll") for (int t = 0; t < (NBK); ++t)                                                        \
+                acc[MH][mb][(B0) + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[(B0) + t][kh], fa[MH][mb][kh], acc[MH][mb][(B0) + t], 0, 0, 0);
+#define T8_BAR()                                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    __builtin_amdgcn_s_barrier();                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);
+#define T8_LGKM0()                                                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
+    __builtin_amdgcn_sched_barrier(0);
+#define T8_PRIO1() __builtin_amdgcn_s_setprio(1);
+#define T8_PRIO0() __builtin_amdgcn_s_setprio(0);
+
+#define T8_KTILE_256(S)                                                                                              \
+    {                                                                                                                \
+        T8_READ_B01(S)                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        T8_READ_A(0, S)                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        T8_ISSUE_B1((S) ^ 1)                                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                                           \
+        T8_BAR() T8_LGKM0() T8_PRIO1() T8_MFMA(0, 0, 2) T8_PRIO0() T8_BAR()                                          \
+        T8_READ_A(1, S)                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        T8_ISSUE_B0(S)                                                                                               \
+        T8_BAR() T8_LGKM0() T8_PRIO1() T8_MFMA(1, 0, 2) T8_PRIO0() T8_BAR()                                          \
+        T8_READ_B23(S)                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        T8_ISSUE_A0(S)                                                                                               \
+        T8_BAR() T8_LGKM0() T8_PRIO1() T8_MFMA(1, 2, 2) T8_PRIO0() T8_BAR()                                          \
+        T8_ISSUE_A1(S)                                                                                               \
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                             \
+        T8_BAR() T8_PRIO1() T8_MFMA(0, 2, 2) T8_PRIO0() T8_BAR()                                                     \
+    }
+    // BN = 192: P1 (m0, n01) | P2 (m0, n2) + (m1, n2) | P3 (m1, n01); streams: region 1 + A1 of the NEXT K-tile in P1, region 0
+    // of K-tile + 2 in P2 (its reads were retired by the lgkmcnt(8) before P1's first barrier), A0 of K-tile + 2 in P3
+#define T8_KTILE_192(S)                                                                                              \
+    {                                                                                                                \
+        T8_READ_B01(S)                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        T8_READ_A(0, S)                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        T8_ISSUE_B1((S) ^ 1)                                                                                         \
+        T8_ISSUE_A1((S) ^ 1)                                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                                           \
+        T8_BAR() T8_LGKM0() T8_PRIO1() T8_MFMA(0, 0, 2) T8_PRIO0() T8_BAR()                                          \
+        T8_READ_B23(S)                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        T8_READ_A(1, S)                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        T8_ISSUE_B0(S)                                                                                               \
+        T8_BAR() T8_LGKM0() T8_PRIO1() T8_MFMA(0, 2, 1) T8_MFMA(1, 2, 1) T8_PRIO0() T8_BAR()                         \
+        T8_ISSUE_A0(S)                                                                                               \
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                             \
+        T8_BAR() T8_PRIO1() T8_MFMA(1, 0, 2) T8_PRIO0() T8_BAR()                                                     \
+    }
+
+    // prologue: K-tile 0 complete into buffer 0, then the pieces of K-tile 1 the steady state would have issued by now
+    if constexpr (BN == 256) {
+        T8_ISSUE_A0(0) T8_ISSUE_B0(0) T8_ISSUE_A1(0) T8_ISSUE_B1(0)
+        T8_ISSUE_B0(1) T8_ISSUE_A0(1) T8_ISSUE_A1(1)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        T8_ISSUE_A0(0) T8_ISSUE_B0(0) T8_ISSUE_A1(0) T8_ISSUE_B1(0)
+        T8_ISSUE_B0(1) T8_ISSUE_A0(1)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    T8_BAR()
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (wr == 1) { T8_BAR() }             // the second half of the workgroup runs one barrier behind ...
+        for (int kt = 0; kt < nk; kt += 2) {
+            if constexpr (BN == 256) { T8_KTILE_256(0) T8_KTILE_256(1) }
+            else { T8_KTILE_192(0) T8_KTILE_192(1) }
+        }
+        if (wr == 0) { T8_BAR() }             // ... and both halves run their epilogues side by side
+        int tm, tn;
+        tile_of_index(p, tile, ntiles, tm, tn);
+        t8_epilogue<BN, EPI>(p, acc, tm * 256 + wr * 128, tn * BN + wc * (BN / 4), lane);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int c = 0; c < NBW; ++c) acc[a][b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int BN, int EPI>
+int launch_one(const GemmArgs& a, hipStream_t st) {
+    constexpr int smem = 2 * (BN == 256 ? 65536 : 57344);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_t8_kernel<BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    const int grid = min(a.tiles_m * a.tiles_n, orv_num_cus());
+    hipLaunchKernelGGL((gemm_t8_kernel<BN, EPI>), dim3(grid), dim3(512), smem, st, a);
+    return orv_check_launch("orv_gemm_bf16");
+}
+
+}  // namespace
+
+namespace orv_gemm {
+int launch_t8(const GemmArgs& a, int bn, int epi, hipStream_t st) {
+    if (bn == 256) {
+        switch (epi) {
+            case 0: return launch_one<256, 0>(a, st);
+            case 1: return launch_one<256, 1>(a, st);
+            case 2: return launch_one<256, 2>(a, st);
+            case 3: return launch_one<256, 3>(a, st);
+            case 4: return launch_one<256, 4>(a, st);
+        }
+    } else if (bn == 192) {
+        switch (epi) {
+            case 0: return launch_one<192, 0>(a, st);
+            case 1: return launch_one<192, 1>(a, st);
+            case 2: return launch_one<192, 2>(a, st);
+            case 3: return launch_one<192, 3>(a, st);
+        }
+    }
+    orv_set_error("orv_gemm_bf16: no t8 kernel for BN=%d epilogue %d", bn, epi);
+    return ORV_EINVAL;
+}
+}  // namespace orv_gemm

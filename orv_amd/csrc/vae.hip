@@ -243,3 +243,36 @@ extern "C" int orv_vae_norm_apply(const void* x, void* out, const float* sums, c
                        (hipStream_t)stream, a);
     return orv_check_launch("orv_vae_norm_apply");
 }
+
+// ---- tile seams of the tiled decode / encode (diffusers AutoencoderKLCogVideoX.blend_v / blend_h) ----
+// b[.., y, :] = a[.., Ha - e + y, :] (1 - y / e) + b[.., y, :] (y / e)  for y < e  (vertical: a is the tile above, same width)
+// b[.., :, x] = a[.., :, Wa - e + x] (1 - x / e) + b[.., :, x] (x / e)  for x < e  (horizontal: a is the tile to the left, same height)
+// channels-last [outer = B * T, H, W, C] bf16, in place on b; one thread per element of the blended strip.
+__global__ void vae_blend_kernel(const bf16_t* __restrict__ a, bf16_t* __restrict__ b, int outer, int Ha, int Wa, int Hb, int Wb, int C,
+                                 int extent, int horizontal) {
+    const int sh = horizontal ? Hb : extent, sw = horizontal ? extent : Wb;   // strip of b that changes
+    const long n = (long)outer * sh * sw * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long r = i / C;
+        const int x = (int)(r % sw); r /= sw;
+        const int y = (int)(r % sh);
+        const long o = r / sh;
+        const int ya = horizontal ? y : Ha - extent + y, xa = horizontal ? Wa - extent + x : x;
+        const float w = (float)(horizontal ? x : y) / (float)extent;
+        const long ib = ((o * Hb + y) * Wb + x) * C + c, ia = ((o * Ha + ya) * Wa + xa) * C + c;
+        b[ib] = f2bf(bf2f(a[ia]) * (1.f - w) + bf2f(b[ib]) * w);
+    }
+}
+extern "C" int orv_vae_blend(const void* a, void* b, int outer, int Ha, int Wa, int Hb, int Wb, int C, int extent, int horizontal,
+                             void* stream) {
+    ORV_REQUIRE(a && b && outer > 0 && Ha > 0 && Wa > 0 && Hb > 0 && Wb > 0 && C > 0, "orv_vae_blend: bad shape");
+    ORV_REQUIRE(extent > 0 && (horizontal ? (extent <= Wa && extent <= Wb && Ha == Hb) : (extent <= Ha && extent <= Hb && Wa == Wb)),
+                "orv_vae_blend: extent %d does not fit the tiles (a %dx%d, b %dx%d, %s)", extent, Ha, Wa, Hb, Wb,
+                horizontal ? "horizontal" : "vertical");
+    const long n = (long)outer * (horizontal ? (long)Hb * extent : (long)extent * Wb) * C;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 65535 ? 65535 : (n + 255) / 256);
+    hipLaunchKernelGGL(vae_blend_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (bf16_t*)b, outer, Ha, Wa, Hb,
+                       Wb, C, extent, horizontal);
+    return orv_check_launch("orv_vae_blend");
+}

@@ -358,6 +358,17 @@ def vae_groupnorm_stats(x, B, N, C, G):
     return sums
 
 
+def vae_blend(a, b, extent, horizontal):
+    """In-place seam blend of channels-last tiles a, b [B, T, H, W, C] (diffusers blend_v / blend_h): see orv_vae_blend."""
+    _need(a, BF16, "a"), _need(b, BF16, "b")
+    if not (a.is_contiguous() and b.is_contiguous()):
+        raise ValueError("vae_blend: tiles must be contiguous")
+    B, T, Ha, Wa, C = a.shape
+    _, _, Hb, Wb, _ = b.shape
+    check(lib().orv_vae_blend(_p(a), _p(b), B * T, Ha, Wa, Hb, Wb, C, int(extent), int(bool(horizontal)), _stream()), "orv_vae_blend")
+    return b
+
+
 def vae_norm_apply(x, out, sums, gamma, beta, zy, zb, B, T, H, W, C, G, Tz, hz, wz, eps, silu, out_lead=0):
     """``out`` is [B, out_lead + T, H, W, C]; frames [0, out_lead) of each clip are left untouched."""
     _need(x, BF16, "x"), _need(out, BF16, "out"), _need(gamma, BF16, "gamma"), _need(beta, BF16, "beta")

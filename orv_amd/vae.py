@@ -192,19 +192,38 @@ class AutoencoderKLCogVideoX(nn.Module):
         self.encoder = CogVideoXEncoder3D(c.in_channels, c.latent_channels, *a)
         self.decoder = CogVideoXDecoder3D(c.latent_channels, c.out_channels, *a)
         self._packed = {}
+        self.use_slicing = self.use_tiling = False
+        self.tile_sample_min_height, self.tile_sample_min_width = c.sample_height // 2, c.sample_width // 2
+        down = 2 ** (len(c.block_out_channels) - 1)
+        self.tile_latent_min_height = int(self.tile_sample_min_height / down)
+        self.tile_latent_min_width = int(self.tile_sample_min_width / down)
+        self.tile_overlap_factor_height, self.tile_overlap_factor_width = 1 / 6, 1 / 5
 
     # ---- diffusers surface the reference's entry points touch ----
+    # Both entry points call ``pipe.vae.enable_slicing(); pipe.vae.enable_tiling()`` (/root/reference/orv/pipeline/
+    # inference_control_to_video.py:98-99, evaluation_control_to_video.py:274-275).  Slicing (one batch element at a time) changes
+    # no arithmetic - every GroupNorm statistic is per batch element - and is accepted as a flag.  Tiling DOES: a latent larger
+    # than one latent tile (30 x 45 for the 480 x 720 VAE config) is decoded tile by tile, each tile with its own GroupNorm
+    # statistics and conv caches, and the seams are blended (``_tiled``).  Off by default, as in diffusers.
     def enable_slicing(self):
-        return None
-
-    def enable_tiling(self, *a, **k):
-        return None
+        self.use_slicing = True
 
     def disable_slicing(self):
-        return None
+        self.use_slicing = False
+
+    def enable_tiling(self, tile_sample_min_height: Optional[int] = None, tile_sample_min_width: Optional[int] = None,
+                      tile_overlap_factor_height: Optional[float] = None, tile_overlap_factor_width: Optional[float] = None):
+        self.use_tiling = True
+        self.tile_sample_min_height = tile_sample_min_height or self.tile_sample_min_height
+        self.tile_sample_min_width = tile_sample_min_width or self.tile_sample_min_width
+        down = 2 ** (len(self.config.block_out_channels) - 1)
+        self.tile_latent_min_height = int(self.tile_sample_min_height / down)
+        self.tile_latent_min_width = int(self.tile_sample_min_width / down)
+        self.tile_overlap_factor_height = tile_overlap_factor_height or self.tile_overlap_factor_height
+        self.tile_overlap_factor_width = tile_overlap_factor_width or self.tile_overlap_factor_width
 
     def disable_tiling(self):
-        return None
+        self.use_tiling = False
 
     @property
     def dtype(self):
@@ -439,11 +458,44 @@ class AutoencoderKLCogVideoX(nn.Module):
             prev = new
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
 
+    def _tiled(self, fn, x, frame_batch, tile_h, tile_w, blend_h_ext, blend_w_ext, limit_h, limit_w):
+        """Tiled decode / encode on channels-last ``x`` [B, T, H, W, C] (diffusers ``tiled_decode`` / ``tiled_encode``): ``fn`` on
+        overlapping tiles (stride = tile x (1 - overlap factor); each tile frame-batched with its own conv caches and GroupNorm
+        statistics), then every tile is blended IN PLACE, in raster order, with the (already blended) tile above and the one
+        to its left (``orv_vae_blend``), cropped to ``limit`` and concatenated."""
+        H, W = x.shape[2], x.shape[3]
+        step_h = int(tile_h * (1 - self.tile_overlap_factor_height))
+        step_w = int(tile_w * (1 - self.tile_overlap_factor_width))
+        rows = []
+        for i in range(0, H, step_h):
+            rows.append([self._batched(fn, x[:, :, i:i + tile_h, j:j + tile_w].contiguous(), frame_batch).contiguous()
+                         for j in range(0, W, step_w)])
+        result_rows = []
+        for i, row in enumerate(rows):
+            result_row = []
+            for j, tile in enumerate(row):
+                if i > 0:
+                    above = rows[i - 1][j]
+                    ops.vae_blend(above, tile, min(above.shape[2], tile.shape[2], blend_h_ext), horizontal=False)
+                if j > 0:
+                    left = row[j - 1]
+                    ops.vae_blend(left, tile, min(left.shape[3], tile.shape[3], blend_w_ext), horizontal=True)
+                result_row.append(tile[:, :, :limit_h, :limit_w])
+            result_rows.append(torch.cat(result_row, dim=3))
+        return torch.cat(result_rows, dim=2)
+
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = True):
         """z [B, 16, f, h, w] -> sample [B, 3, 1 + 4 (f - 1), 8 h, 8 w]."""
         self._check(z)
-        x = self._batched(self._decode_batch, self._channels_last(z), self.num_latent_frames_batch_size)
+        zc = self._channels_last(z)
+        if self.use_tiling and (z.shape[-1] > self.tile_latent_min_width or z.shape[-2] > self.tile_latent_min_height):
+            bh = int(self.tile_sample_min_height * self.tile_overlap_factor_height)
+            bw = int(self.tile_sample_min_width * self.tile_overlap_factor_width)
+            x = self._tiled(self._decode_batch, zc, self.num_latent_frames_batch_size, self.tile_latent_min_height,
+                            self.tile_latent_min_width, bh, bw, self.tile_sample_min_height - bh, self.tile_sample_min_width - bw)
+        else:
+            x = self._batched(self._decode_batch, zc, self.num_latent_frames_batch_size)
         sample = x.permute(0, 4, 1, 2, 3).contiguous().to(z.dtype)
         return DecoderOutput(sample) if return_dict else (sample,)
 
@@ -452,7 +504,13 @@ class AutoencoderKLCogVideoX(nn.Module):
         """x [B, 3, F, H, W] in [-1, 1] -> latent_dist over moments [B, 32, 1 + (F - 1) / 4, H / 8, W / 8]."""
         self._check(x)
         h = self._channels_last(x, cpad=(-x.shape[1]) % 8)            # RGB padded to 8 channels (zero weights beyond 3)
-        h = self._batched(self._encode_batch, h, self.num_sample_frames_batch_size)
+        if self.use_tiling and (x.shape[-1] > self.tile_sample_min_width or x.shape[-2] > self.tile_sample_min_height):
+            bh = int(self.tile_latent_min_height * self.tile_overlap_factor_height)
+            bw = int(self.tile_latent_min_width * self.tile_overlap_factor_width)
+            h = self._tiled(self._encode_batch, h, self.num_sample_frames_batch_size, self.tile_sample_min_height,
+                            self.tile_sample_min_width, bh, bw, self.tile_latent_min_height - bh, self.tile_latent_min_width - bw)
+        else:
+            h = self._batched(self._encode_batch, h, self.num_sample_frames_batch_size)
         moments = h.permute(0, 4, 1, 2, 3).contiguous().to(x.dtype)
         dist = DiagonalGaussianDistribution(moments)
         return AutoencoderKLOutput(dist) if return_dict else (dist,)

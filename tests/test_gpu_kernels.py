@@ -464,7 +464,7 @@ print("BAD", bad) if bad else print("TILE-OK")
 """
 
 
-@pytest.mark.parametrize("tile", ["2,256,256", "2,256,128", "1,256,384", "1,256,256", "1,256,192", "1,256,128", "0,256,192",
+@pytest.mark.parametrize("tile", ["3,256,256", "3,256,192", "2,256,256", "2,256,128", "1,256,384", "1,256,256", "1,256,192", "1,256,128", "0,256,192",
                                   "0,256,128", "0,256,64", "0,128,192", "0,128,128", "0,128,64", "0,192,128"])
 def test_every_gemm_tile_instantiation_forced(tile):
     """The tile chooser only ever picks what its cost model prefers; here every candidate (phased / ring / simple, every tile
@@ -476,3 +476,88 @@ def test_every_gemm_tile_instantiation_forced(tile):
     r = subprocess.run([sys.executable, "-c", _TILE_CHECK, tile.split(",")[2]], cwd=root, env=env, capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0 and "TILE-OK" in r.stdout, (tile, r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("bn", [256, 192])
+def test_t8_gemm_matches_simple_kernel_on_every_epilogue_feature(bn):
+    """gemm_t8_kernel (16x16x32 MFMA, permuted W rows, 16-byte epilogue pieces) against the simple kernel pinned in the same
+    process (orv_gemm_force_tile), on everything the epilogue can do: bias, GELU, gated residual with per-token-group gates that
+    straddle 16-row blocks, row scatter (cmap), r_mod residual, the Y side output, GELU adjoint, ragged M, one-tile and
+    multi-round grids; BN = 256 also the fused qk-LayerNorm epilogue.  Both kernels accumulate in fp32 over the same bf16
+    inputs: outputs agree to bf16 rounding of slightly different summation orders."""
+    from orv_amd import ops
+    from orv_amd._lib import lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5 + bn)
+    other = (0, 256, 128) if bn == 256 else (0, 256, 192)
+
+    def run(tile, fn):
+        lib().orv_gemm_force_tile(*tile)
+        try:
+            return fn()
+        finally:
+            lib().orv_gemm_force_tile(0, 0, 0)
+
+    def close(a, b, what):
+        a, b = a.float(), b.float()
+        assert torch.isfinite(a).all() and torch.isfinite(b).all(), what
+        err = (a - b).abs()
+        assert bool((err <= 1.0e-2 * b.abs() + 1.5e-2).all()), (what, err.max().item())
+
+    N = bn * 3
+    for M, K in [(100, 128), (3226 * 2, 256), (70000, 128)]:
+        A = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
+        W = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(torch.bfloat16)
+        bias = torch.randn(N, device=dev, generator=g).to(torch.bfloat16)
+        R = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16)
+        for epi in (0, 1, 2, 3):
+            def fn():
+                C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+                Y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+                ops.gemm(A, W, None if epi == 3 else bias, C, M, N, K, epilogue=epi, Y=Y, **(dict(R=R, ldr=N) if epi >= 2 else {}))
+                return C, Y
+            (c1, y1), (c0, y0) = run((3, 256, bn), fn), run(other, fn)
+            close(c1, c0, (bn, M, K, epi, "C")), close(y1, y0, (bn, M, K, epi, "Y"))
+    # gated residual with token groups (text rows + frames of 37 rows: gate rows change inside 16-row blocks), row scatter into
+    # a joint buffer and a residual addressed modulo r_mod
+    seq, n_text, per_group, Bn = 500, 19, 37, 3
+    Mv = (seq - n_text) * Bn
+    K = 128
+    A = torch.randn(Mv, K, device=dev, generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev, generator=g).to(torch.bfloat16)
+    n_groups = 1 + (seq - n_text + per_group - 1) // per_group
+    gate = torch.randn(Bn, n_groups, N, device=dev, generator=g)
+    base = torch.randn(Bn * seq, N, device=dev, generator=g).to(torch.bfloat16)
+
+    def fn_gate():
+        C = base.clone()
+        ops.gemm(A, W, bias, C, Mv, N, K, epilogue=2, R=C, ldr=N, gate=gate, gate_b=n_groups * N, gate_g=N,
+                 grp=ops.Groups(seq, n_text, per_group), cmap=ops.RowMap(seq - n_text, seq, n_text))
+        return C
+    close(run((3, 256, bn), fn_gate), run(other, fn_gate), (bn, "gate + cmap"))
+    Rm = torch.randn(97, N, device=dev, generator=g).to(torch.bfloat16)
+
+    def fn_rmod():
+        C = torch.full((Mv, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.gemm(A, W, bias, C, Mv, N, K, epilogue=2, R=Rm, ldr=N, r_mod=97)
+        return C
+    close(run((3, 256, bn), fn_rmod), run(other, fn_rmod), (bn, "r_mod"))
+    if bn == 256:
+        heads = 4
+        Nq = 3 * heads * 64
+        M, K = 3226, 256
+        A = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
+        W = (torch.randn(Nq, K, device=dev, generator=g) / K ** 0.5).to(torch.bfloat16)
+        bias = torch.randn(Nq, device=dev, generator=g).to(torch.bfloat16)
+        aff = [torch.randn(64, device=dev, generator=g).to(torch.bfloat16) for _ in range(4)]
+
+        def fn_qk():
+            C = torch.full((M, Nq), float("nan"), dtype=torch.bfloat16, device=dev)
+            Y = torch.full((M, Nq), float("nan"), dtype=torch.bfloat16, device=dev)
+            ops.gemm(A, W, bias, C, M, Nq, K, epilogue=4, Y=Y, qknorm=(aff[0], aff[1], aff[2], aff[3], 1e-6, 0.18, heads))
+            return C, Y
+        (c1, y1), (c0, y0) = run((3, 256, 256), fn_qk), run((0, 256, 128), fn_qk)
+        close(y1, y0, "qknorm Y")
+        # LayerNorm output of near-identical inputs: compare in units of the affine scale
+        assert ((c1.float() - c0.float()).abs() <= 2e-2 * c0.float().abs() + 6e-2).all()

@@ -202,3 +202,69 @@ def test_conv_kernels_against_torch_conv3d(B, T, H, W, Cin, Cout, kt, t_shift, r
                   R=None if res is None else res.to(dev), ldr=Cout)
     err = (out.float().cpu() - ref).abs()
     assert bool((err <= 1.6e-2 * ref.abs() + 2e-2).all()), err.max().item()
+
+
+# ---- tiling (what the reference's entry points switch on: inference_control_to_video.py:98-99) -------------------------------
+TILED = dict(TINY, sample_height=96, sample_width=160)     # tile 48 x 80 px = 6 x 10 latent, stride 5 x 8, blend 8 x 16 px
+
+
+def test_blend_kernel_matches_the_formula():
+    """orv_vae_blend against b[y] = a[-e + y] (1 - y / e) + b[y] (y / e) (diffusers blend_v / blend_h) in fp32, one bf16 rounding."""
+    from orv_amd import ops
+    g = torch.Generator().manual_seed(2)
+    for horizontal, (ha, wa, hb, wb), e in [(False, (7, 9, 5, 9), 4), (True, (6, 11, 6, 4), 3), (False, (3, 5, 8, 5), 3)]:
+        a = torch.randn(2, 3, ha, wa, 8, generator=g).to(BF)
+        b = torch.randn(2, 3, hb, wb, 8, generator=g).to(BF)
+        want = b.float().clone()
+        for t in range(e):
+            w = t / e
+            if horizontal:
+                want[:, :, :, t] = a.float()[:, :, :, wa - e + t] * (1 - w) + b.float()[:, :, :, t] * w
+            else:
+                want[:, :, t] = a.float()[:, :, ha - e + t] * (1 - w) + b.float()[:, :, t] * w
+        got = ops.vae_blend(a.cuda(), b.cuda().clone(), e, horizontal).cpu()
+        assert torch.allclose(got.float(), want.to(BF).float(), rtol=8e-3, atol=1e-6)
+        untouched = got[:, :, :, e:] if horizontal else got[:, :, e:]
+        assert torch.equal(untouched, b[:, :, :, e:] if horizontal else b[:, :, e:])
+
+
+def test_tiled_decode_matches_tiled_oracle():
+    """Latent 8 x 14 against a 6 x 10 tile: 4 tiles (6x10, 6x6, 3x10, 3x6), each decoded with its own GroupNorm statistics and
+    conv caches, seams blended in place in raster order.  HIP tiled == oracle tiled, and tiled != untiled (it is arithmetic)."""
+    ref, m = make(TILED, seed=5)
+    z = torch.randn(2, 16, 3, 8, 14, generator=torch.Generator().manual_seed(9)).to(BF).float()
+    ref.enable_tiling(); m.enable_tiling(); m.enable_slicing()
+    with torch.no_grad():
+        want = ref.decode(z)
+        ref.disable_tiling()
+        untiled = ref.decode(z)
+    got = m.decode(z.to("cuda:0", BF)).sample
+    assert got.shape == want.shape == untiled.shape == (2, 3, 9, 64, 112)
+    assert rel_l2(got, want) <= 3e-2
+    assert rel_l2(untiled, want) > 5e-2            # per-tile statistics: a different function
+    m.disable_tiling()
+    assert rel_l2(m.decode(z.to("cuda:0", BF)).sample, untiled) <= 3e-2
+
+
+def test_tiled_encode_matches_tiled_oracle():
+    ref, m = make(TILED, seed=6)
+    x = (torch.rand(1, 3, 9, 64, 112, generator=torch.Generator().manual_seed(4)) * 2 - 1).to(BF).float()
+    ref.enable_tiling(); m.enable_tiling()
+    with torch.no_grad():
+        want = ref.encode(x)
+    dist = m.encode(x.to("cuda:0", BF)).latent_dist
+    assert dist.mean.shape == want.mean.shape == (1, 16, 3, 8, 14)
+    assert rel_l2(dist.parameters, want.parameters) <= 3e-2
+
+
+def test_tiling_leaves_small_inputs_on_the_untiled_path():
+    """A latent that fits one latent tile (<= 6 x 10 here; <= 30 x 45 for the real config) is decoded untiled even with tiling
+    enabled: bit-identical to the run with tiling disabled."""
+    _, m = make(TILED, seed=7)
+    z = torch.randn(1, 16, 3, 6, 10, generator=torch.Generator().manual_seed(1)).to("cuda:0", BF)
+    plain = m.decode(z).sample
+    m.enable_tiling()
+    assert torch.equal(m.decode(z).sample, plain)
+    real = type(m)()                               # default config: 480 x 720 -> tiles of 30 x 45 latent / 240 x 360 px
+    real.enable_tiling()
+    assert (real.tile_latent_min_height, real.tile_latent_min_width, real.tile_sample_min_height, real.tile_sample_min_width) == (30, 45, 240, 360)

@@ -148,3 +148,34 @@ def test_diagonal_gaussian_known_answer():
     g = torch.Generator().manual_seed(3)
     eps = torch.randn(d.mean.shape, generator=torch.Generator().manual_seed(3))
     assert torch.allclose(d.sample(g), d.mean + d.std * eps)
+
+
+def test_tile_geometry_and_blend_known_answers():
+    """Tiling arithmetic of the 480 x 720 VAE config, by hand: sample tile 240 x 360, latent tile 30 x 45, strides
+    int(30 * 5/6) = 25 and int(45 * 4/5) = 36, sample-space blend extents 40 / 72, crop 200 x 288: a 40 x 60 latent is the four
+    tiles (30|15) x (45|24) and reassembles to 320 x 480.  Seam blend: constant tiles a = 1, b = 3 over an extent of 4 give
+    1, 1.5, 2, 2.5 on b's first four rows (weights y / 4), the rest of b untouched; tiles are blended in place in raster order,
+    so the tile BELOW sees the already-blended tile above."""
+    import torch
+    from oracle.vae import AutoencoderKLCogVideoX
+    v = AutoencoderKLCogVideoX(block_out_channels=(8, 8, 8, 8), layers_per_block=1, norm_num_groups=4)
+    v.enable_tiling()
+    assert (v.tile_sample_min_height, v.tile_sample_min_width, v.tile_latent_min_height, v.tile_latent_min_width) == (240, 360, 30, 45)
+    assert [int(30 * (1 - v.tile_overlap_factor_height)), int(45 * (1 - v.tile_overlap_factor_width))] == [25, 36]
+    assert [int(240 * v.tile_overlap_factor_height), int(360 * v.tile_overlap_factor_width)] == [40, 72]
+    seen = []
+
+    def fake_decoder(z, cc):                      # 8 x nearest upsampling stands in for the decoder: records the tile sizes
+        seen.append(tuple(z.shape[-2:]))
+        return z[:, :3].repeat_interleave(8, -2).repeat_interleave(8, -1)
+    z = torch.arange(40 * 60, dtype=torch.float32).reshape(1, 1, 1, 40, 60).expand(1, 16, 1, 40, 60).contiguous()
+    out = v._tiled(fake_decoder, z, 2, 30, 45, 40, 72, 200, 288)
+    assert seen == [(30, 45), (30, 24), (15, 45), (15, 24)] and out.shape == (1, 3, 1, 320, 480)
+    # every tile shows the same underlying image, so blending tiles of it must reproduce it (to fp32 rounding of v (1 - w) + v w)
+    assert torch.allclose(out, z[:, :3].repeat_interleave(8, -2).repeat_interleave(8, -1), rtol=1e-6, atol=0)
+    a, b = torch.ones(1, 1, 1, 6, 2), torch.full((1, 1, 1, 5, 2), 3.0)
+    r = AutoencoderKLCogVideoX.blend_v(a, b, 4)
+    assert r is b and torch.equal(b[0, 0, 0, :, 0], torch.tensor([1.0, 1.5, 2.0, 2.5, 3.0]))
+    a, b = torch.ones(1, 1, 1, 2, 3), torch.full((1, 1, 1, 2, 7), 5.0)
+    AutoencoderKLCogVideoX.blend_h(a, b, 4)        # extent clipped to min(3, 7, 4) = 3: weights 0, 1/3, 2/3
+    assert torch.allclose(b[0, 0, 0, 0], torch.tensor([1.0, 1 + 4 / 3, 1 + 8 / 3, 5.0, 5.0, 5.0, 5.0]))

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <vector>
 #include <random>
+#include <algorithm>
 #include "../include/orv_mi355.h"
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} }while(0)
 static inline uint16_t f2bf(float f){ uint32_t u; memcpy(&u,&f,4); u += 0x7fff + ((u>>16)&1); return (uint16_t)(u>>16);} 
@@ -45,9 +46,30 @@ static void bench(int M,int N,int K,int epi,int iters){
   printf("bench M=%5d N=%5d K=%5d epi=%d: %.3f ms  %.1f TFLOP/s\n",M,N,K,epi,ms,2.0*M*N*K/ms/1e9);
   hipFree(dA);hipFree(dW);hipFree(db);hipFree(dC);hipFree(dg);
 }
+// same-process interleaved A/B of forced tile candidates: ab M N K epi rounds "ring,bm,bn" ["ring,bm,bn" ...]
+static void ab(int M,int N,int K,int epi,int rounds,int nt,char** tiles){
+  auto A=rnd_bf((size_t)M*K,1.f,1), W=rnd_bf((size_t)N*K,0.05f,2), bias=rnd_bf(N,0.5f,3);
+  uint16_t *dA=up(A),*dW=up(W),*db=up(bias); uint16_t *dC,*dR; CK(hipMalloc(&dC,(size_t)M*N*2)); CK(hipMalloc(&dR,(size_t)M*N*2)); CK(hipMemset(dC,0,(size_t)M*N*2)); CK(hipMemset(dR,0,(size_t)M*N*2));
+  int seq=3226; int B=(M+seq-1)/seq; int G=6; std::vector<float> gate((size_t)B*G*N,0.5f); float* dg=up(gate);
+  orv_gemm_t g{}; g.A=dA; g.lda=K; g.W=dW; g.ldw=K; g.bias=db; g.C=dC; g.ldc=N; g.M=M; g.N=N; g.K=K; g.epilogue=epi; g.R=dR; g.ldr=N; g.gate=dg; g.gate_b=(long)G*N; g.gate_g=N; g.grp={seq,226,600};
+  hipEvent_t e0,e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  std::vector<std::vector<double>> tf(nt);
+  const int iters = 2.0*M*N*K > 5e11 ? 8 : 30;
+  for(int r=0;r<rounds;r++) for(int t=0;t<nt;t++){
+    int a,b,c; sscanf(tiles[t],"%d,%d,%d",&a,&b,&c); orv_gemm_force_tile(a,b,c);
+    if(orv_gemm_bf16(&g,nullptr)){ printf("tile %s: %s\n",tiles[t],orv_last_error()); tf[t].push_back(0); continue; }
+    for(int i=0;i<2;i++) orv_gemm_bf16(&g,nullptr);
+    CK(hipEventRecord(e0)); for(int i=0;i<iters;i++) orv_gemm_bf16(&g,nullptr); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms,e0,e1)); ms/=iters;
+    tf[t].push_back(2.0*M*N*K/ms/1e9);
+  }
+  for(int t=0;t<nt;t++){ std::sort(tf[t].begin(),tf[t].end()); printf("ab M=%5d N=%5d K=%5d epi=%d tile %-10s: median %.0f  min %.0f  max %.0f TFLOP/s  (%.4f ms)\n",M,N,K,epi,tiles[t],tf[t][tf[t].size()/2],tf[t].front(),tf[t].back(),2.0*M*N*K/tf[t][tf[t].size()/2]/1e9); }
+  orv_gemm_force_tile(0,0,0);
+  hipFree(dA);hipFree(dW);hipFree(db);hipFree(dC);hipFree(dR);hipFree(dg);
+}
 int main(int argc,char**argv){
   if(orv_device_check(0)){ printf("%s\n",orv_last_error()); return 2; }
   if(argc>=9 && !strcmp(argv[1],"check")){ return check(atoi(argv[2]),atoi(argv[3]),atoi(argv[4]),atoi(argv[5]),atoi(argv[6]),atoi(argv[7]),atoi(argv[8])); }
+  if(argc>=8 && !strcmp(argv[1],"ab")){ ab(atoi(argv[2]),atoi(argv[3]),atoi(argv[4]),atoi(argv[5]),atoi(argv[6]),argc-7,argv+7); return 0; }
   if(argc>=7 && !strcmp(argv[1],"bench")){ bench(atoi(argv[2]),atoi(argv[3]),atoi(argv[4]),atoi(argv[5]),atoi(argv[6])); return 0; }
   int bad=0;
   bad+=check(64,128,128,0,64,8,0); bad+=check(100,192,256,1,50,8,14); bad+=check(300,64,1920,0,300,0,0);

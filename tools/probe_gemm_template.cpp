@@ -194,7 +194,8 @@ static void launch_tpl(const uint16_t* A, const uint16_t* W, uint16_t* C, int M,
     if (g_map == 0) hipLaunchKernelGGL(gemm_tpl_kernel<0>, dim3(tiles_m * tiles_n), dim3(512), 131072, 0, A, W, C, M, N, K, tiles_m, tiles_n);
     else hipLaunchKernelGGL(gemm_tpl_kernel<1>, dim3(tiles_m * tiles_n), dim3(512), 131072, 0, A, W, C, M, N, K, tiles_m, tiles_n);
 }
-static void launch_ph(const uint16_t* A, const uint16_t* W, uint16_t* C, int M, int N, int K) {
+static void launch_ph(const uint16_t* A, const uint16_t* W, uint16_t* C, int M, int N, int K, int ring = 2) {
+    orv_gemm_force_tile(ring, 256, 256);
     orv_gemm_t g{}; g.A = A; g.lda = K; g.W = W; g.ldw = K; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.epilogue = 0;
     if (orv_gemm_bf16(&g, nullptr)) { printf("orv_gemm_bf16: %s\n", orv_last_error()); exit(1); }
 }
@@ -216,7 +217,6 @@ static int check(int M, int N, int K) {
 }
 
 int main(int argc, char** argv) {
-    setenv("ORV_GEMM_TILE", "2,256,256", 1);
     const int rounds = argc > 1 ? atoi(argv[1]) : 5;
     const bool pmc = getenv("TPL_PMC") != nullptr;     // under rocprofv3 --pmc: a handful of launches only
     if (orv_device_check(0)) { printf("%s\n", orv_last_error()); return 2; }
@@ -231,18 +231,18 @@ int main(int argc, char** argv) {
             uint16_t *dA = up(A), *dW = up(W), *dC; CK(hipMalloc(&dC, (size_t)s.M*s.N*2));
             hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
             const int iters = pmc ? 2 : (s.K >= 8192 ? 8 : 30);
-            std::vector<double> tf[3];
+            std::vector<double> tf[4];
             for (int r = 0; r < (pmc ? 1 : rounds); ++r)
-                for (int v = 0; v < 3; ++v) {           // 0 = template (product tile map), 1 = template (guide's map), 2 = gemm_ph_kernel<256,0>
+                for (int v = 0; v < 4; ++v) {           // 0 = template (product tile map), 1 = template (guide's map), 2 = gemm_ph_kernel<256,0>, 3 = gemm_t8_kernel<256,0>
                     g_map = v == 1 ? 1 : 0;
-                    auto go = [&]() { if (v == 2) launch_ph(dA, dW, dC, s.M, s.N, s.K); else launch_tpl(dA, dW, dC, s.M, s.N, s.K); };
+                    auto go = [&]() { if (v >= 2) launch_ph(dA, dW, dC, s.M, s.N, s.K, v); else launch_tpl(dA, dW, dC, s.M, s.N, s.K); };
                     for (int i = 0; i < (pmc ? 0 : 3); ++i) go();
                     CK(hipEventRecord(e0)); for (int i = 0; i < iters; ++i) go(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
                     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
                     tf[v].push_back(2.0 * s.M * s.N * s.K / ms / 1e9);
                 }
-            const char* names[3] = {"template(map=product)", "template(map=guide)  ", "gemm_ph_kernel<256,0>"};
-            for (int v = 0; v < 3; ++v) {
+            const char* names[4] = {"template(map=product)", "template(map=guide)  ", "gemm_ph_kernel<256,0>", "gemm_t8_kernel<256,0>"};
+            for (int v = 0; v < 4; ++v) {
                 std::sort(tf[v].begin(), tf[v].end());
                 printf("%s M=%5d N=%5d K=%5d %s: median %.0f  min %.0f  max %.0f TFLOP/s (%zu rounds)\n", zero ? "zero  " : "random", s.M, s.N, s.K,
                        names[v], tf[v][tf[v].size()/2], tf[v].front(), tf[v].back(), tf[v].size());
