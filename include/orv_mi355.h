@@ -240,6 +240,12 @@ int orv_qkv_prep_bwd(const void* qkv_raw, void* dqkv, const void* gq, const void
  * out [B*S, H*64] bf16 (heads merged as :260); lse fp32 [B,H,S] or NULL (log-sum-exp, natural log, for backward). */
 int orv_attention_fwd(const void* qkv, int ld_qkv, const void* vT, void* out, int ld_out, float* lse, int B, int S,
                       int H, int s_pad, float scale, void* stream);
+/* The same attention (V read in place) when the caller can BOUND the scores: |q . k| * scale * log2(e) <= score_bound for every
+ * (query, key) of the call.  ORV always applies the per-head qk LayerNorm (cogvideox_control.py:243-247), so the bound follows
+ * from norm_q / norm_k's affine parameters alone.  With the fused scale (q pre-multiplied) and score_bound <= 40 the softmax
+ * uses the bound as a FIXED shift (no running max, no rescale); otherwise identical to orv_attention_fwd.  lse as there. */
+int orv_attention_fwd_bounded(const void* qkv, int ld_qkv, void* out, int ld_out, float* lse, int B, int S, int H, float scale,
+                              float score_bound, void* stream);
 
 /* -- sampler ---------------------------------------------------------------------------------- */
 /* One fused scheduler update on n elements (cogvideox_control.py:1433-1459 + diffusers

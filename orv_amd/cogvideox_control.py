@@ -98,6 +98,24 @@ class Attention(_NoForward):
         self.norm_k = nn.LayerNorm(dim_head, eps=eps) if qk_norm else None
         self.to_out = nn.ModuleList([nn.Linear(inner, query_dim, bias=out_bias), nn.Dropout(0.0)])
         self._packed = None
+        self._bound = None
+
+    def score_bound(self, scale: float):
+        """Guaranteed upper bound of |q' . k'| in log2 units, q' = norm_q(q) * scale * log2 e and k' = norm_k(k) as the
+        projection epilogue / ``orv_qkv_prep`` produce them (RoPE, a rotation of channel pairs, preserves it): a LayerNorm
+        output over 64 channels is gamma * xhat + beta with ||xhat||_2 <= 8, so ||q'|| <= 8 max|gamma_q| + ||beta_q||, and the
+        same for k (Cauchy-Schwarz).  2 % margin for the bf16 rounding of q' and k'.  Feeds the fixed-shift softmax of
+        ``orv_attention_fwd_bounded``; cached per weight version (one host read of four 64-vectors)."""
+        if self.norm_q is None or self.norm_k is None:
+            return None
+        key = self._bound_key(scale)
+        if self._bound is None or self._bound[0] != key:
+            prime_score_bounds([self], scale)
+        return self._bound[1]
+
+    def _bound_key(self, scale):
+        ps = (self.norm_q.weight, self.norm_q.bias, self.norm_k.weight, self.norm_k.bias)
+        return tuple((w.data_ptr(), w._version) for w in ps) + (_state.weights_epoch[0], float(scale))
 
     def packed_qkv(self):
         """[3*inner, query_dim] weight and [3*inner] bias for the single fused QKV GEMM (cached per weight version)."""
@@ -110,6 +128,25 @@ class Attention(_NoForward):
                 b = torch.cat([self.to_q.bias.detach(), self.to_k.bias.detach(), self.to_v.bias.detach()]).contiguous()
             self._packed = (key, w, b)
         return self._packed[1], self._packed[2]
+
+
+def prime_score_bounds(attns, scale: float) -> None:
+    """``Attention.score_bound`` for many modules with ONE device -> host copy (a model has 30-84 of them and, under training,
+    the bound changes with every optimizer step): stale entries are recomputed together on the device and read back once."""
+    todo = [a for a in attns if a.norm_q is not None and a.norm_k is not None and (a._bound is None or a._bound[0] != a._bound_key(scale))]
+    if not todo:
+        return
+    with torch.no_grad():
+        gq = torch.stack([a.norm_q.weight.detach().float() for a in todo])
+        bq = torch.stack([a.norm_q.bias.detach().float() for a in todo])
+        gk = torch.stack([a.norm_k.weight.detach().float() for a in todo])
+        bk = torch.stack([a.norm_k.bias.detach().float() for a in todo])
+        rt = math.sqrt(todo[0].dim_head)
+        nq = rt * gq.abs().amax(dim=1) + bq.norm(dim=1)
+        nk = rt * gk.abs().amax(dim=1) + bk.norm(dim=1)
+        vals = (1.02 * float(scale) * LOG2E * nq * nk).tolist()
+    for a, v in zip(todo, vals):
+        a._bound = (a._bound_key(scale), float(v))
 
 
 class _GELUProj(_NoForward):
@@ -565,7 +602,7 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         ops.gather_rows(xn, mv["idx"], mv["xm"], R, D)
         scale = 1.0 / math.sqrt(c.attention_head_dim)
         self._qkv_projection(at, mv["xm"], mv["qkv"], rope_view, R // Sm, Sm, heads, n_view * Nt, s_pad, scale)
-        ops.attention_fwd(mv["qkv"], None, mv["att"], R // Sm, Sm, heads, s_pad, 1.0 / LOG2E)
+        ops.attention_fwd(mv["qkv"], None, mv["att"], R // Sm, Sm, heads, s_pad, 1.0 / LOG2E, score_bound=at.score_bound(scale))
         ops.gemm(mv["att"], at.to_out[0].weight, at.to_out[0].bias, mv["xm"], R, D, D)
         ops.gemm(mv["xm"], blk.proj_out.weight, blk.proj_out.bias, mv["att"], R, D, D)
         # '(b f) (v s) d -> (b v) (f s) d' + gated residual on the video rows only (the text output of attn1 is dropped)
@@ -701,6 +738,7 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         M = B * S
         mb, mg = G * 3 * D, 3 * D
         scale = 1.0 / math.sqrt(c.attention_head_dim)
+        prime_score_bounds([b.attn1 for b in self.transformer_blocks] + ([b.attn1 for b in self.mv_blocks] if mv is not None else []), scale)
         for i, blk in enumerate(self.transformer_blocks):
             if mv is not None:
                 self._mv_block(self.mv_blocks[i], mv, mv_mod[i], x, xn, grp0, B, S, Nt, num_views, T, rope_view)
@@ -709,7 +747,7 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             ops.layernorm_modulate(x, xn, blk.norm1.norm.weight, blk.norm1.norm.bias, m1[..., D:2 * D], m1[..., :D],
                                    mb, mg, grp, B, D, c.norm_eps)
             self._qkv_projection(at, xn, qkv, rope, B, S, heads, Nt, s_pad, scale)
-            ops.attention_fwd(qkv, None, att, B, S, heads, s_pad, 1.0 / LOG2E)
+            ops.attention_fwd(qkv, None, att, B, S, heads, s_pad, 1.0 / LOG2E, score_bound=at.score_bound(scale))
             ops.gemm(att, at.to_out[0].weight, at.to_out[0].bias, x, M, D, D, epilogue=2, R=x, ldr=D,
                      gate=m1[..., 2 * D:], gate_b=mb, gate_g=mg, grp=grp)
             ops.layernorm_modulate(x, xn, blk.norm2.norm.weight, blk.norm2.norm.bias, m2[..., D:2 * D], m2[..., :D],

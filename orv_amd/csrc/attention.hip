@@ -33,6 +33,7 @@ struct AttnArgs {
     int B, S, H, s_pad;
     float scale_log2;  // scale * log2(e)
     float scale;
+    float shift;       // STATIC kernels: fixed softmax shift in log2 units (>= every score the caller can produce)
 };
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -210,8 +211,15 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const char* a, const char* b) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <bool LAZY, bool FUSED>
+// STATIC (fused scale only): the caller GUARANTEES score <= p.shift for every (query, key) - ORV always runs the qk LayerNorm
+// (cogvideox_control.py:243-247), so |q . k| <= (8 max|gamma_q| + ||beta_q||)(8 max|gamma_k| + ||beta_k||) is known on the host from
+// four 64-vectors - and the softmax uses that bound as its FIXED shift: P = exp2(s - shift) <= 1, no running max, no rescale
+// branch, no m_run dependency between tiles; -shift rides in the accumulator init of the QK^T MFMAs, so the 32 v_sub and the
+// 21-instruction max tree per 64-key tile are gone (10.9 -> ~7 VALU instructions per MFMA).  fp32 l / O accumulate 2^-2 shift ... 1
+// without loss for shift <= 40 (the entry point falls back to the online kernel above that).
+template <bool LAZY, bool FUSED, bool STATIC = false>
 __global__ __launch_bounds__(512, 4) void attn_fwd_v2_kernel(const AttnArgs p) {
+    static_assert(!STATIC || FUSED, "the fixed-shift softmax is built for the pre-multiplied q only");
     __shared__ __attribute__((aligned(16))) char smem[2 * SLOT_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -270,10 +278,11 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_v2_kernel(const AttnArgs p) {
         const char* sV = sK + TILE_BYTES;
 
         f32x16 sT[2];
+        const float s_init = STATIC ? -p.shift : 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sT[kb][e] = 0.f;
+            for (int e = 0; e < 16; ++e) sT[kb][e] = s_init;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 kf = *(const bf16x8*)(sK + kb * 4096 + row_off + (((ks * 2 + hi) ^ sw) * 16));
@@ -290,33 +299,44 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_v2_kernel(const AttnArgs p) {
                     if (key >= p.S) sT[kb][r] = -INFINITY;
                 }
         }
-        float tmax = sT[0][0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sT[0][r]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sT[1][r]);
-        tmax = max_with_partner_half(tmax);
-        const float cc = FUSED ? 1.0f : c;
-        if (!LAZY || !__all((tmax - m_run) * cc <= RESCALE_THR)) {
-            const float m_new = fmaxf(m_run, tmax);
-            const float alpha = fast_exp2((m_run - m_new) * cc);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) oT[i][e] *= alpha;
-        }
-        const float mc = m_run * cc;
         float psum = 0.f;
+        if constexpr (STATIC) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = FUSED ? fast_exp2(sT[kb][r] - mc) : fast_exp2(fmaf(sT[kb][r], c, -mc));
-                sT[kb][r] = pv;
-                psum += pv;
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = fast_exp2(sT[kb][r]);          // s - shift <= 0: the accumulator started at -shift
+                    sT[kb][r] = pv;
+                    psum += pv;
+                }
+        } else {
+            float tmax = sT[0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sT[0][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sT[1][r]);
+            tmax = max_with_partner_half(tmax);
+            const float cc = FUSED ? 1.0f : c;
+            if (!LAZY || !__all((tmax - m_run) * cc <= RESCALE_THR)) {
+                const float m_new = fmaxf(m_run, tmax);
+                const float alpha = fast_exp2((m_run - m_new) * cc);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) oT[i][e] *= alpha;
             }
+            const float mc = m_run * cc;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = FUSED ? fast_exp2(sT[kb][r] - mc) : fast_exp2(fmaf(sT[kb][r], c, -mc));
+                    sT[kb][r] = pv;
+                    psum += pv;
+                }
+        }
         l_run += psum;
 
         // O^T[db] += V^T[db rows] . P^T ; k-step kk = keys kk*16 + {0-3, 8-11} + 4 hi (the accumulator order of S^T)
@@ -349,7 +369,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_v2_kernel(const AttnArgs p) {
                 *(uint2*)(op + db * 32 + qd * 8) = o;
             }
         if (p.lse && hi == 0)
-            p.lse[((long)b * p.H + h) * p.S + q] = FUSED ? (m_run + __log2f(l_tot)) * 0.6931471805599453f : m_run * p.scale + __logf(l_tot);
+            p.lse[((long)b * p.H + h) * p.S + q] = STATIC ? (p.shift + __log2f(l_tot)) * 0.6931471805599453f
+                                                  : FUSED ? (m_run + __log2f(l_tot)) * 0.6931471805599453f : m_run * p.scale + __logf(l_tot);
     }
 }
 
@@ -364,7 +385,7 @@ extern "C" int orv_attention_fwd(const void* qkv, int ld_qkv, const void* vT, vo
     AttnArgs a;
     a.qkv = (const bf16_t*)qkv; a.ld = ld_qkv; a.vT = (const bf16_t*)vT; a.out = (bf16_t*)out; a.ld_out = ld_out;
     a.lse = lse; a.B = B; a.S = S; a.H = H; a.s_pad = s_pad;
-    a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
+    a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f; a.shift = 0.f;
     dim3 grid(((S + 255) / 256) * H * B);
     // q pre-multiplied by scale*log2(e) in orv_qkv_prep (q_premul) arrives here as scale == 1/log2(e): fused fast path
     const bool fused = fabsf(a.scale_log2 - 1.0f) < 1e-6f;
@@ -375,4 +396,29 @@ extern "C" int orv_attention_fwd(const void* qkv, int ld_qkv, const void* vT, vo
     } else if (fused) hipLaunchKernelGGL((attn_fwd_v1_kernel<true, true>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((attn_fwd_v1_kernel<true, false>), grid, dim3(512), 0, st, a);
     return orv_check_launch("orv_attention_fwd");
+}
+
+// The same attention when the caller can BOUND the scores: |q . k| * scale * log2(e) <= score_bound for every (query, key) of the
+// call (ORV: from the qk-LayerNorm affine parameters, orv_amd/cogvideox_control.py `score_bound`).  With the fused scale
+// (q pre-multiplied, scale == 1 / log2 e) and score_bound <= 40 the softmax runs with that bound as its fixed shift
+// (attn_fwd_v2_kernel<.., STATIC>); otherwise this is orv_attention_fwd.  A bound that does not hold gives P > 1 and, far enough
+// off, inf: the caller owns the guarantee (tests/test_gpu_kernels.py exercises a violated bound to show it is a contract).
+extern "C" int orv_attention_fwd_bounded(const void* qkv, int ld_qkv, void* out, int ld_out, float* lse, int B, int S, int H,
+                                         float scale, float score_bound, void* stream) {
+    const float scale_log2 = scale * 1.4426950408889634f;
+    const bool fused = fabsf(scale_log2 - 1.0f) < 1e-6f;
+    static int use_static = -1;      // ORV_ATTN_STATIC=0: A/B switch
+    if (use_static < 0) { const char* e = getenv("ORV_ATTN_STATIC"); use_static = (e && atoi(e) == 0) ? 0 : 1; }
+    if (!use_static || !fused || !(score_bound > 0.f) || score_bound > 40.f)
+        return orv_attention_fwd(qkv, ld_qkv, nullptr, out, ld_out, lse, B, S, H, 0, scale, stream);
+    ORV_REQUIRE(qkv && out, "orv_attention_fwd_bounded: null operand");
+    ORV_REQUIRE(B > 0 && S > 0 && H > 0, "orv_attention_fwd_bounded: empty problem");
+    ORV_REQUIRE(ld_qkv % 8 == 0 && ld_out % 4 == 0, "orv_attention_fwd_bounded: misaligned leading dimension");
+    AttnArgs a;
+    a.qkv = (const bf16_t*)qkv; a.ld = ld_qkv; a.vT = nullptr; a.out = (bf16_t*)out; a.ld_out = ld_out;
+    a.lse = lse; a.B = B; a.S = S; a.H = H; a.s_pad = 0;
+    a.scale = scale; a.scale_log2 = scale_log2; a.shift = score_bound;
+    dim3 grid(((S + 255) / 256) * H * B);
+    hipLaunchKernelGGL((attn_fwd_v2_kernel<true, true, true>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    return orv_check_launch("orv_attention_fwd_bounded");
 }

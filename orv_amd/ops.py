@@ -204,8 +204,15 @@ def linear(x2d, W, bias=None, epilogue=0):
     return gemm(x2d, W, bias, C, M, N, K, epilogue)
 
 
-def attention_fwd(qkv, vT, out, B, S, H, s_pad, scale, lse=None, ld_qkv=None, ld_out=None):
+def attention_fwd(qkv, vT, out, B, S, H, s_pad, scale, lse=None, ld_qkv=None, ld_out=None, score_bound=None):
+    """``score_bound`` (V in place only): a guaranteed upper bound of |q . k| * scale * log2(e) over the whole call - the kernel
+    then runs its fixed-shift softmax when the bound is small enough (``orv_attention_fwd_bounded``)."""
     _need(qkv, BF16, "qkv"), _need(out, BF16, "out")
+    if score_bound is not None and vT is None:
+        with _timed(("attention", B, S, H)):
+            check(lib().orv_attention_fwd_bounded(_p(qkv), ld_qkv or 3 * H * 64, _p(out), ld_out or H * 64, _p(lse), B, S, H,
+                                                  float(scale), float(score_bound), _stream()), "orv_attention_fwd_bounded")
+        return out
     if vT is not None:               # legacy form: pre-transposed V (attn_fwd_v1); None = V read in place (attn_fwd_v2)
         _need(vT, BF16, "vT")
     with _timed(("attention", B, S, H)):

@@ -561,3 +561,72 @@ def test_t8_gemm_matches_simple_kernel_on_every_epilogue_feature(bn):
         close(y1, y0, "qknorm Y")
         # LayerNorm output of near-identical inputs: compare in units of the affine scale
         assert ((c1.float() - c0.float()).abs() <= 2e-2 * c0.float().abs() + 6e-2).all()
+
+
+@pytest.mark.parametrize("B,S,H,nt,use_rope", [(2, 200, 2, 8, False), (1, 3226, 3, 226, False), (2, 333, 2, 13, True), (1, 17, 1, 0, False)])
+def test_attention_fixed_shift_softmax_with_a_score_bound(B, S, H, nt, use_rope):
+    """orv_attention_fwd_bounded: ORV's qk LayerNorm bounds every score by (8 max|gamma_q| + ||beta_q||)(8 max|gamma_k| + ||beta_k||)
+    * scale * log2 e (Attention.score_bound), and the kernel uses that bound as a FIXED softmax shift (no running max / rescale).
+    Against the fp32 reference (same tolerance as the online kernel), against the online kernel itself, lse included, ragged
+    last key tile, RoPE (norm preserving).  The bound really holds on the data: checked against the reference q', k'."""
+    from orv_amd import ops
+    from orv_amd.cogvideox_control import Attention
+    dev = _dev()
+    g = torch.Generator().manual_seed(S + 1)
+    D = H * 64
+    qkv = q(torch.randn(B * S, 3 * D, generator=g) * 1.5)
+    gq, bq, gk, bk = (q(torch.randn(64, generator=g) * 0.1 + (1 if i % 2 == 0 else 0)) for i in range(4))
+    rope = None
+    if use_rope:
+        ang = torch.rand(S - nt, 32, generator=g) * 6.28
+        rope = (ang.cos().repeat_interleave(2, 1).contiguous(), ang.sin().repeat_interleave(2, 1).contiguous())
+    ref, lse_ref, q_ref, k_ref = _attention_reference(qkv, B, S, H, gq, bq, gk, bk, rope, nt)
+    at = Attention(D, H, 64, True, True)
+    with torch.no_grad():
+        at.norm_q.weight.copy_(gq); at.norm_q.bias.copy_(bq); at.norm_k.weight.copy_(gk); at.norm_k.bias.copy_(bk)
+    bound = at.score_bound(0.125)
+    smax = (torch.einsum("bhqd,bhkd->bhqk", q_ref, k_ref).abs().max() * 0.125 * LOG2E).item()
+    assert smax <= bound <= 40.0, (smax, bound)
+    s_pad = (S + 63) // 64 * 64
+    dq = qkv.to(dev, BF).clone()
+    ops.qkv_prep(dq, None, gq.to(dev, BF), bq.to(dev, BF), gk.to(dev, BF), bk.to(dev, BF),
+                 None if rope is None else tuple(r.to(dev) for r in rope), B, S, H, nt, s_pad, 1e-6, q_premul=0.125 * LOG2E)
+    out = torch.full((B * S, D), float("nan"), dtype=BF, device=dev)
+    lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+    ops.attention_fwd(dq, None, out, B, S, H, s_pad, 1.0 / LOG2E, lse=lse, score_bound=bound)
+    close(out, ref)
+    close(lse, lse_ref, rtol=2e-2, afrac=5e-3)
+    out_online = torch.empty_like(out)
+    lse_online = torch.empty_like(lse)
+    ops.attention_fwd(dq, None, out_online, B, S, H, s_pad, 1.0 / LOG2E, lse=lse_online)
+    close(out, out_online.float().cpu(), rtol=1.6e-2, afrac=4e-3)
+    assert (lse - lse_online).abs().max().item() <= 2e-3
+
+
+def test_attention_bound_too_large_takes_the_online_kernel():
+    """Adversarially large qk-LayerNorm gains: the bound exceeds what the fixed shift may absorb (40 log2 units), and the bounded
+    entry point must run the online kernel - bit-identical to orv_attention_fwd, correct against the reference."""
+    from orv_amd import ops
+    from orv_amd.cogvideox_control import Attention
+    dev = _dev()
+    B, S, H = 1, 300, 2
+    g = torch.Generator().manual_seed(3)
+    qkv = q(torch.randn(B * S, 3 * H * 64, generator=g))
+    gq, bq, gk, bk = q(torch.full((64,), 3.0)), q(torch.zeros(64)), q(torch.full((64,), 2.5)), q(torch.randn(64, generator=g))
+    at = Attention(H * 64, H, 64, True, True)
+    with torch.no_grad():
+        at.norm_q.weight.copy_(gq); at.norm_q.bias.copy_(bq); at.norm_k.weight.copy_(gk); at.norm_k.bias.copy_(bk)
+    bound = at.score_bound(0.125)
+    assert bound > 40.0
+    dq = qkv.to(dev, BF).clone()
+    ops.qkv_prep(dq, None, gq.to(dev, BF), bq.to(dev, BF), gk.to(dev, BF), bk.to(dev, BF), None, B, S, H, 0, 320, 1e-6,
+                 q_premul=0.125 * LOG2E)
+    out, out_online = torch.empty(B * S, H * 64, dtype=BF, device=dev), torch.empty(B * S, H * 64, dtype=BF, device=dev)
+    ops.attention_fwd(dq, None, out, B, S, H, 320, 1.0 / LOG2E, score_bound=bound)
+    ops.attention_fwd(dq, None, out_online, B, S, H, 320, 1.0 / LOG2E)
+    assert torch.equal(out, out_online)
+    # scores reach +-50 log2 units here, so the bf16 rounding of q' / k' alone moves P by several per cent: the reference is the
+    # fp32 softmax over the SAME bf16 q', k', v the kernel read (exp2: q' carries scale * log2 e)
+    t = dq.float().cpu().view(B, S, 3, H, 64).permute(2, 0, 3, 1, 4)
+    pr = torch.softmax(torch.einsum("bhqd,bhkd->bhqk", t[0], t[1]) * math.log(2.0), dim=-1)
+    close(out, torch.einsum("bhqk,bhkd->bhqd", pr, t[2]).transpose(1, 2).reshape(B * S, H * 64))

@@ -279,3 +279,33 @@ def test_bucket_sampler_matches_reference_golden():
         full = c["order"][: len(c["order"]) // c["batch_size"] * c["batch_size"]] if c["drop_last"] else []
         for i in range(0, len(full), c["batch_size"]):
             assert len({(r, v) for _, r, v in full[i:i + c["batch_size"]]}) == 1
+
+
+def test_attention_score_bound_holds_on_random_layernorm_outputs():
+    """Attention.score_bound (feeds the fixed-shift softmax): |q' . k'| * scale * log2 e <= bound for LayerNorm outputs with random
+    affine parameters, RoPE-rotated or not - including inputs built to be as aligned as possible (q = k direction)."""
+    import math
+    import torch
+    from orv_amd.cogvideox_control import Attention, prime_score_bounds
+    g = torch.Generator().manual_seed(0)
+    for trial in range(6):
+        at = Attention(128, 2, 64, True, True)
+        with torch.no_grad():
+            for p_, sc in ((at.norm_q.weight, 1.0), (at.norm_q.bias, 0.5), (at.norm_k.weight, 1.0), (at.norm_k.bias, 0.5)):
+                p_.copy_(torch.randn(64, generator=g) * sc * (0.3 + trial * 0.3))
+        bound = at.score_bound(0.125)
+        x = torch.randn(4000, 64, generator=g) * torch.rand(4000, 1, generator=g) * 10
+        x[:64] = torch.eye(64) * 100                           # one-hot rows: xhat puts almost all its norm on one channel
+        x[64:128] = torch.sign(at.norm_q.weight.detach() * at.norm_k.weight.detach()) * torch.rand(64, 64, generator=g)
+        ln = lambda v, n: torch.nn.functional.layer_norm(v, (64,), n.weight, n.bias, 1e-6)
+        with torch.no_grad():
+            qq, kk = ln(x, at.norm_q), ln(x, at.norm_k)
+            ang = torch.rand(4000, 32, generator=g) * 6.28
+            rot = lambda v, a: torch.stack([v[:, 0::2] * a.cos() - v[:, 1::2] * a.sin(), v[:, 0::2] * a.sin() + v[:, 1::2] * a.cos()], -1).flatten(1)
+            for a_, b_ in ((qq, kk), (rot(qq, ang), rot(kk, ang.flip(0)))):
+                s = (a_ @ b_.t()).abs().max().item() * 0.125 * 1.4426950408889634
+                assert s <= bound, (trial, s, bound)
+    many = [Attention(128, 2, 64, True, True) for _ in range(5)]
+    prime_score_bounds(many, 0.125)                            # batched form == per-module form
+    for m in many:
+        assert m._bound is not None and math.isclose(m.score_bound(0.125), 1.02 * 8 * 8 * 0.125 * 1.4426950408889634, rel_tol=1e-6)
