@@ -374,6 +374,322 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_v2_kernel(const AttnArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// v3 "ping-pong" (fused scale only; V in place): the two waves of every SIMD are kept HALF A TILE out of phase by the barrier
+// sequence - while one is in its matrix segment X_t = { PV of tile t-1 ; QK^T of tile t } (16 MFMAs, 8 ds_read_b128, 16 transposing
+// reads, no VALU) its partner is in its vector segment Y_t = { exp2, row sum, bf16 pack of tile t } (no MFMA), and vice versa.
+// With one s_barrier per segment the workgroup's second half (waves 4-7, the second wave of every SIMD) runs one barrier behind
+// the first, so on each SIMD the matrix pipe (512 cycles per tile and wave) and the VALU issue port (~90 instructions per tile and
+// wave at head_dim 64) are used by different waves at the same time instead of both waves hitting the same pipe right after a
+// common barrier (PMC of v2: MFMA busy 0.40-0.45 although neither pipe is saturated).  Registers stay within 128: S_t lives
+// X_t -> Y_t, the packed P_t lives Y_t -> X_{t+1}, no second score set - two workgroups per CU as before.
+//   * DMA roles: waves 0-3 stage the K tiles (K_{t+1} issued in their X_t behind the transposing reads, waited at the end of
+//     Y_t), waves 4-7 the V tiles (V_{t+1} issued in their Y_t, waited at the end of their X_{t+1}).  Two 8-KiB slots per operand
+//     (32 KiB: unchanged).
+//   * STATIC (the caller bounds |score| by <= 40 log2 units, see orv_attention_fwd_bounded): P = exp2(s) with NO shift at all - P <=
+//     2^40, l <= S 2^40, O <= l max|v| are far inside fp32 / bf16 range and a common factor cancels in O / l; otherwise the online
+//     softmax with the lazy rescale, taken in Y_t between PV_{t-1} and PV_t, i.e. with every pending product already in O (cdna
+//     guide T13 ordering).
+//   * epilogue: O rows leave as 16-byte pieces (two 8-byte column groups exchanged between lane and lane ^ 32, guide T21).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int PP_SLOTS = 2;        // K / V tiles resident per operand (tile t in slot t % 2, staged one tile ahead).  Measured and
+// dropped: three slots with the tiles staged TWO ahead from inline-asm LDS-DMA (so that hipcc's vmcnt(0) in front of every
+// ds_read_b64_tr_b16 that follows a DMA builtin cannot drain the stream) and counted vmcnt(2) waits - 0.365-0.373 ms against
+// 0.344-0.349 ms standalone, 0.3395 against 0.3275 ms in the model (profiles/r3_attention_pingpong.txt): the loop does not wait
+// for the DMA, and the third slot pair costs more than it hides.
+template <bool STATIC>
+__global__ __launch_bounds__(512, 4) void attn_fwd_pp_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * PP_SLOTS * TILE_BYTES];   // K slots | V slots
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wq = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
+    const int nqt = (p.S + 255) / 256;
+    const int item = orv_xcd_item(blockIdx.x, gridDim.x);
+    const int bh = item / nqt, h = bh % p.H, b = bh / p.H;
+    const int q0 = (item % nqt) * 256 + wave * 32;
+    const int D = p.H * 64;
+    const long row0 = (long)b * p.S;
+    const bool active = q0 < p.S;          // a wave whose 32 query rows all lie past S only stages tiles and meets the barriers
+
+    bf16x8 qf[4];
+    {
+        const int qr = min(q0 + l31, p.S - 1);
+        const bf16_t* qp = p.qkv + (row0 + qr) * p.ld + h * 64 + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+    }
+
+    // ---- staging: the four waves of a half move one operand's 64-row tile, wave wq rows 16 wq .. 16 wq + 15 (two pieces) ----
+    // this lane's source line of piece j in tile t: key row t * KV + 16 wq + 8 j + lane / 8 (clamped to S - 1: keys past S read a
+    // valid row, their P is forced to 0), 16-byte chunk = slot ^ swizzle(row)
+    auto src_of = [&](int j, int t) {
+        const int sr = wq * 16 + j * 8 + (lane >> 3), slot = lane & 7;
+        const int chunk = grp == 0 ? (slot ^ ((sr >> 1) & 7))                      // K: conflict-free image for ds_read_b128
+                                   : (slot ^ (((sr >> 1) & 1) << 2));              // V: 64-byte halves swapped when (key >> 1) & 1
+        return p.qkv + (row0 + min(t * KV + sr, p.S - 1)) * p.ld + (grp == 0 ? D : 2 * D) + h * 64 + chunk * 8;
+    };
+    const bf16_t* const sbase0 = src_of(0, 0);
+    const bf16_t* const sbase1 = src_of(1, 0);
+    char* const sdst = smem + grp * PP_SLOTS * TILE_BYTES + wq * 2048;
+    const int nt = (p.S + KV - 1) / KV;
+    const bool ragged = (p.S & (KV - 1)) != 0;
+    // this half's operand tile t -> slot t % 2.  The tile offset is wave-uniform (scalar unit): per tile and piece one 64-bit
+    // vector add instead of a 64-bit multiply + clamp (that address arithmetic was ~20 % of the kernel's VALU instructions); only
+    // the ragged last tile recomputes its clamped addresses (nothing but the two tile-0 pointers stays live across the loop).
+    auto stage = [&](int t) {
+        char* const d = sdst + (t % PP_SLOTS) * TILE_BYTES;
+        if (__builtin_expect(ragged && t == nt - 1, 0)) {
+            glds16(src_of(0, t), d);
+            glds16(src_of(1, t), d + 1024);
+        } else {
+            const long toff = (long)t * KV * p.ld;
+            glds16(sbase0 + toff, d);
+            glds16(sbase1 + toff, d + 1024);
+        }
+    };
+
+    f32x16 oT[2], sT[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { oT[i][e] = 0.f; sT[i][e] = 0.f; }
+    union { bf16x8 v; uint32_t u[4]; } pf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pf[i].u[e] = 0u;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int row_off = l31 * 128;
+    const int r16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int v_row = (4 * hi + (r16 >> 2)) * 128 + g16 * 32 + (r16 & 3) * 8;
+    const int v_off0 = v_row + ((r16 >> 3) << 6);
+    const int v_off1 = v_row + ((1 - (r16 >> 3)) << 6);
+#define PP_BAR()                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    __builtin_amdgcn_s_barrier();                                                                 \
+    __builtin_amdgcn_sched_barrier(0);
+    // matrix segment: PV of tile t - 1 (t > 0), then QK^T of tile t (t < nt).  Fragment reads run two MFMA pairs ahead of their
+    // use and the order is pinned (left alone, hipcc puts every ds_read right in front of its MFMA and waits lgkmcnt(0) each time:
+    // ~100 exposed cycles per MFMA in a segment whose SIMD partner is busy on the VALU and cannot fill the pipe).  While PV runs the
+    // score registers are dead (32 free for V^T fragments), while QK^T runs P is (16 free for K fragments): peak stays under 128.
+#define PP_FENCE() __builtin_amdgcn_sched_barrier(0);
+    auto seg_x = [&](int t, auto stage_k) {
+#ifndef ORV_PP_NOPRIO
+        __builtin_amdgcn_s_setprio(1);      // matrix segment first on the SIMD (+1-3 %, same-process A/B)
+#endif
+        const char* sK = smem + (t % PP_SLOTS) * TILE_BYTES + row_off;
+        auto kread = [&](int kb, int ks) { return *(const bf16x8*)(sK + kb * 4096 + (((ks * 2 + hi) ^ sw) * 16)); };
+        bf16x8 k0, k1, k2, k3;
+        if (t > 0) {
+            const char* sV = smem + PP_SLOTS * TILE_BYTES + ((t - 1) % PP_SLOTS) * TILE_BYTES;
+            bf16x8 va0 = tr_read_pair(sV + v_off0, sV + 8 * 128 + v_off0), va1 = tr_read_pair(sV + v_off1, sV + 8 * 128 + v_off1);
+            bf16x8 vb0 = tr_read_pair(sV + 2048 + v_off0, sV + 2048 + 8 * 128 + v_off0), vb1 = tr_read_pair(sV + 2048 + v_off1, sV + 2048 + 8 * 128 + v_off1);
+            PP_FENCE()
+            oT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0, pf[0].v, oT[0], 0, 0, 0);
+            oT[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1, pf[0].v, oT[1], 0, 0, 0);
+            PP_FENCE()
+            va0 = tr_read_pair(sV + 4096 + v_off0, sV + 4096 + 8 * 128 + v_off0); va1 = tr_read_pair(sV + 4096 + v_off1, sV + 4096 + 8 * 128 + v_off1);
+            PP_FENCE()
+            oT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb0, pf[1].v, oT[0], 0, 0, 0);
+            oT[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb1, pf[1].v, oT[1], 0, 0, 0);
+            PP_FENCE()
+            vb0 = tr_read_pair(sV + 6144 + v_off0, sV + 6144 + 8 * 128 + v_off0); vb1 = tr_read_pair(sV + 6144 + v_off1, sV + 6144 + 8 * 128 + v_off1);
+            PP_FENCE()
+            // the DMA issue sits BEHIND the last transposing read: hipcc puts s_waitcnt vmcnt(0) in front of every ds_read_b64_tr_b16
+            // that follows an LDS-DMA in program order (the builtin carries no memory operand it could disambiguate), plain
+            // ds_read_b128 are left alone - so issued here the only such wait is next segment's, long after the data landed
+            stage_k();
+            PP_FENCE()
+            if (t < nt) { k0 = kread(0, 0); k1 = kread(0, 1); }
+            PP_FENCE()
+            oT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0, pf[2].v, oT[0], 0, 0, 0);
+            oT[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1, pf[2].v, oT[1], 0, 0, 0);
+            PP_FENCE()
+            if (t < nt) { k2 = kread(0, 2); k3 = kread(0, 3); }
+            PP_FENCE()
+            oT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb0, pf[3].v, oT[0], 0, 0, 0);
+            oT[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb1, pf[3].v, oT[1], 0, 0, 0);
+            PP_FENCE()
+        } else {
+            stage_k();
+            PP_FENCE()
+            k0 = kread(0, 0); k1 = kread(0, 1); k2 = kread(0, 2); k3 = kread(0, 3);
+            PP_FENCE()
+        }
+        if (t < nt) {
+            f32x16 z;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) z[e] = 0.f;
+            sT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0], z, 0, 0, 0);
+            sT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[1], sT[0], 0, 0, 0);
+            PP_FENCE()
+            k0 = kread(1, 0); k1 = kread(1, 1);
+            PP_FENCE()
+            sT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, qf[2], sT[0], 0, 0, 0);
+            sT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k3, qf[3], sT[0], 0, 0, 0);
+            PP_FENCE()
+            k2 = kread(1, 2); k3 = kread(1, 3);
+            PP_FENCE()
+            sT[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0], z, 0, 0, 0);
+            sT[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[1], sT[1], 0, 0, 0);
+            sT[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, qf[2], sT[1], 0, 0, 0);
+            sT[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k3, qf[3], sT[1], 0, 0, 0);
+            PP_FENCE()
+        }
+#ifndef ORV_PP_NOPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    };
+    // vector segment: softmax of tile t -> packed P_t
+    auto seg_y = [&](int t) {
+        if (t == nt - 1 && (p.S & (KV - 1)) != 0) {
+            const int kv0 = t * KV;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= p.S) sT[kb][r] = -INFINITY;
+                }
+        }
+        float psum = 0.f;
+        if constexpr (STATIC) {
+#ifdef ORV_PP_PSUM4
+            float ps4[4] = {0.f, 0.f, 0.f, 0.f};      // four independent chains instead of one 32-deep dependent add chain
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = fast_exp2(sT[kb][r]);
+                    sT[kb][r] = pv;
+                    ps4[r & 3] += pv;
+                }
+            psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+#else
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = fast_exp2(sT[kb][r]);
+                    sT[kb][r] = pv;
+                    psum += pv;
+                }
+#endif
+        } else {
+            float tmax = sT[0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sT[0][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sT[1][r]);
+            tmax = max_with_partner_half(tmax);
+            if (!__all(tmax - m_run <= RESCALE_THR)) {
+                const float m_new = fmaxf(m_run, tmax);
+                const float alpha = fast_exp2(m_run - m_new);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) oT[i][e] *= alpha;
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = fast_exp2(sT[kb][r] - m_run);
+                    sT[kb][r] = pv;
+                    psum += pv;
+                }
+        }
+        l_run += psum;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int kb = kk >> 1, r0 = (kk & 1) * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pf[kk].u[i] = pack2bf(sT[kb][r0 + 2 * i], sT[kb][r0 + 2 * i + 1]);
+        }
+    };
+
+    // prologue: K_0 (first half) and V_0 (second half) land before anybody reads.
+    // Schedule (I_n = the n-th barrier interval; first half: X_t in I_2t, Y_t in I_2t+1; second half one interval later):
+    //   K_{t+1}: first half, in its X_t (I_2t, behind the transposing reads), into the slot of K_{t-1} (last read in I_2t-1);
+    //            waited at the end of Y_t, read from I_2t+2
+    //   V_{t+1}: second half, in its Y_t (I_2t+2), into the slot of V_{t-1} (last read by PV_{t-1} in I_2t+1); waited at the end of
+    //            its X_{t+1} (I_2t+3), read from I_2t+4
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_BAR()
+    const bool act = __builtin_amdgcn_readfirstlane((int)active) != 0;       // provably wave-uniform: real branches, no exec masking
+    if (grp == 0) {
+        if (act) {
+            for (int t = 0; t < nt; ++t) {
+                seg_x(t, [&]() { if (t + 1 < nt) stage(t + 1); });
+                PP_BAR()
+                seg_y(t);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K_{t+1} landed (this wave's pieces); visible after the barrier
+                PP_BAR()
+            }
+            seg_x(nt, [&]() {});
+        } else {
+            for (int t = 0; t < nt; ++t) {
+                if (t + 1 < nt) stage(t + 1);
+                PP_BAR()
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PP_BAR()
+            }
+        }
+        PP_BAR()                                            // the second half runs one barrier behind
+    } else {
+        PP_BAR()
+        if (act) {
+            for (int t = 0; t < nt; ++t) {
+                seg_x(t, [&]() {});
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // V_t landed (issued in Y_{t-1} / the prologue)
+                PP_BAR()
+                if (t + 1 < nt) stage(t + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                seg_y(t);
+                PP_BAR()
+            }
+            seg_x(nt, [&]() {});
+        } else {
+            for (int t = 0; t < nt; ++t) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PP_BAR()
+                if (t + 1 < nt) stage(t + 1);
+                PP_BAR()
+            }
+        }
+    }
+#undef PP_BAR
+#undef PP_FENCE
+
+    const float l_tot = sum_with_partner_half(l_run);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + l31;
+    if (q < p.S) {
+        // lane holds d = 32 db + 8 qd + 4 hi + (0..3) of row q: groups qd = 2 u (lower half-wave) and 2 u + 1 (upper) are exchanged
+        // so that every lane stores ONE aligned 16-byte piece: lower -> d 32 db + 16 u + 0..7, upper -> + 8..15
+        bf16_t* op = p.out + (row0 + q) * p.ld_out + h * 64 + hi * 8;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                uint32_t a0 = pack2bf(oT[db][(2 * u) * 4 + 0] * inv, oT[db][(2 * u) * 4 + 1] * inv);
+                uint32_t a1 = pack2bf(oT[db][(2 * u) * 4 + 2] * inv, oT[db][(2 * u) * 4 + 3] * inv);
+                uint32_t b0 = pack2bf(oT[db][(2 * u + 1) * 4 + 0] * inv, oT[db][(2 * u + 1) * 4 + 1] * inv);
+                uint32_t b1 = pack2bf(oT[db][(2 * u + 1) * 4 + 2] * inv, oT[db][(2 * u + 1) * 4 + 3] * inv);
+                // a of the upper half-wave <-> b of the lower half-wave
+                { const auto r = __builtin_amdgcn_permlane32_swap(a0, b0, false, false); a0 = r[0]; b0 = r[1]; }
+                { const auto r = __builtin_amdgcn_permlane32_swap(a1, b1, false, false); a1 = r[0]; b1 = r[1]; }
+                *(uint4*)(op + db * 32 + u * 16) = make_uint4(a0, a1, b0, b1);
+            }
+        if (p.lse && hi == 0)
+            p.lse[((long)b * p.H + h) * p.S + q] = (STATIC ? __log2f(l_tot) : m_run + __log2f(l_tot)) * 0.6931471805599453f;
+    }
+}
+
 }  // namespace
 
 extern "C" int orv_attention_fwd(const void* qkv, int ld_qkv, const void* vT, void* out, int ld_out, float* lse, int B,
@@ -390,8 +706,12 @@ extern "C" int orv_attention_fwd(const void* qkv, int ld_qkv, const void* vT, vo
     // q pre-multiplied by scale*log2(e) in orv_qkv_prep (q_premul) arrives here as scale == 1/log2(e): fused fast path
     const bool fused = fabsf(a.scale_log2 - 1.0f) < 1e-6f;
     hipStream_t st = (hipStream_t)stream;
+    static int use_pp = -1;          // ORV_ATTN_PP=0: A/B switch (v2 instead of the ping-pong kernel)
+    if (use_pp < 0) { const char* e = getenv("ORV_ATTN_PP"); use_pp = (e && atoi(e) == 0) ? 0 : 1; }
     if (!vT) {                       // V read in place from the packed projection (transposing LDS reads): the shipped path
-        if (fused) hipLaunchKernelGGL((attn_fwd_v2_kernel<true, true>), grid, dim3(512), 0, st, a);
+        if (fused && use_pp && ld_out % 8 == 0 && ((uintptr_t)out & 15) == 0)
+            hipLaunchKernelGGL((attn_fwd_pp_kernel<false>), grid, dim3(512), 0, st, a);
+        else if (fused) hipLaunchKernelGGL((attn_fwd_v2_kernel<true, true>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((attn_fwd_v2_kernel<true, false>), grid, dim3(512), 0, st, a);
     } else if (fused) hipLaunchKernelGGL((attn_fwd_v1_kernel<true, true>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((attn_fwd_v1_kernel<true, false>), grid, dim3(512), 0, st, a);
@@ -419,6 +739,11 @@ extern "C" int orv_attention_fwd_bounded(const void* qkv, int ld_qkv, void* out,
     a.lse = lse; a.B = B; a.S = S; a.H = H; a.s_pad = 0;
     a.scale = scale; a.scale_log2 = scale_log2; a.shift = score_bound;
     dim3 grid(((S + 255) / 256) * H * B);
-    hipLaunchKernelGGL((attn_fwd_v2_kernel<true, true, true>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    static int use_pp = -1;
+    if (use_pp < 0) { const char* e = getenv("ORV_ATTN_PP"); use_pp = (e && atoi(e) == 0) ? 0 : 1; }
+    if (use_pp && ld_out % 8 == 0 && ((uintptr_t)out & 15) == 0)
+        hipLaunchKernelGGL((attn_fwd_pp_kernel<true>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((attn_fwd_v2_kernel<true, true, true>), grid, dim3(512), 0, (hipStream_t)stream, a);
     return orv_check_launch("orv_attention_fwd_bounded");
 }

@@ -12,6 +12,11 @@ int main(int argc,char**argv){ int B=argc>1?atoi(argv[1]):4, S=argc>2?atoi(argv[
   orv_qkv_prep(qkv,vT,nullptr,nullptr,nullptr,nullptr,nullptr,nullptr,B,S,H,226,s_pad,1e-6f,premul,nullptr);
   hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
   uint16_t* vt_arg = getenv("ATTN_V1") ? vT : nullptr;   // default: V in place (attn_fwd_v2)
+  if(getenv("BOUND")){ float bd=atof(getenv("BOUND"));   // bounded scores: orv_attention_fwd_bounded (fixed-shift / ping-pong kernels)
+    for(int i=0;i<3;i++) orv_attention_fwd_bounded(qkv,3*H*64,out,H*64,nullptr,B,S,H,sc,bd,nullptr);
+    int it=getenv("ITERS")?atoi(getenv("ITERS")):20;
+    hipEventRecord(e0); for(int i=0;i<it;i++) orv_attention_fwd_bounded(qkv,3*H*64,out,H*64,nullptr,B,S,H,sc,bd,nullptr); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms,e0,e1); ms/=it;
+    printf("attention(bounded %.1f) B=%d S=%d H=%d: %.4f ms  %.1f TFLOP/s\n",bd,B,S,H,ms,4.0*B*H*(double)S*S*64/ms/1e9); return 0; }
   for(int i=0;i<3;i++) orv_attention_fwd(qkv,3*H*64,vt_arg,out,H*64,nullptr,B,S,H,s_pad,sc,nullptr);
   hipEventRecord(e0); for(int i=0;i<20;i++) orv_attention_fwd(qkv,3*H*64,vt_arg,out,H*64,nullptr,B,S,H,s_pad,sc,nullptr); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms,e0,e1); ms/=20;
   printf("attention B=%d S=%d H=%d: %.4f ms  %.1f TFLOP/s\n",B,S,H,ms,4.0*B*H*(double)S*S*64/ms/1e9);
