@@ -122,18 +122,20 @@ def cpu_baseline(cfg, layers, threads):
             d = time.perf_counter() - t0
         return d, d * 30.0 / n_layers
 
-    dt, per_step = timed(layers, threads, torch.float32)
-    # bf16 beside fp32, and 8 threads beside the host's own count (the build container has 8 cores)
-    dt_bf, per_bf = timed(layers, threads, torch.bfloat16)
-    small = max(1, layers // 3)
-    dt_8, per_8 = timed(small, min(8, threads), torch.float32)
+    # thread sweep on ONE block each (the 128-thread run of earlier rounds was the slowest point of this curve: oversubscribed),
+    # then the sample proper - `layers` of the 30 blocks - with the best count; bf16 beside fp32
+    sweep = {}
+    for nthr in sorted({n for n in (8, 16, 32, 64, threads) if n <= max(threads, 8)}):
+        sweep[nthr] = timed(1, nthr, torch.float32)[0]
+    best = min(sweep, key=sweep.get)
+    dt, per_step = timed(layers, best, torch.float32)
+    dt_bf, per_bf = timed(max(1, layers // 3), best, torch.bfloat16)
     torch.set_num_threads(threads)
-    return {"value": 1.0 / per_step, "unit": "denoise-steps/s", "cores": threads, "kind": "port",
-            "sample": f"1 clip x 1 step, fp32 eager PyTorch oracle, {layers}/30 blocks timed ({dt:.2f} s) and scaled to 30",
-            "s_per_step": per_step,
-            "variants": [
-                {"dtype": "bf16", "cores": threads, "s_per_step": per_bf, "sample": f"{layers}/30 blocks ({dt_bf:.2f} s)"},
-                {"dtype": "f32", "cores": min(8, threads), "s_per_step": per_8, "sample": f"{small}/30 blocks ({dt_8:.2f} s)"}]}
+    return {"value": 1.0 / per_step, "unit": "denoise-steps/s", "cores": best, "kind": "port",
+            "sample": f"1 clip x 1 step, fp32 eager PyTorch oracle, {layers}/30 blocks timed ({dt:.2f} s) and scaled to 30; "
+                      f"threads = best of a one-block sweep",
+            "s_per_step": per_step, "thread_sweep_s_per_block": {str(k): round(v, 3) for k, v in sweep.items()},
+            "variants": [{"dtype": "bf16", "cores": best, "s_per_step": per_bf, "sample": f"{max(1, layers // 3)}/30 blocks ({dt_bf:.2f} s)"}]}
 
 
 def ranks_seen(world, dev):
@@ -160,20 +162,28 @@ def vae_decode_leg(latents, dev, loop_wall, steps, world, B, barrier):
             p.data.normal_(0, 1.0 / (p[0].numel() ** 0.5), generator=g)
     vae = vae.to(torch.bfloat16).eval()
     z = (latents.permute(0, 2, 1, 3, 4) / 1.15258426).contiguous()            # decode_latents layout (:1476-1479)
-    vae.decode(z)                          # untimed: weight packing, allocator growth and code-object loads at THIS batch size
-    barrier()
-    t0 = time.perf_counter()
-    out = vae.decode(z).sample
-    barrier()
-    dt = time.perf_counter() - t0
-    assert out.shape == (B, 3, 17, 320, 480) and torch.isfinite(out.float()).all()
+
+    def timed_decode():
+        vae.decode(z)                      # untimed: weight packing, allocator growth and code-object loads at THIS batch size
+        barrier()
+        t0 = time.perf_counter()
+        out = vae.decode(z).sample
+        barrier()
+        dt = time.perf_counter() - t0
+        assert out.shape == (B, 3, 17, 320, 480) and torch.isfinite(out.float()).all()
+        return dt
+    dt_plain = timed_decode()
+    vae.enable_slicing(); vae.enable_tiling()          # what the reference's entry points do (inference_control_to_video.py:98-99):
+    dt = timed_decode()                                # a 40 x 60 latent is 4 tiles of <= 30 x 45 (1.29 x the voxels) + seam blends
     step_s = loop_wall / steps
-    return {"ms_per_clip": round(1e3 * dt / B, 2), "parity": "unpinned (oracle/vae.py restates diffusers; no reference fixture)",
+    return {"ms_per_clip": round(1e3 * dt / B, 2), "ms_per_clip_untiled": round(1e3 * dt_plain / B, 2),
+            "tiling": "enable_tiling() as the reference: 4 tiles 30x45 / 30x24 / 15x45 / 15x24 latent, blend 40 / 72 px",
+            "parity": "unpinned (oracle/vae.py restates diffusers incl. tiled_decode; no reference fixture)",
             "frames_per_sec_50_steps_incl_decode": round(17.0 * world * B / (50 * step_s + dt), 3),
             "frames_per_sec_50_steps_excl_decode": round(17.0 * world * B / (50 * step_s), 3)}
 
 
-def train_mode(args, model, latents, image_latents, prompt, actions, sched, dev, rank, world, cfg=None):
+def train_mode(args, model, latents, image_latents, prompt, actions, sched, dev, rank, world, cfg=None, leg=None):
     """BASELINE configs[2]: CogVideoX-2B SFT step (train_cogvideox_control_to_video_sft.py:1005-1104), B clips per GPU, bf16
     params/grads, data parallel: forward+backward through the HIP kernels, ONE bucketed RCCL all-reduce of the gradients,
     global-norm clip + fused AdamW.  value = trained clips per second (all GPUs)."""
@@ -202,14 +212,23 @@ def train_mode(args, model, latents, image_latents, prompt, actions, sched, dev,
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    n_warm, n_steps = (leg if leg is not None else (args.warmup, args.steps))
+    torch.cuda.reset_peak_memory_stats()
+    for _ in range(n_warm):
         step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(n_steps):
         loss = step()
     barrier()
     wall = time.perf_counter() - t0
+    if leg is not None:            # `train` leg of the default (denoise) line: configs[2] at B clips, N = 1, a few steps
+        c_ = cfg or {**CFG_2B, "num_layers": args.layers}
+        fl = 3.0 * flops_per_sample(c_, 226 + 3000)
+        return {"workload": "configs[2]: CogVideoX-2B SFT step (fwd + bwd + global-norm clip + fused AdamW), bf16 params + grads",
+                "batch_per_gpu": B, "warmup": n_warm, "steps": n_steps, "ms_per_step": round(1e3 * wall / n_steps, 2),
+                "clips_per_sec": round(B * n_steps / wall, 3), "achieved_tflops_attn_ffn": round(B * n_steps / wall * fl / 1e12, 1),
+                "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "final_loss": float(loss)}
     if world > 1:
         w = torch.tensor([wall], device=dev, dtype=torch.float64)
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
@@ -281,8 +300,9 @@ def main():
     ap.add_argument("--mode", choices=["denoise", "train"], default="denoise",
                     help="denoise (headline, BASELINE configs[1]) or train (configs[2]: one SFT step = fwd+bwd+all-reduce+AdamW)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay the transformer forward from a HIP graph (B=1 latency); "
-                                                         "the per-kernel roofline needs the eager path and is omitted")
+    ap.add_argument("--graph", action="store_true", help="(default since round 3) replay the transformer forward from a HIP graph")
+    ap.add_argument("--eager", action="store_true", help="time the eager launch path instead of the HIP-graph replay")
+    ap.add_argument("--no-legs", action="store_true", help="skip the b1 / train legs reported beside the headline (N = 1 only)")
     ap.add_argument("--cpu-baseline-layers", type=int, default=6)
     ap.add_argument("--model", choices=["2b", "5b"], default="2b",
                     help="2b = the headline (BASELINE configs[1]/[2]); 5b = configs[4] (CogVideoX1.5-5B, DROID 256x384x29f, p_t=2, "
@@ -315,7 +335,7 @@ def main():
     torch.cuda.set_device(dev)
 
     from orv_amd import ops, schedulers
-    from orv_amd._lib import check, lib
+    from orv_amd._lib import LIB_PATH, check, lib
     check(lib().orv_device_check(local), "orv_device_check")
 
     B = args.batch
@@ -336,19 +356,29 @@ def main():
     ts = sched.timesteps.tolist()
     controls = {"actions": actions}
 
+    # The timed path is what the sampler runs: the transformer forward replayed from a HIP graph (GraphedTransformer: bit-identical to
+    # the eager launches, tests/test_gpu_model.py), which removes ~1.2 ms of launch gaps per step.  The per-kernel timeline (HIP
+    # events around every GEMM / attention launch) cannot be taken inside a graph: it comes from a SECOND, eager loop after the
+    # timed region.  --eager times the eager path instead.
+    use_graph = not args.eager
     fwd = model
-    if args.graph:                      # transformer forward replayed from a HIP graph (per-kernel timeline unavailable)
+    if use_graph:
         from orv_amd.cogvideox_control import GraphedTransformer
         fwd = GraphedTransformer(model)
 
-    @torch.no_grad()                    # the reference sampler runs under torch.no_grad (cogvideox_control.py:1228)
-    def step(i, lat):
-        t = ts[i % len(ts)]
-        model_in = torch.cat([lat, image_latents], dim=2)                   # cogvideox_control.py:1409-1413
-        tvec = torch.full((B,), t, device=dev, dtype=torch.int64)
-        v = fwd(hidden_states=model_in, encoder_hidden_states=prompt, timestep=tvec,
-                controls_or_guidances=controls, return_dict=False)[0]
-        return sched.step(v, t, lat, return_dict=False)[0]
+    def make_step(fn, Bn, lat_img, prm, ctl):
+        @torch.no_grad()                    # the reference sampler runs under torch.no_grad (cogvideox_control.py:1228)
+        def step(i, lat):
+            t = ts[i % len(ts)]
+            model_in = torch.cat([lat, lat_img], dim=2)                       # cogvideox_control.py:1409-1413
+            tvec = torch.full((Bn,), t, device=dev, dtype=torch.int64)
+            v = fn(hidden_states=model_in, encoder_hidden_states=prm, timestep=tvec,
+                   controls_or_guidances=ctl, return_dict=False)[0]
+            return sched.step(v, t, lat, return_dict=False)[0]
+        return step
+
+    step = make_step(fwd, B, image_latents, prompt, controls)
+    eager_step = make_step(model, B, image_latents, prompt, controls)
 
     if args.mode == "train":
         return train_mode(args, model, latents, image_latents, prompt, actions, sched, dev, rank, world)
@@ -360,18 +390,29 @@ def main():
             torch.cuda.synchronize()
 
     lat = latents
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, 3 if use_graph else 0)):        # a graph needs one eager + one capturing call before it replays
         lat = step(i, lat)
     barrier()
-    ops.start_timeline()
     t0 = time.perf_counter()
     lat = latents
     for i in range(args.steps):
         lat = step(i, lat)
     barrier()
     wall = time.perf_counter() - t0
-    timeline = ops.stop_timeline()
     assert torch.isfinite(lat.float()).all(), "non-finite latents"
+    # per-kernel timeline: eager loop, outside the timed region (same kernels, same shapes, same stream)
+    n_tl = args.steps if not use_graph else min(args.steps, 10)
+    lat2 = latents
+    for i in range(2):
+        lat2 = eager_step(i, lat2)
+    torch.cuda.synchronize()
+    ops.start_timeline()
+    t1 = time.perf_counter()
+    for i in range(n_tl):
+        lat2 = eager_step(i, lat2)
+    torch.cuda.synchronize()
+    eager_ms = 1e3 * (time.perf_counter() - t1) / n_tl
+    timeline = ops.stop_timeline()
     if world > 1:
         w = torch.tensor([wall], device=dev, dtype=torch.float64)
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
@@ -380,6 +421,26 @@ def main():
     vae_leg = None
     if not args.no_vae and args.layers == 30:
         vae_leg = vae_decode_leg(lat, dev, wall, args.steps, world, B, barrier)
+    legs = {}
+    if world == 1 and not args.no_legs and args.layers == 30:
+        # b1: the demo shape (inference_control_to_video.py runs ONE clip), graph-replayed
+        l1, il1, p1, a1 = synthetic_inputs(1, dev, torch.bfloat16)
+        model.action_embed.forced_mask = torch.zeros(1, dtype=torch.bool)
+        s1 = make_step(GraphedTransformer(model) if use_graph else model, 1, il1, p1, {"actions": a1})
+        x1 = l1
+        for i in range(3):
+            x1 = s1(i, x1)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for i in range(20):
+            x1 = s1(i, x1)
+        torch.cuda.synchronize()
+        legs["b1"] = {"workload": "configs[1] at B = 1 (the demo entry point), 20 steps", "ms_per_step": round(1e3 * (time.perf_counter() - tb) / 20, 3),
+                      "timed_path": "hip-graph replay" if use_graph else "eager"}
+        del s1, x1
+        # train: configs[2] on this GPU (last: the fused optimizer moves the parameters into its flat buffers)
+        model.action_embed.forced_mask = torch.zeros(B, dtype=torch.bool)
+        legs["train"] = train_mode(args, model, latents, image_latents, prompt, actions, sched, dev, rank, world, leg=(3, 5))
 
     if rank == 0:
         S = 226 + 3000
@@ -388,6 +449,9 @@ def main():
         fl = flops_per_sample(cfg, S)
         # per-kernel live timings -> dominant kernel roofline
         kernels = []
+        # the attention symbol orv_attention_fwd_bounded launches for this model (random-init qk-LayerNorm: bound ~11.8 log2 units)
+        attn_sym = "attn_fwd_pp_kernel<true>" if os.environ.get("ORV_ATTN_PP", "1") != "0" and os.environ.get("ORV_ATTN_STATIC", "1") != "0" \
+            else ("attn_fwd_pp_kernel<false>" if os.environ.get("ORV_ATTN_PP", "1") != "0" else "attn_fwd_v2_kernel")
         for key, ms in timeline.items():
             if key[0] == "gemm":
                 _, M, N, K, epi = key
@@ -399,7 +463,7 @@ def main():
                 flop, name = 2.0 * M * N * K, f"{sym} M={M} N={N} K={K}"
             else:
                 _, b, s, h = key
-                flop, name = 4.0 * b * h * s * s * 64, f"attn_fwd_v2_kernel<true, true> B={b} S={s} H={h}"
+                flop, name = 4.0 * b * h * s * s * 64, f"{attn_sym} B={b} S={s} H={h}"
             avg = sum(ms) / len(ms)
             kernels.append({"kernel": name, "launches": len(ms), "avg_ms": round(avg, 4), "total_ms": round(sum(ms), 2),
                             "tflops": round(flop / avg / 1e9, 1)})
@@ -447,7 +511,14 @@ def main():
                 "unit": "TFLOP/s", "frac": round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "mfma_busy": mfma_busy, "clock_ghz_under_pmc": clock, "launches": dom["launches"], "avg_ms": dom["avg_ms"]},
             "kernels": kernels[:8],
+            "timed_path": "hip-graph replay of the transformer forward (bit-identical to eager)" if use_graph else "eager launches",
+            "eager_ms_per_step": round(eager_ms, 3),
+            "kernel_timeline": f"HIP events on the launch stream over a separate eager loop of {n_tl} steps after the timed region",
+            "lib": {"path": os.path.relpath(LIB_PATH, ROOT), "orv_version": int(lib().orv_version())},
+            "pmc_source": "roofline.traffic / mfma_busy / clock_ghz_under_pmc are read from profiles/hbm_traffic.json (separate rocprofv3 "
+                          "--pmc passes of this command, tools/pmc_bench.sh), not re-measured in this run",
             "vae_decode": vae_leg,
+            "b1": legs.get("b1"), "train": legs.get("train"),
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = max(1, (os.cpu_count() or 2) // 2)
