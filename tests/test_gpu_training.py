@@ -1,6 +1,7 @@
 """GPU: the training path (forward that saves activations + hand-written backward, attached to autograd) against torch
-autograd through the CPU fp32 oracle on the same weights/inputs.  Per-parameter gradient rel-L2 <= 6e-2 (bf16 params,
-bf16 gradients, 2-30 chained bf16 GEMMs), loss-level check, and an optimizer step that lowers the loss."""
+autograd through the CPU fp32 oracle on the same weights/inputs.  Per-parameter gradient rel-L2 bound (bf16 params, bf16
+gradients, 2-30 chained bf16 GEMMs): 3e-2 in general, 6e-2 for the q / k projection biases and the qk-LayerNorm parameters
+(``grad_bound``); loss-level check, and an optimizer step that lowers the loss."""
 import pytest
 import torch
 
@@ -15,6 +16,17 @@ BF = torch.bfloat16
 def rel_l2(got, ref):
     got, ref = got.float().cpu(), ref.float().cpu()
     return ((got - ref).norm() / (ref.norm() + 1e-12)).item()
+
+
+def grad_bound(name: str) -> float:
+    """Per-parameter gradient bound (rel-L2 vs fp32 autograd).  One family needs the looser 6e-2: to_q.bias / to_k.bias and
+    norm_q / norm_k.{weight,bias}.  The qk LayerNorm adjoint subtracts from every token's dq its mean and its projection on xhat,
+    so these gradients are sums over ~10^3-10^4 tokens of terms that nearly cancel - the result is one to two orders of magnitude
+    smaller than the summed magnitudes, and the bf16 rounding of the individual terms (2^-9 each) does not shrink with it.
+    Every other parameter (all GEMM weights among them) sits at a p90 of ~1e-2 and is held to 3e-2, so a regression of a few x
+    in any weight gradient fails (profiles/r2_parity_error_distribution.txt)."""
+    qk = (".to_q.bias", ".to_k.bias", ".norm_q.", ".norm_k.")
+    return 6e-2 if any(t in name for t in qk) else 3e-2
 
 
 def _oracle_grads(cfg, w, ins, mask, wout, extra=None, wrec=None):
@@ -85,10 +97,10 @@ def test_parameter_gradients_match_oracle_autograd(name):
         err = rel_l2(p.grad, ref_g[k])
         checked += 1
         errs.append((err, k))
-        if err > 6e-2:
+        if err > grad_bound(k):
             bad.append((k, round(err, 4)))
     errs.sort()
-    # the distribution inside the 6e-2 bound (DESIGN.md §1 quotes it; run with -s to see it)
+    # the distribution inside the bounds (DESIGN.md §1 quotes it; run with -s to see it)
     print(f"[grad-err] {name}: n={len(errs)} median={errs[len(errs) // 2][0]:.2e} p90={errs[int(len(errs) * 0.9)][0]:.2e} "
           f"max={errs[-1][0]:.2e} ({errs[-1][1]})")
     assert checked > 20 and not bad, bad
@@ -118,12 +130,14 @@ def test_multiview_finetune_freezes_base_model():
             assert torch.isfinite(p_.grad.float()).all(), k
 
 
-def test_full_width_layer_gradients():
-    """2B widths, one block, S = 3226: the MFMA dgrad/wgrad and attention-backward tilings at the real shapes."""
+@pytest.mark.parametrize("layers", [1, 4])
+def test_full_width_layer_gradients(layers):
+    """2B widths, S = 3226, one block and FOUR chained blocks (gradients that passed through 3 more full-width blocks' adjoints):
+    the MFMA dgrad / wgrad and attention-backward tilings at the real shapes."""
     from orv_amd.cogvideox_control import CogVideoXTransformer3DModelTraj
     dev = torch.device("cuda:0")
     torch.manual_seed(42)
-    cfg = dict(num_layers=1, in_channels=32, sample_height=40, sample_width=60, sample_frames=17,
+    cfg = dict(num_layers=layers, in_channels=32, sample_height=40, sample_width=60, sample_frames=17,
                modulate_encoder_hidden_states=True)
     m = CogVideoXTransformer3DModelTraj(**cfg)
     for p in m.parameters():
@@ -146,8 +160,10 @@ def test_full_width_layer_gradients():
               "transformer_blocks.0.attn1.to_q.weight", "transformer_blocks.0.attn1.to_k.weight",
               "transformer_blocks.0.attn1.to_v.weight", "transformer_blocks.0.attn1.to_out.0.weight",
               "transformer_blocks.0.norm1.linear.weight", "transformer_blocks.0.norm2.linear.weight", "patch_embed.proj.weight",
-              "patch_embed.text_proj.weight", "proj_out.weight", "time_embedding.linear_1.weight", "action_embed.mlp.0.weight"]:
-        assert rel_l2(named[k].grad, ref_g[k]) <= 6e-2, k
+              "patch_embed.text_proj.weight", "proj_out.weight", "time_embedding.linear_1.weight", "action_embed.mlp.0.weight"] + \
+            [f"transformer_blocks.{layers - 1}.{n}" for n in ("ff.net.2.weight", "attn1.to_q.weight", "attn1.to_out.0.weight",
+                                                              "attn1.to_k.bias", "attn1.norm_q.weight")]:
+        assert rel_l2(named[k].grad, ref_g[k]) <= grad_bound(k), (k, rel_l2(named[k].grad, ref_g[k]))
 
 
 def test_sft_step_lowers_loss():
@@ -327,7 +343,8 @@ def test_gradient_accumulation_window_equals_one_step():
     assert worst <= 1e-2, worst
 
 
-def test_full_width_5b_layer_gradients():
+@pytest.mark.parametrize("layers", [1, 4])
+def test_full_width_5b_layer_gradients(layers):
     """CogVideoX1.5-5B widths (BASELINE configs[4]: D=3072, 48 heads, FF=12288, RoPE, p_t=2, ofs; DROID 256x384 latents
     [1,8,32,32,48] -> S=1762), one block: the hand-written backward at the 5B shapes (3072 / 9216 / 12288-wide dgrad / wgrad
     tilings, RoPE adjoint, p_t patch-embed adjoint) against torch autograd through the fp32 oracle."""
@@ -335,7 +352,7 @@ def test_full_width_5b_layer_gradients():
     from orv_amd.utils import prepare_rotary_positional_embeddings
     dev = torch.device("cuda:0")
     torch.manual_seed(7)
-    cfg = dict(num_attention_heads=48, attention_head_dim=64, num_layers=1, in_channels=32, out_channels=16, patch_size_t=2,
+    cfg = dict(num_attention_heads=48, attention_head_dim=64, num_layers=layers, in_channels=32, out_channels=16, patch_size_t=2,
                ofs_embed_dim=512, use_rotary_positional_embeddings=True, sample_height=32, sample_width=48, sample_frames=29,
                modulate_encoder_hidden_states=True, loaded_pretrained_model_name_or_path="THUDM/CogVideoX1.5-5b-I2V")
     m = CogVideoXTransformer3DModelTraj(**cfg)
@@ -365,8 +382,9 @@ def test_full_width_5b_layer_gradients():
               "transformer_blocks.0.attn1.to_v.weight", "transformer_blocks.0.attn1.to_out.0.weight",
               "transformer_blocks.0.attn1.norm_q.weight", "transformer_blocks.0.norm1.linear.weight",
               "transformer_blocks.0.norm2.linear.weight", "patch_embed.proj.weight", "patch_embed.text_proj.weight",
-              "proj_out.weight", "time_embedding.linear_1.weight", "ofs_embedding.linear_1.weight", "action_embed.mlp.0.weight"]:
-        assert rel_l2(named[k].grad, ref_g[k]) <= 6e-2, k
+              "proj_out.weight", "time_embedding.linear_1.weight", "ofs_embedding.linear_1.weight", "action_embed.mlp.0.weight"] + \
+            [f"transformer_blocks.{layers - 1}.{n}" for n in ("ff.net.0.proj.weight", "attn1.to_v.weight", "attn1.to_q.bias")]:
+        assert rel_l2(named[k].grad, ref_g[k]) <= grad_bound(k), (k, rel_l2(named[k].grad, ref_g[k]))
 
 
 def test_gradient_checkpointing_flag_is_accepted_and_changes_nothing():
