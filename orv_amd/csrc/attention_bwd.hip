@@ -8,6 +8,7 @@
 // Operands whose contraction index is the sequence (K^T, Q^T, dO^T) come from per-head transposed copies
 // [B,H,64,s_pad] written by orv_head_transpose in the key order the accumulator layout produces (bits 2<->3 exchanged).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -322,6 +323,534 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const BwdArgs p) {
     }
 }
 
+// ===============================================================================================================
+// Ping-pong forms of both passes (round 3; the structure of attn_fwd_pp_kernel, attention.hip): the two waves of every SIMD run
+// half a tile out of phase - one in its matrix segment X_t, the other in its vector segment Y_t - separated by one s_barrier per
+// segment, the second half of the workgroup one barrier behind the first.  The passes above have one workgroup per CU (256
+// registers), i.e. two waves per SIMD in lock step with every ds_read right in front of its MFMA: ~690 TFLOP/s.
+//   * No transposed copies any more: the operands whose contraction index is the sequence (K^T for dQ; Q'^T and dO^T for dK, dV)
+//     are read with ds_read_b64_tr_b16 from the SAME row-major tile the score GEMMs read with ds_read_b128, one tile later
+//     (X_t = { gradient GEMMs of tile t-1 ; score GEMMs of tile t }), so orv_head_transpose and the qT / kT / doT buffers are
+//     gone.  One LDS image is conflict-free for both read kinds (swz below).
+//   * dual-use tiles live two segments longer: three 8-KiB slots (tile t in slot t % 3), staged one tile ahead by the first
+//     half (in its X_t, behind the transposing reads - see attention.hip on hipcc's vmcnt(0) in front of them) and two tiles ahead
+//     by the second half (in its Y_t).
+// ===============================================================================================================
+// One LDS image serves both read kinds without bank conflicts: 16-byte chunk c of tile row r lives in slot c ^ f(r),
+//   f(r) = (bit 1 of r) << 2 | (bits 3..2 of r).
+// ds_read_b128 (16-lane groups of rows {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}, one chunk column): even and odd rows use the two
+// halves of the 256-byte bank row, and within either parity the eight rows of a group get eight distinct f.  ds_read_b64_tr_b16
+// (32-lane halves = 4 consecutive rows x one 64-byte half row): rows r and r + 2 share a parity and must not share the half row,
+// which bit 2 of f = bit 1 of r guarantees (the forward's V image is this rule alone).  Before: the ds_read_b128-optimal image
+// c ^ ((r >> 1) & 7) made every transposing read 2-way conflicted and the gradient GEMMs LDS-bound (one 1-KiB fragment per MFMA).
+// LDS-DMA from inline asm (cdna guide 5.7: M0 written in the same statement): hipcc tracks every __builtin_amdgcn_global_load_lds as
+// a pending LDS write and puts s_waitcnt vmcnt(0) in front of the next ds_read_b64_tr_b16 (its builtin carries no memory operand
+// to disambiguate).  Here the transposing reads of the NEXT matrix segment are issued early in the vector segment, i.e. right
+// behind a DMA issue of the same wave: from asm the DMA is invisible to that pass, and its completion is owned by the explicit
+// s_waitcnt vmcnt(0) + s_barrier pairs of the schedule.
+__device__ __forceinline__ void glds16_asm(const void* gsrc, const void* lds_dst) {
+    unsigned keep;
+    const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(d) : "memory");
+}
+__device__ __forceinline__ void glds4_asm(const void* gsrc, const void* lds_dst) {
+    unsigned keep;
+    const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(d) : "memory");
+}
+__device__ __forceinline__ int swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 tr_pair(const char* a, const char* b) {
+#ifdef ORV_BW_ABL_NOTR
+    bf16x8 z; asm volatile("" : "=v"(z)); return z;
+#endif
+    const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)a);
+    const v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)b);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+#define BW_BAR()                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    __builtin_amdgcn_s_barrier();                                                                 \
+    __builtin_amdgcn_sched_barrier(0);
+#define BW_FENCE() __builtin_amdgcn_sched_barrier(0);
+#ifdef ORV_BW_ABL_NOMFMA
+#define BW_MFMA(A_, B_, C_) ([&]() { asm volatile("" ::"v"(A_), "v"(B_)); return C_; }())
+#else
+#define BW_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, C_, 0, 0, 0)
+#endif
+// per-lane byte offsets of the transposing reads into a swizzled [64 rows][64 d] tile: contraction rows kk * 16 + half * 8 + 4 hi +
+// (r16 >> 2), logical bytes db * 64 + g16 * 32 + (r16 & 3) * 8 (4 consecutive d); + kk * 2048 is an immediate
+__device__ __forceinline__ int tr_off(int lane, int db, int half) {
+    const int hi = lane >> 5, r16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int row = half * 8 + 4 * hi + (r16 >> 2);
+    const int chunk = (db * 4 + g16 * 2 + ((r16 & 3) >> 1)) ^ swz(row);
+    return row * 128 + chunk * 16 + (r16 & 1) * 8;
+}
+__device__ __forceinline__ void store_row16(bf16_t* op, const f32x16 (&acc)[2], float sc) {
+    // lane holds d = 32 db + 8 qd + 4 hi + (0..3) of its row: column groups qd = 2u (lower half-wave) / 2u + 1 (upper) are exchanged
+    // so that every lane stores one aligned 16-byte piece (op already includes + hi * 8)
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            uint32_t a0 = pack2bf(acc[db][(2 * u) * 4 + 0] * sc, acc[db][(2 * u) * 4 + 1] * sc);
+            uint32_t a1 = pack2bf(acc[db][(2 * u) * 4 + 2] * sc, acc[db][(2 * u) * 4 + 3] * sc);
+            uint32_t b0 = pack2bf(acc[db][(2 * u + 1) * 4 + 0] * sc, acc[db][(2 * u + 1) * 4 + 1] * sc);
+            uint32_t b1 = pack2bf(acc[db][(2 * u + 1) * 4 + 2] * sc, acc[db][(2 * u + 1) * 4 + 3] * sc);
+            { const auto r = __builtin_amdgcn_permlane32_swap(a0, b0, false, false); a0 = r[0]; b0 = r[1]; }
+            { const auto r = __builtin_amdgcn_permlane32_swap(a1, b1, false, false); a1 = r[0]; b1 = r[1]; }
+            *(uint4*)(op + db * 32 + u * 16) = make_uint4(a0, a1, b0, b1);
+        }
+}
+
+// ===== pass A, ping-pong: dQ.  X_t = { dQ^T += K_{t-1}^T dS_{t-1}^T (8 MFMAs, transposing reads) ; S_t^T = K_t Q^T - lse,
+// dP_t^T = V_t dO^T - delta (16 MFMAs, ds_read_b128) } ; Y_t = { P = exp2(S), dS = P dP, bf16 pack }.
+// K: three slots (read as tile t and as tile t-1), staged by waves 0-3; V: two slots, staged two tiles ahead by waves 4-7.
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(const BwdArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[5 * TILE];          // K slots 0-2 | V slots 0-1
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wq = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5, sw = swz(l31);
+    const int nqt = (p.S + 255) / 256;
+    const int item = orv_xcd_item(blockIdx.x, gridDim.x);
+    const int bh = item / nqt, h = bh % p.H, b = bh / p.H;
+    const int q0 = (item % nqt) * 256 + wave * 32;
+    const int D = p.H * 64;
+    const long row0 = (long)b * p.S;
+    const int qr = min(q0 + l31, p.S - 1);
+    bf16x8 qf[4], dof[4];
+    {
+        const bf16_t* qp = p.qkv + (row0 + qr) * p.ld + h * 64 + hi * 8;
+        const bf16_t* dp = p.dout + (row0 + qr) * p.ld_do + h * 64 + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { qf[ks] = *(const bf16x8*)(qp + ks * 16); dof[ks] = *(const bf16x8*)(dp + ks * 16); }
+    }
+    f32x16 c_lse, c_del;
+    {
+        const long vecq = ((long)b * p.H + h) * p.s_pad + qr;
+        const float nl = p.neg_lse2[vecq], nd = p.neg_delta[vecq];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { c_lse[e] = nl; c_del[e] = nd; }
+    }
+    const int nt = (p.S + 63) / 64;
+    const bool ragged = (p.S & 63) != 0;
+    auto src_of = [&](int j, int t) {              // this lane's source line of piece j in tile t (keys past S: a valid row)
+        const int sr = wq * 16 + j * 8 + (lane >> 3), slot = lane & 7;
+        return p.qkv + (row0 + min(t * 64 + sr, p.S - 1)) * p.ld + (grp == 0 ? D : 2 * D) + h * 64 + (slot ^ swz(sr)) * 8;
+    };
+    const bf16_t* const sbase0 = src_of(0, 0);
+    const bf16_t* const sbase1 = src_of(1, 0);
+    char* const sdst = smem + (grp == 0 ? 0 : 3 * TILE) + wq * 2048;
+    auto stage = [&](int t) {
+        if (t >= nt) return;
+#ifdef ORV_BW_ABL_NODMA
+        if (t > 1) return;
+#endif
+        char* const d = sdst + (grp == 0 ? t % 3 : t & 1) * TILE;
+        if (__builtin_expect(ragged && t == nt - 1, 0)) {
+            glds16_asm(src_of(0, t), d);
+            glds16_asm(src_of(1, t), d + 1024);
+        } else {
+            const long toff = (long)t * 64 * p.ld;
+            glds16_asm(sbase0 + toff, d);
+            glds16_asm(sbase1 + toff, d + 1024);
+        }
+    };
+    f32x16 dq[2], sT[2], dP[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dq[i][e] = 0.f; sT[i][e] = 0.f; dP[i][e] = 0.f; }
+    union { bf16x8 v; uint32_t u[4]; } dsf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dsf[i].u[e] = 0u;
+    const int row_off = l31 * 128;
+    const int t00 = tr_off(lane, 0, 0), t01 = tr_off(lane, 0, 1), t10 = tr_off(lane, 1, 0), t11 = tr_off(lane, 1, 1);
+
+    // transposing-read fragments of the gradient GEMMs, k-steps 0 and 1: fetched at the top of the vector segment Y_{t-1} (the tile
+    // they come from is resident since X_{t-1}) and held across the barrier, so X_t opens with MFMAs instead of an LDS round trip
+    bf16x8 ga0 = qf[0], ga1 = qf[0], gb0 = qf[0], gb1 = qf[0];
+    auto prefetch_g = [&](int t) {                                 // fragments of tile t for the gradient part of X_{t+1}
+        const char* sP = smem + (t % 3) * TILE;
+        ga0 = tr_pair(sP + t00, sP + t01); ga1 = tr_pair(sP + t10, sP + t11);
+        gb0 = tr_pair(sP + 2048 + t00, sP + 2048 + t01); gb1 = tr_pair(sP + 2048 + t10, sP + 2048 + t11);
+    };
+    auto seg_x = [&](int t, auto stage_k) {
+        __builtin_amdgcn_s_setprio(1);
+        const char* sK = smem + (t % 3) * TILE + row_off;
+        const char* sV = smem + 3 * TILE + (t & 1) * TILE + row_off;
+        auto rd = [&](const char* base, int kb, int ks) {
+#ifdef ORV_BW_ABL_NOB128
+            bf16x8 z; asm volatile("" : "=v"(z)); return z;
+#endif
+            return *(const bf16x8*)(base + kb * 4096 + (((ks * 2 + hi) ^ sw) * 16)); };
+        bf16x8 ka0, va0, ka1, va1, kb0, vb0, kb1, vb1;
+        if (t < nt) { ka0 = rd(sK, 0, 0); va0 = rd(sV, 0, 0); ka1 = rd(sK, 0, 1); va1 = rd(sV, 0, 1); }   // first score fragments: in flight under the gradient MFMAs
+        BW_FENCE()
+        stage_k();
+        BW_FENCE()
+        if (t > 0) {
+            const char* sP = smem + ((t - 1) % 3) * TILE;         // K of the previous tile, transposed reads
+            dq[0] = BW_MFMA(ga0, dsf[0].v, dq[0]); dq[1] = BW_MFMA(ga1, dsf[0].v, dq[1]);
+            BW_FENCE()
+            ga0 = tr_pair(sP + 4096 + t00, sP + 4096 + t01); ga1 = tr_pair(sP + 4096 + t10, sP + 4096 + t11);
+            BW_FENCE()
+            dq[0] = BW_MFMA(gb0, dsf[1].v, dq[0]); dq[1] = BW_MFMA(gb1, dsf[1].v, dq[1]);
+            BW_FENCE()
+            gb0 = tr_pair(sP + 6144 + t00, sP + 6144 + t01); gb1 = tr_pair(sP + 6144 + t10, sP + 6144 + t11);
+            if (t < nt) { kb0 = rd(sK, 0, 2); vb0 = rd(sV, 0, 2); kb1 = rd(sK, 0, 3); vb1 = rd(sV, 0, 3); }
+            BW_FENCE()
+            dq[0] = BW_MFMA(ga0, dsf[2].v, dq[0]); dq[1] = BW_MFMA(ga1, dsf[2].v, dq[1]);
+            dq[0] = BW_MFMA(gb0, dsf[3].v, dq[0]); dq[1] = BW_MFMA(gb1, dsf[3].v, dq[1]);
+            BW_FENCE()
+        } else {
+            kb0 = rd(sK, 0, 2); vb0 = rd(sV, 0, 2); kb1 = rd(sK, 0, 3); vb1 = rd(sV, 0, 3);
+            BW_FENCE()
+        }
+        if (t < nt) {
+            // 16 score MFMAs in four groups of (K, V) x two k-steps; the reads of group g + 1 are in flight under group g
+            sT[0] = BW_MFMA(ka0, qf[0], c_lse); dP[0] = BW_MFMA(va0, dof[0], c_del);
+            sT[0] = BW_MFMA(ka1, qf[1], sT[0]); dP[0] = BW_MFMA(va1, dof[1], dP[0]);
+            BW_FENCE()
+            ka0 = rd(sK, 1, 0); va0 = rd(sV, 1, 0); ka1 = rd(sK, 1, 1); va1 = rd(sV, 1, 1);
+            BW_FENCE()
+            sT[0] = BW_MFMA(kb0, qf[2], sT[0]); dP[0] = BW_MFMA(vb0, dof[2], dP[0]);
+            sT[0] = BW_MFMA(kb1, qf[3], sT[0]); dP[0] = BW_MFMA(vb1, dof[3], dP[0]);
+            BW_FENCE()
+            kb0 = rd(sK, 1, 2); vb0 = rd(sV, 1, 2); kb1 = rd(sK, 1, 3); vb1 = rd(sV, 1, 3);
+            BW_FENCE()
+            sT[1] = BW_MFMA(ka0, qf[0], c_lse); dP[1] = BW_MFMA(va0, dof[0], c_del);
+            sT[1] = BW_MFMA(ka1, qf[1], sT[1]); dP[1] = BW_MFMA(va1, dof[1], dP[1]);
+            sT[1] = BW_MFMA(kb0, qf[2], sT[1]); dP[1] = BW_MFMA(vb0, dof[2], dP[1]);
+            sT[1] = BW_MFMA(kb1, qf[3], sT[1]); dP[1] = BW_MFMA(vb1, dof[3], dP[1]);
+            BW_FENCE()
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto seg_y = [&](int t) {
+        prefetch_g(t);
+        BW_FENCE()
+#ifdef ORV_BW_ABL_NOY
+        asm volatile("" ::"v"(sT[0]), "v"(sT[1]), "v"(dP[0]), "v"(dP[1]));
+        return;
+#endif
+        const bool tail = ragged && t == nt - 1;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pv = __builtin_amdgcn_exp2f(sT[kb][r]);
+                if (tail) pv = (t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.S) ? 0.f : pv;
+                sT[kb][r] = pv * dP[kb][r];      // dS^T = P (dP - delta)
+            }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dsf[kk].u[i] = pack2bf(sT[kk >> 1][(kk & 1) * 8 + 2 * i], sT[kk >> 1][(kk & 1) * 8 + 2 * i + 1]);
+    };
+
+    // prologue: K_0 (first half); V_0 and V_1 (second half)
+    stage(0);
+    if (grp == 1) stage(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BW_BAR()
+    const bool act = __builtin_amdgcn_readfirstlane((int)(q0 < p.S)) != 0;
+    if (grp == 0) {
+        if (act) {
+            for (int t = 0; t < nt; ++t) {
+                seg_x(t, [&]() { stage(t + 1); });              // K_{t+1} -> slot of K_{t-2} (last read in the partners' X_{t-1})
+                BW_BAR()
+                seg_y(t);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                BW_BAR()
+            }
+            seg_x(nt, [&]() {});
+        } else {
+            for (int t = 0; t < nt; ++t) {
+                stage(t + 1);
+                BW_BAR()
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                BW_BAR()
+            }
+        }
+        BW_BAR()
+    } else {
+        BW_BAR()
+        if (act) {
+            for (int t = 0; t < nt; ++t) {
+                seg_x(t, [&]() {});
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // V_{t+1} landed (issued in Y_{t-1} / the prologue)
+                BW_BAR()
+                stage(t + 2);                                    // V_{t+2} -> slot of V_t (last read in this half's X_t)
+                BW_FENCE()
+                seg_y(t);
+                BW_BAR()
+            }
+            seg_x(nt, [&]() {});
+        } else {
+            for (int t = 0; t < nt; ++t) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                BW_BAR()
+                stage(t + 2);
+                BW_BAR()
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int q = q0 + l31;
+    if (q < p.S) store_row16(p.dqkv + (row0 + q) * p.ld_dqkv + h * 64 + hi * 8, dq, p.scale);
+}
+
+// ===== pass B, ping-pong: dK, dV (one lane = one key row; loop over query tiles).
+// X_t = { dV^T += dO_{t-1}^T P_{t-1}, dK^T += Q'_{t-1}^T dS_{t-1} (16 MFMAs, transposing reads) ; S_t = Q'_t K^T - lse, dP_t = dO_t V^T - delta
+// (16 MFMAs, ds_read_b128; -lse / -delta of the tile's 64 query rows enter through the accumulator init, from LDS) } ;
+// Y_t = { P = exp2(S), dS = P dP, bf16 pack of both }.  Q' and dO tiles: three slots each; waves 0-3 stage Q' (+ the lse
+// vector) one tile ahead, waves 4-7 dO (+ the delta vector) two tiles ahead.
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[6 * TILE + 6 * 256];   // Q' slots 0-2 | dO slots 0-2 | lse x3 | delta x3
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wq = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5, sw = swz(l31);
+    const int nkt = (p.S + 255) / 256;
+    const int item = orv_xcd_item(blockIdx.x, gridDim.x);
+    const int bh = item / nkt, h = bh % p.H, b = bh / p.H;
+    const int k0 = (item % nkt) * 256 + wave * 32;
+    const int D = p.H * 64;
+    const long row0 = (long)b * p.S;
+    const int kr = min(k0 + l31, p.S - 1);
+    bf16x8 kf[4], vf[4];   // B operands: this lane's key row of K and V
+    {
+        const bf16_t* kp = p.qkv + (row0 + kr) * p.ld + D + h * 64 + hi * 8;
+        const bf16_t* vp = p.qkv + (row0 + kr) * p.ld + 2 * D + h * 64 + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { kf[ks] = *(const bf16x8*)(kp + ks * 16); vf[ks] = *(const bf16x8*)(vp + ks * 16); }
+    }
+    const int nt = (p.S + 63) / 64;
+    const bool ragged = (p.S & 63) != 0;
+    const long hb = (long)(b * p.H + h);
+    auto src_of = [&](int j, int t) {
+        const int sr = wq * 16 + j * 8 + (lane >> 3), slot = lane & 7;
+        const long r = row0 + min(t * 64 + sr, p.S - 1);
+        return (grp == 0 ? p.qkv + r * p.ld : p.dout + r * p.ld_do) + h * 64 + (slot ^ swz(sr)) * 8;
+    };
+    const bf16_t* const sbase0 = src_of(0, 0);
+    const bf16_t* const sbase1 = src_of(1, 0);
+    const long tstep = 64 * (grp == 0 ? p.ld : p.ld_do);
+    char* const sdst = smem + grp * 3 * TILE + wq * 2048;
+    const float* const vsrc = (grp == 0 ? p.neg_lse2 : p.neg_delta) + hb * p.s_pad + lane;
+    char* const vdst = smem + 6 * TILE + grp * 3 * 256;
+    auto stage = [&](int t) {
+        if (t >= nt) return;
+#ifdef ORV_BW_ABL_NODMA
+        if (t > 1) return;
+#endif
+        char* const d = sdst + (t % 3) * TILE;
+        if (__builtin_expect(ragged && t == nt - 1, 0)) {
+            glds16_asm(src_of(0, t), d);
+            glds16_asm(src_of(1, t), d + 1024);
+        } else {
+            glds16_asm(sbase0 + (long)t * tstep, d);
+            glds16_asm(sbase1 + (long)t * tstep, d + 1024);
+        }
+        // the tile's 64-float vector travels by LDS-DMA too (a register round trip would put a vmcnt(0) behind the tile loads)
+        if (wq == 0) glds4_asm(vsrc + t * 64, vdst + (t % 3) * 256);
+    };
+    f32x16 dk[2], dv[2], sS[2], dP[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dk[i][e] = 0.f; dv[i][e] = 0.f; sS[i][e] = 0.f; dP[i][e] = 0.f; }
+    union { bf16x8 v; uint32_t u[4]; } pf[4], dsf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pf[i].u[e] = 0u; dsf[i].u[e] = 0u; }
+    const int row_off = l31 * 128;
+    const int t00 = tr_off(lane, 0, 0), t01 = tr_off(lane, 0, 1), t10 = tr_off(lane, 1, 0), t11 = tr_off(lane, 1, 1);
+
+    // transposing-read fragments of the gradient GEMMs, k-step 0 (dO^T and Q'^T, two d blocks each: 16 registers - k-step 1 as
+    // well does not fit beside the 192 registers of state): fetched at the top of the vector segment Y_{t-1} and held across the
+    // barrier, so X_t opens with MFMAs instead of an LDS round trip
+    bf16x8 o0 = kf[0], o1 = kf[0], g0_ = kf[0], g1_ = kf[0];
+    auto prefetch_g = [&](int t) {                                 // fragments of tile t for the gradient part of X_{t+1}
+        const char* sQp = smem + (t % 3) * TILE;
+        const char* sOp = smem + 3 * TILE + (t % 3) * TILE;
+        o0 = tr_pair(sOp + t00, sOp + t01); o1 = tr_pair(sOp + t10, sOp + t11);
+        g0_ = tr_pair(sQp + t00, sQp + t01); g1_ = tr_pair(sQp + t10, sQp + t11);
+    };
+    auto seg_x = [&](int t, auto stage_q) {
+        __builtin_amdgcn_s_setprio(1);
+        const char* sQ = smem + (t % 3) * TILE + row_off;
+        const char* sO = smem + 3 * TILE + (t % 3) * TILE + row_off;
+        const float* sL = (const float*)(smem + 6 * TILE + (t % 3) * 256);
+        const float* sDl = (const float*)(smem + 6 * TILE + 3 * 256 + (t % 3) * 256);
+        auto rd = [&](const char* base, int qb, int ks) {
+#ifdef ORV_BW_ABL_NOB128
+            bf16x8 z; asm volatile("" : "=v"(z)); return z;
+#endif
+            return *(const bf16x8*)(base + qb * 4096 + (((ks * 2 + hi) ^ sw) * 16)); };
+        auto init = [&](const float* v, int qb) {   // accumulator init: v[q(r)], q(r) = qb * 32 + (r & 3) + 8 (r >> 2) + 4 hi
+            f32x16 c;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 a = *(const float4*)(v + qb * 32 + g * 8 + hi * 4);
+                c[g * 4] = a.x; c[g * 4 + 1] = a.y; c[g * 4 + 2] = a.z; c[g * 4 + 3] = a.w;
+            }
+            return c;
+        };
+        bf16x8 qa0, oa0, qa1, oa1, qb0, ob0, qb1, ob1, o2, o3, g2_, g3_;
+        if (t > 0) {
+            const char* sQp = smem + ((t - 1) % 3) * TILE;               // Q' and dO of the previous tile, transposed reads
+            const char* sOp = smem + 3 * TILE + ((t - 1) % 3) * TILE;
+            o2 = tr_pair(sOp + 2048 + t00, sOp + 2048 + t01); o3 = tr_pair(sOp + 2048 + t10, sOp + 2048 + t11);
+            g2_ = tr_pair(sQp + 2048 + t00, sQp + 2048 + t01); g3_ = tr_pair(sQp + 2048 + t10, sQp + 2048 + t11);
+        }
+        BW_FENCE()
+        stage_q();
+        BW_FENCE()
+        if (t > 0) {
+            const char* sQp = smem + ((t - 1) % 3) * TILE;
+            const char* sOp = smem + 3 * TILE + ((t - 1) % 3) * TILE;
+            // per k-step: dv[0], dv[1] += dO^T[db] P ; dk[0], dk[1] += Q'^T[db] dS   (4 fragments, 4 MFMAs)
+            dv[0] = BW_MFMA(o0, pf[0].v, dv[0]); dv[1] = BW_MFMA(o1, pf[0].v, dv[1]);
+            dk[0] = BW_MFMA(g0_, dsf[0].v, dk[0]); dk[1] = BW_MFMA(g1_, dsf[0].v, dk[1]);
+            BW_FENCE()
+            o0 = tr_pair(sOp + 4096 + t00, sOp + 4096 + t01); o1 = tr_pair(sOp + 4096 + t10, sOp + 4096 + t11);
+            g0_ = tr_pair(sQp + 4096 + t00, sQp + 4096 + t01); g1_ = tr_pair(sQp + 4096 + t10, sQp + 4096 + t11);
+            BW_FENCE()
+            dv[0] = BW_MFMA(o2, pf[1].v, dv[0]); dv[1] = BW_MFMA(o3, pf[1].v, dv[1]);
+            dk[0] = BW_MFMA(g2_, dsf[1].v, dk[0]); dk[1] = BW_MFMA(g3_, dsf[1].v, dk[1]);
+            BW_FENCE()
+            o2 = tr_pair(sOp + 6144 + t00, sOp + 6144 + t01); o3 = tr_pair(sOp + 6144 + t10, sOp + 6144 + t11);
+            g2_ = tr_pair(sQp + 6144 + t00, sQp + 6144 + t01); g3_ = tr_pair(sQp + 6144 + t10, sQp + 6144 + t11);
+            BW_FENCE()
+            dv[0] = BW_MFMA(o0, pf[2].v, dv[0]); dv[1] = BW_MFMA(o1, pf[2].v, dv[1]);
+            dk[0] = BW_MFMA(g0_, dsf[2].v, dk[0]); dk[1] = BW_MFMA(g1_, dsf[2].v, dk[1]);
+            BW_FENCE()
+            if (t < nt) { qa0 = rd(sQ, 0, 0); oa0 = rd(sO, 0, 0); qa1 = rd(sQ, 0, 1); oa1 = rd(sO, 0, 1); }   // first score fragments: under the last gradient MFMAs
+            BW_FENCE()
+            dv[0] = BW_MFMA(o2, pf[3].v, dv[0]); dv[1] = BW_MFMA(o3, pf[3].v, dv[1]);
+            dk[0] = BW_MFMA(g2_, dsf[3].v, dk[0]); dk[1] = BW_MFMA(g3_, dsf[3].v, dk[1]);
+            BW_FENCE()
+        } else {
+            qa0 = rd(sQ, 0, 0); oa0 = rd(sO, 0, 0); qa1 = rd(sQ, 0, 1); oa1 = rd(sO, 0, 1);
+            BW_FENCE()
+        }
+        if (t < nt) {
+            f32x16 cl = init(sL, 0), cd = init(sDl, 0);
+            qb0 = rd(sQ, 0, 2); ob0 = rd(sO, 0, 2); qb1 = rd(sQ, 0, 3); ob1 = rd(sO, 0, 3);
+            BW_FENCE()
+            sS[0] = BW_MFMA(qa0, kf[0], cl); dP[0] = BW_MFMA(oa0, vf[0], cd);
+            sS[0] = BW_MFMA(qa1, kf[1], sS[0]); dP[0] = BW_MFMA(oa1, vf[1], dP[0]);
+            BW_FENCE()
+            qa0 = rd(sQ, 1, 0); oa0 = rd(sO, 1, 0); qa1 = rd(sQ, 1, 1); oa1 = rd(sO, 1, 1);
+            cl = init(sL, 1); cd = init(sDl, 1);
+            BW_FENCE()
+            sS[0] = BW_MFMA(qb0, kf[2], sS[0]); dP[0] = BW_MFMA(ob0, vf[2], dP[0]);
+            sS[0] = BW_MFMA(qb1, kf[3], sS[0]); dP[0] = BW_MFMA(ob1, vf[3], dP[0]);
+            BW_FENCE()
+            qb0 = rd(sQ, 1, 2); ob0 = rd(sO, 1, 2); qb1 = rd(sQ, 1, 3); ob1 = rd(sO, 1, 3);
+            BW_FENCE()
+            sS[1] = BW_MFMA(qa0, kf[0], cl); dP[1] = BW_MFMA(oa0, vf[0], cd);
+            sS[1] = BW_MFMA(qa1, kf[1], sS[1]); dP[1] = BW_MFMA(oa1, vf[1], dP[1]);
+            sS[1] = BW_MFMA(qb0, kf[2], sS[1]); dP[1] = BW_MFMA(ob0, vf[2], dP[1]);
+            sS[1] = BW_MFMA(qb1, kf[3], sS[1]); dP[1] = BW_MFMA(ob1, vf[3], dP[1]);
+            BW_FENCE()
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto seg_y = [&](int t) {
+        prefetch_g(t);
+        BW_FENCE()
+#ifdef ORV_BW_ABL_NOY
+        asm volatile("" ::"v"(sS[0]), "v"(sS[1]), "v"(dP[0]), "v"(dP[1]));
+        return;
+#endif
+        const bool tail = ragged && t == nt - 1;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // (rows of keys >= S compute garbage that is never stored; only query rows >= S must not contribute)
+                float pv = __builtin_amdgcn_exp2f(sS[qb][r]);
+                if (tail) pv = (t * 64 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.S) ? 0.f : pv;
+                sS[qb][r] = pv;                 // P
+                dP[qb][r] = pv * dP[qb][r];     // dS
+            }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pf[kk].u[i] = pack2bf(sS[kk >> 1][(kk & 1) * 8 + 2 * i], sS[kk >> 1][(kk & 1) * 8 + 2 * i + 1]);
+                dsf[kk].u[i] = pack2bf(dP[kk >> 1][(kk & 1) * 8 + 2 * i], dP[kk >> 1][(kk & 1) * 8 + 2 * i + 1]);
+            }
+    };
+
+    // prologue: Q'_0 (+ lse_0) by the first half; dO_0, dO_1 (+ delta) by the second half
+    stage(0);
+    if (grp == 1) stage(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BW_BAR()
+    const bool act = __builtin_amdgcn_readfirstlane((int)(k0 < p.S)) != 0;
+    if (grp == 0) {
+        if (act) {
+            for (int t = 0; t < nt; ++t) {
+                seg_x(t, [&]() { stage(t + 1); });
+                BW_BAR()
+                seg_y(t);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                BW_BAR()
+            }
+            seg_x(nt, [&]() {});
+        } else {
+            for (int t = 0; t < nt; ++t) {
+                stage(t + 1);
+                BW_BAR()
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                BW_BAR()
+            }
+        }
+        BW_BAR()
+    } else {
+        BW_BAR()
+        if (act) {
+            for (int t = 0; t < nt; ++t) {
+                seg_x(t, [&]() {});
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                BW_BAR()
+                stage(t + 2);                                    // dO_{t+2} -> slot of dO_{t-1} (last read in this half's X_t)
+                BW_FENCE()
+                seg_y(t);
+                BW_BAR()
+            }
+            seg_x(nt, [&]() {});
+        } else {
+            for (int t = 0; t < nt; ++t) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                BW_BAR()
+                stage(t + 2);
+                BW_BAR()
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int key = k0 + l31;
+    if (key < p.S) {
+        // dk = scale * dS_raw^T q = dS_raw^T q' / log2(e)
+        store_row16(p.dqkv + (row0 + key) * p.ld_dqkv + D + h * 64 + hi * 8, dk, 0.6931471805599453f);
+        store_row16(p.dqkv + (row0 + key) * p.ld_dqkv + 2 * D + h * 64 + hi * 8, dv, 1.0f);
+    }
+}
+#undef BW_BAR
+#undef BW_FENCE
+#undef BW_MFMA
+
 // ---- adjoint of orv_qkv_prep on the q and k thirds, in place on dqkv (dq, dk arrive as gradients of the normalised,
 //      rotated, un-premultiplied q / k): inverse RoPE rotation, LayerNorm(64) backward; norm_q / norm_k weight gradients.
 __global__ __launch_bounds__(256) void qkv_prep_bwd_kernel(const bf16_t* __restrict__ qkv_raw, bf16_t* __restrict__ dqkv,
@@ -435,12 +964,20 @@ extern "C" int orv_head_transpose(const void* src, int ld, int col0, void* dst, 
     return orv_check_launch("orv_head_transpose");
 }
 
+// qT / kT / doT (per-head transposed copies written by orv_head_transpose) feed the two-pass kernels of rounds 1-2 only; with all
+// three NULL - what the host passes since round 3 - the ping-pong kernels read K^T / Q'^T / dO^T with transposing LDS reads from the
+// row-major tiles.  ORV_ATTN_BWD_PP=0 + non-NULL copies: the old kernels (A/B).
 extern "C" int orv_attention_bwd(const void* qkv, int ld_qkv, const void* qT, const void* kT, const void* out,
                                  const void* dout, int ld_out, const void* doT, const float* lse, float* neg_lse2,
                                  float* neg_delta, void* dqkv, int ld_dqkv, int B, int S, int H, int s_pad, float scale,
                                  void* stream) {
-    ORV_REQUIRE(qkv && qT && kT && out && dout && doT && lse && neg_lse2 && neg_delta && dqkv, "orv_attention_bwd: null operand");
+    ORV_REQUIRE(qkv && out && dout && lse && neg_lse2 && neg_delta && dqkv, "orv_attention_bwd: null operand");
     ORV_REQUIRE(s_pad == ((S + 63) / 64) * 64, "orv_attention_bwd: s_pad must be S rounded up to 64");
+    static int use_pp = -1;
+    if (use_pp < 0) { const char* e = getenv("ORV_ATTN_BWD_PP"); use_pp = (e && atoi(e) == 0) ? 0 : 1; }
+    const bool have_t = qT && kT && doT;
+    const bool pp = (use_pp || !have_t) && ld_dqkv % 8 == 0 && ((uintptr_t)dqkv & 15) == 0;
+    ORV_REQUIRE(pp || have_t, "orv_attention_bwd: the transposed-copy kernels need qT, kT and doT (or a 16-byte aligned dqkv for the ping-pong kernels)");
     hipStream_t st = (hipStream_t)stream;
     const long groups = (long)B * s_pad * H;
     hipLaunchKernelGGL(bwd_prep_kernel, dim3((unsigned)((groups * 8 + 255) / 256)), dim3(256), 0, st, (const bf16_t*)out,
@@ -450,8 +987,13 @@ extern "C" int orv_attention_bwd(const void* qkv, int ld_qkv, const void* qT, co
     a.dout = (const bf16_t*)dout; a.ld_do = ld_out; a.neg_lse2 = neg_lse2; a.neg_delta = neg_delta;
     a.dqkv = (bf16_t*)dqkv; a.ld_dqkv = ld_dqkv; a.B = B; a.S = S; a.H = H; a.s_pad = s_pad; a.scale = scale;
     dim3 grid(((S + 255) / 256) * H * B);   // 1-D: orv_xcd_item hands head-major items to the XCDs
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(512), 0, st, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(512), 0, st, a);
+    if (pp) {
+        hipLaunchKernelGGL(attn_bwd_dq_pp_kernel, grid, dim3(512), 0, st, a);
+        hipLaunchKernelGGL(attn_bwd_dkv_pp_kernel, grid, dim3(512), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(512), 0, st, a);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(512), 0, st, a);
+    }
     return orv_check_launch("orv_attention_bwd");
 }
 

@@ -15,6 +15,7 @@ its activations with plain torch ops on those few-kB tensors; all matmuls, inclu
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -92,8 +93,11 @@ class _AttnBufs:
 
     def __init__(self, B_, S_, heads, dev):
         self.s_pad = (S_ + 63) // 64 * 64
-        z = lambda: torch.zeros(B_, heads, 64, self.s_pad, dtype=BF16, device=dev)
-        self.qT, self.kT, self.doT = z(), z(), z()
+        # the ping-pong backward kernels read K^T / Q'^T / dO^T with transposing LDS reads: no per-head transposed copies
+        self.qT = self.kT = self.doT = None
+        if os.environ.get("ORV_ATTN_BWD_PP", "1") == "0":
+            z = lambda: torch.zeros(B_, heads, 64, self.s_pad, dtype=BF16, device=dev)
+            self.qT, self.kT, self.doT = z(), z(), z()
         self.nl = torch.empty(B_, heads, self.s_pad, dtype=torch.float32, device=dev)
         self.nd = torch.empty(B_, heads, self.s_pad, dtype=torch.float32, device=dev)
 
@@ -117,10 +121,11 @@ def _attn_backward(at, ly, xn, datt, bufs, B_, S_, n_text, heads, rope, scale, g
     D = heads * 64
     M_ = B_ * S_
     dev = xn.device
-    ops.head_transpose(ly.qkvn, 0, bufs.qT, B_, S_, heads, bufs.s_pad, ld=3 * D)
-    ops.head_transpose(ly.qkvn, D, bufs.kT, B_, S_, heads, bufs.s_pad, ld=3 * D)
-    ops.head_transpose(datt, 0, bufs.doT, B_, S_, heads, bufs.s_pad, ld=D)
     dqkv = torch.empty(M_, 3 * D, dtype=BF16, device=dev)
+    if bufs.qT is not None:              # ORV_ATTN_BWD_PP=0: the two-pass kernels of rounds 1-2 on per-head transposed copies (A/B)
+        ops.head_transpose(ly.qkvn, 0, bufs.qT, B_, S_, heads, bufs.s_pad, ld=3 * D)
+        ops.head_transpose(ly.qkvn, D, bufs.kT, B_, S_, heads, bufs.s_pad, ld=3 * D)
+        ops.head_transpose(datt, 0, bufs.doT, B_, S_, heads, bufs.s_pad, ld=D)
     ops.attention_bwd(ly.qkvn, bufs.qT, bufs.kT, ly.att, datt, bufs.doT, ly.lse, bufs.nl, bufs.nd, dqkv, B_, S_, heads,
                       bufs.s_pad, scale)
     dgq, dbq, dgk, dbk = z32(64), z32(64), z32(64), z32(64)

@@ -1,7 +1,7 @@
 """GPU: the training path (forward that saves activations + hand-written backward, attached to autograd) against torch
 autograd through the CPU fp32 oracle on the same weights/inputs.  Per-parameter gradient rel-L2 bound (bf16 params, bf16
-gradients, 2-30 chained bf16 GEMMs): 3e-2 in general, 6e-2 for the q / k projection biases and the qk-LayerNorm parameters
-(``grad_bound``); loss-level check, and an optimizer step that lowers the loss."""
+gradients, 2-30 chained bf16 GEMMs): 3e-2 in general, 6e-2 for the q projection bias and the qk-LayerNorm parameters, 1e-1 for
+the k projection bias (``grad_bound``); loss-level check, and an optimizer step that lowers the loss."""
 import pytest
 import torch
 
@@ -25,7 +25,13 @@ def grad_bound(name: str) -> float:
     smaller than the summed magnitudes, and the bf16 rounding of the individual terms (2^-9 each) does not shrink with it.
     Every other parameter (all GEMM weights among them) sits at a p90 of ~1e-2 and is held to 3e-2, so a regression of a few x
     in any weight gradient fails (profiles/r2_parity_error_distribution.txt)."""
-    qk = (".to_q.bias", ".to_k.bias", ".norm_q.", ".norm_k.")
+    if ".to_k.bias" in name:
+        # the extreme member of the family: shifting EVERY key of a head by one vector would leave the softmax untouched (a per-query
+        # constant in the scores) were it not for norm_k's centring / scaling of each key - the gradient is that second-order
+        # residue, 3-4 orders of magnitude below the summed magnitudes at S = 3226 (measured 7.4e-2 through four full-width blocks,
+        # <= 5.6e-2 on the golden configs)
+        return 1e-1
+    qk = (".to_q.bias", ".norm_q.", ".norm_k.")
     return 6e-2 if any(t in name for t in qk) else 3e-2
 
 

@@ -41,3 +41,4 @@ with open(out+'/summary.txt','w') as fh:
             for k in ("SQ_WAIT_ANY","SQ_WAIT_INST_ANY","SQ_ACTIVE_INST_ANY","SQ_ACTIVE_INST_VALU","SQ_ACTIVE_INST_LDS","SQ_WAIT_INST_LDS","SQ_ACTIVE_INST_VMEM"):
                 if k in tot: emit(f"{k}/SQ_WAVE_CYCLES {tot[k]/tot['SQ_WAVE_CYCLES']:.3f}")
 PY
+find $OUT -name "*.csv" -size +200k -delete

@@ -14,6 +14,9 @@ ops.head_transpose(qkv, 0, qT, B, S, H, s_pad, ld=3 * D); ops.head_transpose(qkv
 ops.head_transpose(dout, 0, doT, B, S, H, s_pad, ld=D)
 nl = torch.empty(B, H, s_pad, dtype=torch.float32, device=dev); nd = torch.empty_like(nl)
 dqkv = torch.empty_like(qkv)
+import os
+if os.environ.get("ORV_ATTN_BWD_PP", "1") != "0":
+    qT = kT = doT = None          # ping-pong kernels: no transposed copies
 f = lambda: ops.attention_bwd(qkv, qT, kT, out, dout, doT, lse, nl, nd, dqkv, B, S, H, s_pad, 1.0 / 1.4426950408889634)
 for _ in range(3): f()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
