@@ -199,7 +199,7 @@ def train_mode(args, model, latents, image_latents, prompt, actions, sched, dev,
 
     is5b = cfg is not None and cfg.get("patch_size_t") is not None
     if getattr(args, "grad_ckpt", False):
-        model.enable_gradient_checkpointing()       # accepted; nothing is recomputed here (all activations stay in HBM)
+        model.enable_gradient_checkpointing()       # block-level activation recompute (BASELINE configs[4] names it)
 
     def step():
         # orv_amd.sft.sft_step = train script :1005-1104 (noise + timestep draw, add_noise, forward, x0 loss, backward,
@@ -247,7 +247,7 @@ def train_mode(args, model, latents, image_latents, prompt, actions, sched, dev,
             "achieved_tflops_attn_ffn": round(value * fl / 1e12, 1), "final_loss": float(loss),
             "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
             "config": {"workload": ("configs[4]: CogVideoX1.5-5B SFT step, DROID 256x384x29f latents [B,8,16,32,48], p_t=2, RoPE, "
-                                    "ofs, bf16 params+grads, all activations resident (no recompute)") if is5b else
+                                    "ofs, bf16 params+grads, " + ("activation checkpointing (block-level recompute)" if getattr(args, "grad_ckpt", False) else "all activations resident (no recompute)")) if is5b else
                                    "configs[2]: CogVideoX-2B SFT step, 320x480x17f latents, bf16 params+grads, DP",
                        "batch_per_gpu": B, "num_layers": c_["num_layers"], "seq_len": S_,
                        "parallelism": f"dp{world} (one RCCL all-reduce/step)",
@@ -307,6 +307,8 @@ def main():
     ap.add_argument("--model", choices=["2b", "5b"], default="2b",
                     help="2b = the headline (BASELINE configs[1]/[2]); 5b = configs[4] (CogVideoX1.5-5B, DROID 256x384x29f, p_t=2, "
                          "RoPE, ofs) - train mode only")
+    ap.add_argument("--grad-ckpt", dest="grad_ckpt", action="store_true",
+                    help="train mode: gradient checkpointing (block inputs kept, activations recomputed in the backward)")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE-decode leg (frames/s including decode)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch the ranks, rendezvous (gloo, no GPU work), print the ranks seen and exit: checks the launcher")

@@ -333,11 +333,17 @@ def forward_train(model, hidden_states, encoder_hidden_states, controls, timeste
         mv.bufs = _AttnBufs(mv.Bm, mv.Sm, heads, dev)
         # gate of (b f)-batch row groups {text, view 0, view 1, ...}: text rows of the attention output are dropped (zero gate)
         mv.grp = ops.groups(mv.Sm, mv.n_text, Pm)
-        mv.layers = []
         sv.mv = mv
-    sv.layers = []
-    for i, blk in enumerate(model.transformer_blocks):
-        if sv.mv is not None:
+    # One transformer block (+ its multiview block) as a function of its input: the forward proper, and - under gradient
+    # checkpointing - the recompute the backward asks for (the reference wraps every block in torch.utils.checkpoint,
+    # cogvideox_control.py:867-899; enabled by config/traj_image_2b_multiview.yaml:33 and BASELINE configs[4]).  Everything else it
+    # needs (modulation tables, row maps, RoPE tables, scratch) lives in `sv` / this closure for the lifetime of the step.
+    mv = sv.mv
+    rope_view = sv.rope_view
+    def run_block(i, x):
+        blk = model.transformer_blocks[i]
+        mly = None
+        if mv is not None:
             mblk, mly, m = model.mv_blocks[i], _Saved(), mv.mod[i]
             mly.x_in = x
             xn = e(M, D)
@@ -345,14 +351,13 @@ def forward_train(model, hidden_states, encoder_hidden_states, controls, timeste
                                    2 * 3 * D, 3 * D, mv.grp0, B, D, c.norm_eps)
             mly.xm = e(mv.R, D)
             ops.gather_rows(xn, mv.idx, mly.xm, mv.R, D)
-            _attn_forward(mblk.attn1, mly.xm, mly, mv.bufs, mv.Bm, mv.Sm, mv.n_text, heads, sv.rope_view, scale)
+            _attn_forward(mblk.attn1, mly.xm, mly, mv.bufs, mv.Bm, mv.Sm, mv.n_text, heads, rope_view, scale)
             mly.ao, mly.y = e(mv.R, D), e(mv.R, D)
             wo = mblk.attn1.to_out[0]
             ops.gemm(mly.att, wo.weight, wo.bias, mly.ao, mv.R, D, D)
             ops.gemm(mly.ao, mblk.proj_out.weight, mblk.proj_out.bias, mly.y, mv.R, D, D)
             x = x.clone()
             ops.scatter_gated_rows(mly.y, mv.idx, m[:, 1, 2 * D:], 2 * 3 * D, x, mv.R, D, S, Nt)
-            mv.layers.append(mly)
         m1, m2 = mod[2 * i], mod[2 * i + 1]
         at = blk.attn1
         ly = _Saved()
@@ -374,8 +379,37 @@ def forward_train(model, hidden_states, encoder_hidden_states, controls, timeste
         x2, ly.y2 = e(M, D), e(M, D)
         ops.gemm(ly.h, f2.weight, f2.bias, x2, M, D, FF, epilogue=2, R=ly.x1, ldr=D, gate=m2[..., 2 * D:], gate_b=mb,
                  gate_g=mg, grp=grp, Y=ly.y2, ldy=D)
-        x = x2
-        sv.layers.append(ly)
+        return x2, ly, mly
+
+    # gradient checkpointing: keep only every block's INPUT (49.5 MB per block at B = 4 instead of ~0.94 GB of activations);
+    # `backward` rebuilds the block's activations with `sv.recompute(i)` right before it needs them - same kernels, same inputs,
+    # deterministic: gradients are bit-identical to the run that keeps everything
+    sv.checkpointed = bool(getattr(model, "gradient_checkpointing", False)) and model.training
+    checkpointed = sv.checkpointed
+    layers = sv.layers = []
+    if mv is not None:
+        mv.layers = []
+    for i in range(len(model.transformer_blocks)):
+        x_in = x
+        x, ly, mly = run_block(i, x)
+        if checkpointed:
+            stub = _Saved()
+            stub.block_input = x_in
+            ly, mly = stub, (None if mly is None else stub)
+        layers.append(ly)
+        if mv is not None:
+            mv.layers.append(mly)
+
+    def recompute(i):
+        """Rebuild block i's saved activations from its input (checkpointed step); frees them again when the caller drops them."""
+        _, ly, mly = run_block(i, layers[i].block_input)
+        layers[i] = ly
+        if mv is not None:
+            mv.layers[i] = mly
+    # (the closures reference `layers`, `mv` and locals, never `sv` itself: no reference cycle through sv.recompute, so a step's
+    #  activations are released by reference counting the moment the autograd node dies - a cycle here kept the previous step's
+    #  ~100 GB alive until the next garbage collection: 5B went from 329 to 889 ms per step and 105 to 200 GiB)
+    sv.recompute = recompute
     sv.x_last = x
     gv = ops.groups(Nv, 0, per_group)
     sv.vis, sv.vis2 = e(B * Nv, D), e(B * Nv, D)
@@ -512,6 +546,8 @@ def backward(model, sv, dout, drecon=None, grad_hook=None) -> Dict[int, torch.Te
         dmv = z32(L, B, 2, 3 * D)
         ones_gate = torch.ones(B, D, dtype=torch.float32, device=dev)
     for i in reversed(range(L)):
+        if sv.checkpointed:
+            sv.recompute(i)              # gradient checkpointing: this block's activations are rebuilt from its input now
         blk, ly = model.transformer_blocks[i], sv.layers[i]
         at = blk.attn1
         m1, m2 = sv.mod[2 * i], sv.mod[2 * i + 1]
@@ -590,6 +626,12 @@ def backward(model, sv, dout, drecon=None, grad_hook=None) -> Dict[int, torch.Te
                                        c.norm_eps)
             f32_to_param_grad(mblk.norm1.norm.weight, dg), f32_to_param_grad(mblk.norm1.norm.bias, db_)
             dx = dx_in
+        if sv.checkpointed:             # the recomputed activations of this block are dead: give the memory back
+            del ly
+            sv.layers[i] = None
+            if mv is not None:
+                mly = None
+                mv.layers[i] = None
 
     # ---- visual-guidance fuse (:846-858): x_vis += icl([x_vis + c0 | x_vis + c1]) ----
     pe = model.patch_embed

@@ -393,31 +393,52 @@ def test_full_width_5b_layer_gradients(layers):
         assert rel_l2(named[k].grad, ref_g[k]) <= grad_bound(k), (k, rel_l2(named[k].grad, ref_g[k]))
 
 
-def test_gradient_checkpointing_flag_is_accepted_and_changes_nothing():
+@pytest.mark.parametrize("name", ["fwd_actions", "fwd_multiview"])
+def test_gradient_checkpointing_recomputes_and_gives_identical_gradients(name):
     """The reference wraps every block in torch.utils.checkpoint when ``gradient_checkpointing`` is on
-    (cogvideox_control.py:867-899; train...sft.py:387-388) to fit 80 GB cards.  Here every activation the backward needs stays
-    resident (288 GB HBM, DESIGN.md §4 'Training step'): the flag is part of the surface, is honoured as 'nothing to recompute',
-    and must not change a single gradient bit-pattern beyond run-to-run noise."""
+    (cogvideox_control.py:867-899; train...sft.py:387-388; config/traj_image_2b_multiview.yaml:33).  Here the training forward
+    then keeps only every block's input and the backward rebuilds each block's activations from it (same kernels, same inputs):
+    every gradient must be BIT-identical to the run that keeps all activations, the saved state must really be the stubs
+    (no activation tensors alive between forward and backward), and the multiview blocks take part."""
+    from orv_amd import training
     from orv_amd.cogvideox_control import CogVideoXTransformer3DModelTraj
     dev = torch.device("cuda:0")
-    cfg, extra, ins, w, outs = load_golden("fwd_actions")
+    cfg, extra, ins, w, outs = load_golden(name)
     wout = torch.randn(outs["sample"].shape, generator=torch.Generator().manual_seed(1)).to(dev)
-    grads = []
+    grads, saved = [], []
     for ckpt in (False, True):
         m = CogVideoXTransformer3DModelTraj(**cfg)
         m.load_state_dict(w)
         m = m.to(dev, BF).train()
+        for p_ in m.parameters():
+            p_.requires_grad_(True)
         if ckpt:
             m.enable_gradient_checkpointing()
             assert m.gradient_checkpointing is True
-        m.action_embed.forced_mask = torch.tensor(extra["mask"])
-        out = m(ins["hidden_states"].to(dev, BF), ins["encoder_hidden_states"].to(dev, BF), {"actions": ins["actions"].to(dev)},
-                ins["timestep"].to(dev), return_dict=False)[0]
+        ctrl = {}
+        if "actions" in ins:
+            ctrl["actions"] = ins["actions"].to(dev)
+            m.action_embed.forced_mask = torch.tensor(extra["mask"])
+        out, _, _, sv = training.forward_train(m, ins["hidden_states"].to(dev, BF), ins["encoder_hidden_states"].to(dev, BF), ctrl,
+                                               ins["timestep"].to(dev), num_views=extra["num_views"])
+        saved.append([sorted(vars(ly)) for ly in sv.layers])
+        out = m(ins["hidden_states"].to(dev, BF), ins["encoder_hidden_states"].to(dev, BF), ctrl, ins["timestep"].to(dev),
+                return_dict=False, num_views=extra["num_views"])[0]
         (out.float() * wout).sum().backward()
-        grads.append({n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None})
-    assert grads[0].keys() == grads[1].keys()
+        grads.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert all(keys == ["block_input"] for keys in saved[1]) and all(len(keys) > 8 for keys in saved[0])
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 20
+    exact = 0
     for n in grads[0]:
-        assert rel_l2(grads[1][n], grads[0][n]) <= 2e-3, n
+        # GEMM-produced weight gradients of the token stream are deterministic -> bit-identical; sums taken with fp32 atomics
+        # (modulation tables, bias column sums, LayerNorm affine, the conditioning branch behind them) differ by summation order
+        # between ANY two runs
+        if n.endswith(".weight") and grads[0][n].ndim == 2 and (".ff." in n or ".attn1.to_" in n):
+            assert torch.equal(grads[1][n], grads[0][n]), n
+            exact += 1
+        else:
+            assert rel_l2(grads[1][n], grads[0][n]) <= 2e-3, n
+    assert exact >= 10
 
 
 def test_inplace_gradient_views_equal_the_copied_path():
