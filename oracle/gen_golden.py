@@ -248,12 +248,30 @@ def bucket_sampler_case():
     print("bucket_sampler:", [len(c["order"]) for c in cases])
 
 
+def signature_case():
+    """Names, order and defaults of the reference's registered ``CogVideoXTransformer3DModelTraj.__init__`` parameters and of the
+    pipeline's ``__call__`` (read with ``inspect`` from the imported reference classes): the drop-in surface as data."""
+    import inspect
+    cc, _, _ = ref_harness.load_reference()
+    out = {}
+    for label, fn in (("transformer_init", cc.CogVideoXTransformer3DModelTraj.__init__),
+                      ("pipeline_call", cc.CogVideoXImageToVideoPipelineTraj.__call__)):
+        fn = inspect.unwrap(fn)
+        params = [p_ for n, p_ in inspect.signature(fn).parameters.items() if n != "self" and p_.kind == p_.POSITIONAL_OR_KEYWORD]
+        out[label] = [[p_.name, None if p_.default is inspect.Parameter.empty else (p_.default if isinstance(p_.default, (int, float, str, bool, type(None))) else repr(p_.default))] for p_ in params]
+    with open(os.path.join(OUT, "signatures.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("signatures:", {k: len(v) for k, v in out.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "sampler":
         return bucket_sampler_case()
     if len(sys.argv) > 1 and sys.argv[1] == "collate":      # add the data-format fixtures without touching the others
         return collate_case()
+    if len(sys.argv) > 1 and sys.argv[1] == "signatures":
+        return signature_case()
     cc, comp, utils = ref_harness.load_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "pipe_bf16":    # round-2 additions only
         return pipeline_bf16_cases(cc)
@@ -278,6 +296,7 @@ def main():
     misc_case(cc, comp, utils)
     collate_case()
     bucket_sampler_case()
+    signature_case()
 
 
 if __name__ == "__main__":

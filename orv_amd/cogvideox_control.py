@@ -282,10 +282,23 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
 
     config_name = "config.json"
 
-    def __init__(self, **kwargs):
+    # the reference's registered signature (:452-494): same names, order and defaults, positional use included
+    def __init__(self, num_attention_heads: int = 30, attention_head_dim: int = 64, in_channels: int = 16,
+                 out_channels: Optional[int] = 16, flip_sin_to_cos: bool = True, freq_shift: int = 0, time_embed_dim: int = 512,
+                 ofs_embed_dim: Optional[int] = None, text_embed_dim: int = 4096, num_layers: int = 30, dropout: float = 0.0,
+                 attention_bias: bool = True, sample_width: int = 90, sample_height: int = 60, sample_frames: int = 49,
+                 patch_size: int = 2, patch_size_t: Optional[int] = None, temporal_compression_ratio: int = 4,
+                 max_text_seq_length: int = 226, activation_fn: str = "gelu-approximate", timestep_activation_fn: str = "silu",
+                 norm_elementwise_affine: bool = True, norm_eps: float = 1e-5, spatial_interpolation_scale: float = 1.875,
+                 temporal_interpolation_scale: float = 1.0, use_rotary_positional_embeddings: bool = False,
+                 use_learned_positional_embeddings: bool = False, patch_bias: bool = True,
+                 loaded_pretrained_model_name_or_path: Optional[str] = None, modulate_encoder_hidden_states: bool = False,
+                 num_control_blocks: int = 12, recon_action: bool = False, visual_guidance: bool = False,
+                 num_control_keys: int = 2, multiview: bool = False, max_n_view: int = 3, from_t2v: bool = False, **kwargs):
+        given = {k: v for k, v in locals().items() if k in _CONFIG_DEFAULTS}
         super().__init__()
-        unknown = {k: v for k, v in kwargs.items() if k not in _CONFIG_DEFAULTS and not k.startswith("_")}
-        cfg = {**_CONFIG_DEFAULTS, **{k: v for k, v in kwargs.items() if k in _CONFIG_DEFAULTS}}
+        unknown = {k: v for k, v in kwargs.items() if not k.startswith("_")}
+        cfg = {**_CONFIG_DEFAULTS, **given}
         self._extra_config = unknown
         self.config = FrozenConfig(cfg)
         c = self.config

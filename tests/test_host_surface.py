@@ -309,3 +309,28 @@ def test_attention_score_bound_holds_on_random_layernorm_outputs():
     prime_score_bounds(many, 0.125)                            # batched form == per-module form
     for m in many:
         assert m._bound is not None and math.isclose(m.score_bound(0.125), 1.02 * 8 * 8 * 0.125 * 1.4426950408889634, rel_tol=1e-6)
+
+
+def test_constructor_and_call_signatures_equal_the_reference():
+    """Names, order and defaults of ``CogVideoXTransformer3DModelTraj.__init__`` (the 37 registered config arguments, positional use
+    included) and of ``CogVideoXImageToVideoPipelineTraj.__call__`` against tests/golden/signatures.json, which
+    oracle/gen_golden.py wrote with ``inspect`` from the imported reference classes (cogvideox_control.py:452-494, :1228-1257)."""
+    import inspect
+    import json
+    import os
+    from orv_amd.cogvideox_control import CogVideoXImageToVideoPipelineTraj, CogVideoXTransformer3DModelTraj
+    with open(os.path.join(os.path.dirname(__file__), "golden", "signatures.json")) as f:
+        ref = json.load(f)
+
+    def sig(fn):
+        out = []
+        for n, p_ in inspect.signature(fn).parameters.items():
+            if n == "self" or p_.kind != p_.POSITIONAL_OR_KEYWORD:
+                continue
+            d = p_.default
+            out.append([n, None if d is inspect.Parameter.empty else (d if isinstance(d, (int, float, str, bool, type(None))) else repr(d))])
+        return out
+    assert sig(CogVideoXTransformer3DModelTraj.__init__) == ref["transformer_init"] and len(ref["transformer_init"]) == 37
+    assert sig(CogVideoXImageToVideoPipelineTraj.__call__) == ref["pipeline_call"]
+    m = CogVideoXTransformer3DModelTraj(2, 64, 32, num_layers=1, sample_width=12, sample_height=8, sample_frames=9)
+    assert (m.config.num_attention_heads, m.config.attention_head_dim, m.config.in_channels, m.config.num_layers) == (2, 64, 32, 1)
