@@ -224,6 +224,15 @@ def attention_fwd(qkv, vT, out, B, S, H, s_pad, scale, lse=None, ld_qkv=None, ld
 def sched_step(x, v_c, v_u, guidance_scale, old_x0, noise, sa, sb, m3, m4, cx, cd, cn, want_x0=True):
     x = _need(x.contiguous(), BF16, "x")
     v_c = _need(v_c.contiguous(), BF16, "v_c")
+    if v_u is not None:
+        v_u = _need(v_u.contiguous(), BF16, "v_u")
+    if old_x0 is not None:
+        old_x0 = _need(old_x0.contiguous(), torch.float32, "old_x0")
+    if noise is not None:
+        noise = _need(noise.contiguous(), torch.float32, "noise")
+    for name, o in (("v_c", v_c), ("v_u", v_u), ("old_x0", old_x0), ("noise", noise)):
+        if o is not None and o.numel() != x.numel():
+            raise ValueError(f"sched_step: {name} has {o.numel()} elements, x has {x.numel()}")
     x_out = torch.empty_like(x)
     x0 = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_x0 else None
     check(lib().orv_sched_step(_p(x), _p(v_c), _p(v_u), float(guidance_scale), _p(old_x0), _p(noise), _p(x_out), _p(x0),

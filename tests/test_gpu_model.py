@@ -346,7 +346,7 @@ def test_full_depth_2b_two_dpm_steps_vs_oracle_loop(monkeypatch):
     g = torch.Generator().manual_seed(123)
     draws = [torch.randn(lat.shape, generator=g).to(BF).float() for _ in range(2 * n_steps)]    # the reference draws twice per step
     q_hip, q_ref = list(draws), list(draws)
-    monkeypatch.setattr(schedulers, "_randn_like", lambda sample, generator: q_hip.pop(0).to(sample.device, sample.dtype))
+    monkeypatch.setattr(schedulers, "_randn_like", lambda sample, generator: q_hip.pop(0).to(sample.device, torch.float32))   # as _randn_like: bf16 draw, fp32 copy
     monkeypatch.setattr(leaf, "randn_tensor", lambda shape, generator=None, device=None, dtype=None: q_ref.pop(0).to(dtype))
     sched = schedulers.CogVideoXDPMScheduler(**kw)
     sched.set_timesteps(50)
