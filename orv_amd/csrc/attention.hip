@@ -411,6 +411,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_pp_kernel(const AttnArgs p) {
     const int D = p.H * 64;
     const long row0 = (long)b * p.S;
     const bool active = q0 < p.S;          // a wave whose 32 query rows all lie past S only stages tiles and meets the barriers
+#ifdef ORV_PP_TRACE
+    const unsigned long long trace_t0 = wall_clock64();     // tools/attn_trace.sh: workgroup start / end on the 100 MHz clock
+#endif
 
     bf16x8 qf[4];
     {
@@ -668,6 +671,18 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_pp_kernel(const AttnArgs p) {
     const float l_tot = sum_with_partner_half(l_run);
     const float inv = 1.0f / l_tot;
     const int q = q0 + l31;
+#ifdef ORV_PP_TRACE
+    // timeline build only (never the product library): (start, end, HW_ID | XCC_ID << 32, item) per workgroup through the lse pointer
+    if (p.lse && tid == 0) {
+        unsigned long long* tr = (unsigned long long*)p.lse + (long)blockIdx.x * 4;
+        tr[0] = trace_t0; tr[1] = wall_clock64();
+        tr[2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
+        tr[3] = (unsigned long long)item;
+    }
+    const bool write_lse = false;
+#else
+    const bool write_lse = true;
+#endif
     if (q < p.S) {
         // lane holds d = 32 db + 8 qd + 4 hi + (0..3) of row q: groups qd = 2 u (lower half-wave) and 2 u + 1 (upper) are exchanged
         // so that every lane stores ONE aligned 16-byte piece: lower -> d 32 db + 16 u + 0..7, upper -> + 8..15
@@ -685,7 +700,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_pp_kernel(const AttnArgs p) {
                 { const auto r = __builtin_amdgcn_permlane32_swap(a1, b1, false, false); a1 = r[0]; b1 = r[1]; }
                 *(uint4*)(op + db * 32 + u * 16) = make_uint4(a0, a1, b0, b1);
             }
-        if (p.lse && hi == 0)
+        if (write_lse && p.lse && hi == 0)
             p.lse[((long)b * p.H + h) * p.S + q] = (STATIC ? __log2f(l_tot) : m_run + __log2f(l_tot)) * 0.6931471805599453f;
     }
 }
