@@ -171,6 +171,9 @@ int orv_gemm_force_tile(int ring, int bm, int bn);
 /* dst[c, r] = src[r, c] ([R, C] bf16 -> [C, ld_dst], columns [R, ld_dst) zero-filled).  Feeds the NT GEMM with the
  * K-contiguous operands of dgrad (W^T) and wgrad (dY^T, X^T): dX = dY . W, dW = dY^T . X (torch autograd of nn.Linear). */
 int orv_transpose_bf16(const void* src, int ld_src, void* dst, int ld_dst, int R, int C, void* stream);
+/* orv_transpose_bf16 with colsum[c] += sum_r src[r, c] taken in the same pass (fp32 atomics): dY^T for the weight gradient and the
+ * bias gradient of one nn.Linear from ONE read of dY (orv_transpose_bf16 followed by orv_colsum reads it twice). */
+int orv_transpose_colsum_bf16(const void* src, int ld_src, void* dst, int ld_dst, int R, int C, float* colsum, void* stream);
 /* out[c] += sum_r src[r, c] (fp32 atomics): bias gradients. */
 int orv_colsum(const void* src, int ld, float* out, int R, int C, void* stream);
 /* Adjoint of out = x + gate[b,g(row)] * y (cogvideox_control.py:419-421,442-443): dy = gate * dout (bf16),

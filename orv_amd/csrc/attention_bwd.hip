@@ -967,6 +967,24 @@ extern "C" int orv_head_transpose(const void* src, int ld, int col0, void* dst, 
 // qT / kT / doT (per-head transposed copies written by orv_head_transpose) feed the two-pass kernels of rounds 1-2 only; with all
 // three NULL - what the host passes since round 3 - the ping-pong kernels read K^T / Q'^T / dO^T with transposing LDS reads from the
 // row-major tiles.  ORV_ATTN_BWD_PP=0 + non-NULL copies: the old kernels (A/B).
+namespace {
+// per-device side stream + fork / join events of orv_attention_bwd (created on first use, kept)
+struct BwdSide { hipStream_t stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool ok = false, tried = false; };
+BwdSide* bwd_side() {
+    static BwdSide sides[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    BwdSide& s = sides[dev];
+    if (!s.tried) {
+        s.tried = true;
+        s.ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&s.ev_join, hipEventDisableTiming) == hipSuccess;
+    }
+    return s.ok ? &s : nullptr;
+}
+}  // namespace
+
 extern "C" int orv_attention_bwd(const void* qkv, int ld_qkv, const void* qT, const void* kT, const void* out,
                                  const void* dout, int ld_out, const void* doT, const float* lse, float* neg_lse2,
                                  float* neg_delta, void* dqkv, int ld_dqkv, int B, int S, int H, int s_pad, float scale,
@@ -988,8 +1006,23 @@ extern "C" int orv_attention_bwd(const void* qkv, int ld_qkv, const void* qT, co
     a.dqkv = (bf16_t*)dqkv; a.ld_dqkv = ld_dqkv; a.B = B; a.S = S; a.H = H; a.s_pad = s_pad; a.scale = scale;
     dim3 grid(((S + 255) / 256) * H * B);   // 1-D: orv_xcd_item hands head-major items to the XCDs
     if (pp) {
-        hipLaunchKernelGGL(attn_bwd_dq_pp_kernel, grid, dim3(512), 0, st, a);
-        hipLaunchKernelGGL(attn_bwd_dkv_pp_kernel, grid, dim3(512), 0, st, a);
+        // The two passes are independent (dQ | dK, dV: disjoint columns of dqkv) and each is 1560 one-per-CU workgroups = 6.09 -> 7
+        // rounds of 256 CUs at B = 4: launched on two streams the dispatcher fills the empty part of one pass's last round with
+        // the other's workgroups (fork / join by events, legal under stream capture).  ORV_ATTN_BWD_FORK=0: back to back.
+        static int fork = -1;
+        if (fork < 0) { const char* e = getenv("ORV_ATTN_BWD_FORK"); fork = (e && atoi(e) == 0) ? 0 : 1; }
+        BwdSide* side = fork ? bwd_side() : nullptr;
+        if (side) {
+            hipEventRecord(side->ev_fork, st);
+            hipStreamWaitEvent(side->stream, side->ev_fork, 0);
+            hipLaunchKernelGGL(attn_bwd_dkv_pp_kernel, grid, dim3(512), 0, side->stream, a);
+            hipLaunchKernelGGL(attn_bwd_dq_pp_kernel, grid, dim3(512), 0, st, a);
+            hipEventRecord(side->ev_join, side->stream);
+            hipStreamWaitEvent(st, side->ev_join, 0);
+        } else {
+            hipLaunchKernelGGL(attn_bwd_dq_pp_kernel, grid, dim3(512), 0, st, a);
+            hipLaunchKernelGGL(attn_bwd_dkv_pp_kernel, grid, dim3(512), 0, st, a);
+        }
     } else {
         hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(512), 0, st, a);
         hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(512), 0, st, a);

@@ -36,6 +36,66 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
     }
 }
 
+// ---- the same transpose with the column sums of src taken on the way (bias gradient of a linear layer next to the dY^T its
+//      weight gradient needs: one read of dY instead of two).  A workgroup walks RT consecutive 64-row tiles of one 64-column
+//      strip, so a column gets ceil(R / (64 RT)) fp32 atomics - as many as orv_colsum's slabs.
+template <int RT>
+__global__ __launch_bounds__(256) void transpose_colsum_kernel(const bf16_t* __restrict__ src, long lds_, bf16_t* __restrict__ dst,
+                                                               long ldd, int R, int C, float* __restrict__ csum) {
+    __shared__ bf16_t tile[2][64][72];
+    __shared__ float red[32][65];
+    const int c0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, lr = tid >> 3, ch = tid & 7;
+    const bool col_ok = c0 + ch * 8 < C;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint4 u[2];
+    auto fetch = [&](int t) {
+        const int r0 = (blockIdx.x * RT + t) * 64;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int r = lr + 32 * it;
+            u[it] = (r0 + r < R && col_ok) ? *(const uint4*)(src + (long)(r0 + r) * lds_ + c0 + ch * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    fetch(0);
+#pragma unroll 1
+    for (int t = 0; t < RT; ++t) {
+        const int r0 = (blockIdx.x * RT + t) * 64;
+        if (r0 >= ldd) break;                              // whole-workgroup uniform
+        bf16_t (*tl)[72] = tile[t & 1];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            *(uint4*)&tl[lr + 32 * it][ch * 8] = u[it];
+            const uint32_t w[4] = {u[it].x, u[it].y, u[it].z, u[it].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { cs[2 * e] += bf2f(w[e] & 0xffff); cs[2 * e + 1] += bf2f(w[e] >> 16); }
+        }
+        if (t + 1 < RT) fetch(t + 1);                      // next tile's loads fly over this tile's LDS round trip
+        __syncthreads();                                   // (two LDS tiles: the previous tile's readers are past their reads)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int c = lr + 32 * it;
+            if (c0 + c >= C) continue;
+            bf16_t o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = tl[ch * 8 + e][c];
+            uint4 v;
+            v.x = o[0] | ((uint32_t)o[1] << 16); v.y = o[2] | ((uint32_t)o[3] << 16);
+            v.z = o[4] | ((uint32_t)o[5] << 16); v.w = o[6] | ((uint32_t)o[7] << 16);
+            if (r0 + ch * 8 < ldd) *(uint4*)(dst + (long)(c0 + c) * ldd + r0 + ch * 8) = v;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[lr][ch * 8 + e] = cs[e];
+    __syncthreads();
+    if (tid < 64 && c0 + tid < C) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) s_ += red[r][tid];
+        atomicAdd(csum + c0 + tid, s_);
+    }
+}
+
 // ---- out[c] += sum_r src[r, c]  (bias gradients).  One block = 512 columns x a slab of rows: thread -> (8-column chunk,
 //      row phase 0..3), 16-byte loads, four rows in flight; LDS combine of the 4 phases, fp32 atomics across slabs.
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ src, long ld, float* __restrict__ out, int R,
@@ -600,6 +660,18 @@ extern "C" int orv_transpose_bf16(const void* src, int ld_src, void* dst, int ld
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (long)ld_src,
                        (bf16_t*)dst, (long)ld_dst, R, C);
     return orv_check_launch("orv_transpose_bf16");
+}
+
+extern "C" int orv_transpose_colsum_bf16(const void* src, int ld_src, void* dst, int ld_dst, int R, int C, float* colsum,
+                                         void* stream) {
+    ORV_REQUIRE(src && dst && colsum && R > 0 && C > 0, "orv_transpose_colsum_bf16: bad arguments");
+    ORV_REQUIRE(ld_src % 8 == 0 && ld_dst % 8 == 0 && ld_dst >= R && C % 8 == 0, "orv_transpose_colsum_bf16: misaligned");
+    constexpr int RT = 4;
+    const int row_tiles = (ld_dst + 63) / 64;
+    dim3 grid((row_tiles + RT - 1) / RT, (C + 63) / 64);
+    hipLaunchKernelGGL(transpose_colsum_kernel<RT>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (long)ld_src,
+                       (bf16_t*)dst, (long)ld_dst, R, C, colsum);
+    return orv_check_launch("orv_transpose_colsum_bf16");
 }
 
 extern "C" int orv_colsum(const void* src, int ld, float* out, int R, int C, void* stream) {

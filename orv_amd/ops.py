@@ -8,6 +8,7 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import os
 import torch
 
 from ._lib import Gemm, Groups, RowMap, check, lib
@@ -252,12 +253,24 @@ def gaussian_sample(moments, eps, scale):
 
 
 # ---- backward (training) ----------------------------------------------------------------------------------------------
-def transpose(src, R, C, ld_dst=None, out=None, ld_src=None):
-    """[R, C] bf16 -> [C, ld_dst] (ld_dst = R rounded up to 64, zero padded): K-contiguous operand for dgrad/wgrad."""
+def transpose(src, R, C, ld_dst=None, out=None, ld_src=None, colsum=None):
+    """[R, C] bf16 -> [C, ld_dst] (ld_dst = R rounded up to 64, zero padded): K-contiguous operand for dgrad/wgrad.
+    ``colsum`` (fp32 [C], accumulated into): the column sums of ``src`` from the same pass (bias gradient beside dY^T)."""
     _need(src, BF16, "src")
     ld_dst = ld_dst or (R + 63) // 64 * 64
     if out is None:
         out = torch.empty(C, ld_dst, dtype=BF16, device=src.device)
+    if colsum is not None:
+        _need(colsum, torch.float32, "colsum")
+        if colsum.numel() < C or not colsum.is_contiguous():
+            raise ValueError(f"transpose: colsum needs {C} contiguous fp32 elements")
+        if os.environ.get("ORV_TRANSPOSE_COLSUM", "1") == "0":       # A/B switch: two passes over src
+            check(lib().orv_transpose_bf16(_p(src), ld_src or C, _p(out), ld_dst, R, C, _stream()), "orv_transpose_bf16")
+            check(lib().orv_colsum(_p(src), ld_src or C, _p(colsum), R, C, _stream()), "orv_colsum")
+            return out
+        check(lib().orv_transpose_colsum_bf16(_p(src), ld_src or C, _p(out), ld_dst, R, C, _p(colsum), _stream()),
+              "orv_transpose_colsum_bf16")
+        return out
     check(lib().orv_transpose_bf16(_p(src), ld_src or C, _p(out), ld_dst, R, C, _stream()), "orv_transpose_bf16")
     return out
 

@@ -44,9 +44,10 @@ def _acc_grad(store: Dict, p: torch.nn.Parameter) -> torch.Tensor:
     return g
 
 
-def _wgrad(dY2d, X2d, dW, M, N, K, accumulate=True):
-    """dW[N,K] (+)= dY[M,N]^T . X[M,K]  through two transposes and the NT GEMM (contraction over the M rows)."""
-    dYT = ops.transpose(dY2d, M, N)           # [N, M_pad]
+def _wgrad(dY2d, X2d, dW, M, N, K, accumulate=True, bias_sum=None):
+    """dW[N,K] (+)= dY[M,N]^T . X[M,K]  through two transposes and the NT GEMM (contraction over the M rows).
+    ``bias_sum`` (fp32 [N]): += column sums of dY, taken by the transpose that reads dY anyway."""
+    dYT = ops.transpose(dY2d, M, N, colsum=bias_sum)           # [N, M_pad]
     XT = ops.transpose(X2d, M, K)             # [K, M_pad]
     if not accumulate and N % 256 == 0 and K % 256 != 0 and K % 64 == 0 and N >= 2 * K:
         # tall gradient whose long side only is a multiple of 256 (FeedForward net.0: [7680, 1920]): compute dW^T = X^T . dY with
@@ -135,15 +136,19 @@ def _attn_backward(at, ly, xn, datt, bufs, B_, S_, n_text, heads, rope, scale, g
     f32_to_param_grad(at.norm_k.weight, dgk), f32_to_param_grad(at.norm_k.bias, dbk)
     wqkv, _ = at.packed_qkv()
     lins = (at.to_q, at.to_k, at.to_v)
+    want_bias = lins[0].bias is not None and any(l.bias.requires_grad for l in lins)
+    bs = z32(3 * D) if want_bias else None
+    bias_done = False
     if any(l.weight.requires_grad for l in lins):
         dwqkv = torch.empty(3 * D, D, dtype=BF16, device=dev)
-        _wgrad(dqkv, xn, dwqkv, M_, 3 * D, D, accumulate=False)
+        _wgrad(dqkv, xn, dwqkv, M_, 3 * D, D, accumulate=False, bias_sum=bs)
+        bias_done = True
         for j, lin in enumerate(lins):
             if lin.weight.requires_grad:
                 _acc_grad(grads, lin.weight).add_(dwqkv[j * D:(j + 1) * D])
-    if lins[0].bias is not None and any(l.bias.requires_grad for l in lins):
-        bs = z32(3 * D)
-        ops.colsum(dqkv, bs, M_, 3 * D)
+    if want_bias:
+        if not bias_done:
+            ops.colsum(dqkv, bs, M_, 3 * D)
         for j, lin in enumerate(lins):
             f32_to_param_grad(lin.bias, bs[j * D:(j + 1) * D])
     dxn = torch.empty(M_, D, dtype=BF16, device=dev)
@@ -490,23 +495,26 @@ def backward(model, sv, dout, drecon=None, grad_hook=None) -> Dict[int, torch.Te
         else:                                   # first (normally only) contribution: no zero-fill + add
             grads[id(param)] = g
 
-    def wgrad_p(param, dY2d, X2d, M_, N_, K_):
+    def wgrad_p(param, dY2d, X2d, M_, N_, K_, bias=None):
+        """Weight gradient of one nn.Linear and, with ``bias``, its bias gradient: the column sums of dY come out of the transpose
+        that makes dY^T (one read of dY; a frozen weight leaves the bias to orv_colsum)."""
+        want_bias = bias is not None and bias.requires_grad
+        bs = z32(N_) if want_bias else None
         if not param.requires_grad:             # frozen weights (e.g. everything but mv_blocks, :641-656) cost no GEMM
+            if want_bias:
+                ops.colsum(dY2d, bs, M_, N_)
+                f32_to_param_grad(bias, bs)
             return
         if id(param) in grads:
-            _wgrad(dY2d, X2d, grads[id(param)], M_, N_, K_)
+            _wgrad(dY2d, X2d, grads[id(param)], M_, N_, K_, bias_sum=bs)
         else:                                   # first (normally only) contribution: plain store, no zero-fill + re-read
             g = _state.grad_view(param)         # straight into the fused optimizer's flat gradient buffer when there is one
             if g is None:
                 g = torch.empty_like(param, dtype=BF16)
             grads[id(param)] = g
-            _wgrad(dY2d, X2d, g, M_, N_, K_, accumulate=False)
-
-    def bias_p(param, dY2d, M_, N_):
-        if param is not None and param.requires_grad:
-            bs = z32(N_)
-            ops.colsum(dY2d, bs, M_, N_)
-            f32_to_param_grad(param, bs)
+            _wgrad(dY2d, X2d, g, M_, N_, K_, accumulate=False, bias_sum=bs)
+        if want_bias:
+            f32_to_param_grad(bias, bs)
 
     # ---- head: unpatchify^T = patchify ; proj_out ; norm_out ; norm_final ----
     if nv_ > 1:
@@ -557,12 +565,10 @@ def backward(model, sv, dout, drecon=None, grad_hook=None) -> Dict[int, torch.Te
         # FFN branch: x2 = x1 + g2 * y2
         dy2 = e(M, D)
         ops.gated_residual_bwd(dx, ly.y2, m2[..., 2 * D:], dm2[..., 2 * D:], dy2, mb, mg, grp, B, D)
-        wgrad_p(f2.weight, dy2, ly.h, M, D, FF)
-        bias_p(f2.bias, dy2, M, D)
+        wgrad_p(f2.weight, dy2, ly.h, M, D, FF, bias=f2.bias)
         du = e(M, FF)
         _dgrad(dy2, f2.weight, du, M, D, FF, epilogue=3, R=ly.u)          # GELU adjoint fused
-        wgrad_p(f0.weight, du, ly.xn2, M, FF, D)
-        bias_p(f0.bias, du, M, FF)
+        wgrad_p(f0.weight, du, ly.xn2, M, FF, D, bias=f0.bias)
         dxn2 = e(M, D)
         _dgrad(du, f0.weight, dxn2, M, FF, D)
         dx1 = e(M, D)
@@ -574,8 +580,7 @@ def backward(model, sv, dout, drecon=None, grad_hook=None) -> Dict[int, torch.Te
         dy1 = e(M, D)
         ops.gated_residual_bwd(dx1, ly.y1, m1[..., 2 * D:], dm1[..., 2 * D:], dy1, mb, mg, grp, B, D)
         wo = at.to_out[0]
-        wgrad_p(wo.weight, dy1, ly.att, M, D, D)
-        bias_p(wo.bias, dy1, M, D)
+        wgrad_p(wo.weight, dy1, ly.att, M, D, D, bias=wo.bias)
         datt = e(M, D)
         _dgrad(dy1, wo.weight, datt, M, D, D)
         dxn1 = _attn_backward(at, ly, ly.xn1, datt, bufs, B, S, Nt, heads, sv.rope, scale, grads, f32_to_param_grad, z32)
@@ -602,13 +607,11 @@ def backward(model, sv, dout, drecon=None, grad_hook=None) -> Dict[int, torch.Te
             ops.gated_residual_bwd(dxm, mly.y, gate_mv.view(b0 * T, 1 + nv_, D), dgate_mv, dy, (1 + nv_) * D, D, mv.grp, mv.Bm,
                                    D)
             dmv[i][:, 1, 2 * D:] += dgate_mv.view(b0, T, 1 + nv_, D)[:, :, 1:].sum(1).reshape(B, D)
-            wgrad_p(mblk.proj_out.weight, dy, mly.ao, mv.R, D, D)
-            bias_p(mblk.proj_out.bias, dy, mv.R, D)
+            wgrad_p(mblk.proj_out.weight, dy, mly.ao, mv.R, D, D, bias=mblk.proj_out.bias)
             dao = e(mv.R, D)
             _dgrad(dy, mblk.proj_out.weight, dao, mv.R, D, D)
             wo = mblk.attn1.to_out[0]
-            wgrad_p(wo.weight, dao, mly.att, mv.R, D, D)
-            bias_p(wo.bias, dao, mv.R, D)
+            wgrad_p(wo.weight, dao, mly.att, mv.R, D, D, bias=wo.bias)
             datt = e(mv.R, D)
             _dgrad(dao, wo.weight, datt, mv.R, D, D)
             dxm_n = _attn_backward(mblk.attn1, mly, mly.xm, datt, mv.bufs, mv.Bm, mv.Sm, mv.n_text, heads, sv.rope_view, scale,
@@ -646,8 +649,7 @@ def backward(model, sv, dout, drecon=None, grad_hook=None) -> Dict[int, torch.Te
     if sv.ctrl_tokens:
         icl = model.initial_combine_linear
         K2 = icl.weight.shape[1]
-        wgrad_p(icl.weight, dvis_rows, sv.comb, B * Nv, D, K2)
-        bias_p(icl.bias, dvis_rows, B * Nv, D)
+        wgrad_p(icl.weight, dvis_rows, sv.comb, B * Nv, D, K2, bias=icl.bias)
         dcomb = e(B * Nv, K2)
         _dgrad(dvis_rows, icl.weight, dcomb, B * Nv, D, K2)
         acc32 = dvis_rows.float()
@@ -668,8 +670,7 @@ def backward(model, sv, dout, drecon=None, grad_hook=None) -> Dict[int, torch.Te
     if mod_text:
         dtxt = dxj[:, :Nt].reshape(B * Nt, D).contiguous()
         Kt = sv.text2d.shape[1]
-        wgrad_p(pe.text_proj.weight, dtxt, sv.text2d, B * Nt, D, Kt)
-        bias_p(pe.text_proj.bias, dtxt, B * Nt, D)
+        wgrad_p(pe.text_proj.weight, dtxt, sv.text2d, B * Nt, D, Kt, bias=pe.text_proj.bias)
 
     # ---- modulation tables -> AdaLN linears -> conditioning (temb, action embedding) ----
     temb32 = sv.temb.float()

@@ -38,6 +38,18 @@ def test_transpose_and_colsum():
         out = torch.zeros(C, dtype=torch.float32, device=dev)
         ops.colsum(x.to(dev, BF), out, R, C)
         close(out, x.sum(0), rtol=1e-3, afrac=1e-3)
+        # the fused form (orv_transpose_colsum_bf16): the same transpose bit for bit, the sums accumulated INTO the buffer
+        acc = torch.full((C,), 2.0, dtype=torch.float32, device=dev)
+        t2 = ops.transpose(x.to(dev, BF), R, C, colsum=acc)
+        assert torch.equal(t2, t)
+        close(acc - 2.0, x.sum(0), rtol=1e-3, afrac=1e-3)
+    # a strided source (a column block of a wider matrix), as the packed q | k | v gradient is read
+    x = q(torch.randn(500, 256))
+    xd = x.to(dev, BF)
+    acc = torch.zeros(128, dtype=torch.float32, device=dev)
+    t3 = ops.transpose(xd[:, 64:192], 500, 128, ld_src=256, colsum=acc)
+    assert torch.equal(t3[:, :500].float().cpu(), x[:, 64:192].t()) and torch.all(t3[:, 500:] == 0)
+    close(acc, x[:, 64:192].sum(0), rtol=1e-3, afrac=1e-3)
 
 
 def test_gemm_dgrad_wgrad_via_transposes():

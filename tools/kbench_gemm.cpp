@@ -66,8 +66,32 @@ static void ab(int M,int N,int K,int epi,int rounds,int nt,char** tiles){
   orv_gemm_force_tile(0,0,0);
   hipFree(dA);hipFree(dW);hipFree(db);hipFree(dC);hipFree(dR);hipFree(dg);
 }
+// warm vs cold operands: cold M N K epi iters   - the same GEMM with (a) one operand set reused, (b) the weights rotating through 32
+// buffers (every layer of the model has its own: HBM- and TLB-cold at each launch), (c) every operand rotating through 8 sets
+static void cold(int M,int N,int K,int epi,int iters){
+  const int NW=32, NS=8;
+  auto A=rnd_bf((size_t)M*K,1.f,1), W=rnd_bf((size_t)N*K,0.05f,2), bias=rnd_bf(N,0.5f,3);
+  std::vector<uint16_t*> dA(NS),dC(NS),dR(NS),dW(NW);
+  for(int i=0;i<NS;i++){ dA[i]=up(A); CK(hipMalloc(&dC[i],(size_t)M*N*2)); CK(hipMalloc(&dR[i],(size_t)M*N*2)); CK(hipMemset(dC[i],0,(size_t)M*N*2)); CK(hipMemset(dR[i],0,(size_t)M*N*2)); }
+  for(int i=0;i<NW;i++) dW[i]=up(W);
+  uint16_t* db=up(bias); int seq=3226; int B=(M+seq-1)/seq; int G=6; std::vector<float> gate((size_t)B*G*N,0.5f); float* dg=up(gate);
+  hipEvent_t e0,e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const char* names[6]={"one operand set","32 weight buffers","32 weights + 8 activation sets","only A rotates (8)","only R rotates (8)","only C rotates (8)"};
+  for(int round=0;round<2;round++) for(int mode=0;mode<6;mode++){
+    auto run=[&](int i){ orv_gemm_t g{}; int s= mode==2 ? i%NS : 0; int w= (mode==1||mode==2) ? i%NW : 0;
+      g.A=dA[mode==3? i%NS : s]; g.lda=K; g.W=dW[w]; g.ldw=K; g.bias=db; g.C=dC[mode==5? i%NS : s]; g.ldc=N; g.M=M; g.N=N; g.K=K; g.epilogue=epi; g.R=dR[mode==4? i%NS : s]; g.ldr=N; g.gate=dg; g.gate_b=(long)G*N; g.gate_g=N; g.grp={seq,226,600};
+      if(orv_gemm_bf16(&g,nullptr)){ printf("%s\n",orv_last_error()); exit(1);} };
+    for(int i=0;i<4;i++) run(i);
+    CK(hipEventRecord(e0)); for(int i=0;i<iters;i++) run(i); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms,e0,e1)); ms/=iters;
+    if(mode==3){   // A rotates AND is rewritten on the device right before each launch (what the model does): is fresh data warm?
+      float tot=0; for(int i=0;i<iters;i++){ CK(hipMemcpyAsync(dA[i%NS],dA[(i+1)%NS],(size_t)M*K*2,hipMemcpyDeviceToDevice,0)); CK(hipEventRecord(e0)); run(i); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float t; CK(hipEventElapsedTime(&t,e0,e1)); tot+=t; }
+      printf("cold M=%5d N=%5d K=%5d epi=%d %-28s: %.4f ms (per-launch events; loop-timed %.4f)\n",M,N,K,epi,"A rotates, rewritten just before",tot/iters,ms); }
+    printf("cold M=%5d N=%5d K=%5d epi=%d %-28s: %.4f ms  %.0f TFLOP/s\n",M,N,K,epi,names[mode],ms,2.0*M*N*K/ms/1e9);
+  }
+}
 int main(int argc,char**argv){
   if(orv_device_check(0)){ printf("%s\n",orv_last_error()); return 2; }
+  if(argc>=7 && !strcmp(argv[1],"cold")){ cold(atoi(argv[2]),atoi(argv[3]),atoi(argv[4]),atoi(argv[5]),atoi(argv[6])); return 0; }
   if(argc>=9 && !strcmp(argv[1],"check")){ return check(atoi(argv[2]),atoi(argv[3]),atoi(argv[4]),atoi(argv[5]),atoi(argv[6]),atoi(argv[7]),atoi(argv[8])); }
   if(argc>=8 && !strcmp(argv[1],"ab")){ ab(atoi(argv[2]),atoi(argv[3]),atoi(argv[4]),atoi(argv[5]),atoi(argv[6]),argc-7,argv+7); return 0; }
   if(argc>=7 && !strcmp(argv[1],"bench")){ bench(atoi(argv[2]),atoi(argv[3]),atoi(argv[4]),atoi(argv[5]),atoi(argv[6])); return 0; }
