@@ -217,6 +217,12 @@ int orv_adamw_flat(void* p, const void* g, float* m, float* v, long n, const lon
 int orv_adamw_flat_steps(void* p, const void* g, float* m, float* v, long n, const long* seg_start,
                          const unsigned char* seg_active, const int* seg_step, int nseg, float lr, float beta1, float beta2,
                          float eps, float weight_decay, int step, const float* clip_coef, void* stream);
+/* dst_ptr[s][j] = bf16(src[src_off[s] + j]), j < len[s], for nseg segments (src_off / dst_ptr / len are DEVICE arrays; dst_ptr holds
+ * device addresses of bf16 storage; max_len = max len[s]): the small fp32-accumulated parameter gradients go from the backward's
+ * accumulator arena into the fused optimizer's flat gradient buffer in one launch (the reference leaves this to autograd's
+ * per-parameter accumulation, train_cogvideox_control_to_video_sft.py:1093). */
+int orv_scatter_f32_to_bf16(const float* src, const long* src_off, const long* dst_ptr, const int* len, int nseg, int max_len,
+                            void* stream);
 /* out[0] += sum g^2 (gradient-norm reduction, orv/utils.py:166-174). */
 int orv_sumsq(const void* g, long n, float* out, void* stream);
 

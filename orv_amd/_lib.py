@@ -84,6 +84,7 @@ SIGNATURES = {
                                c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
     "orv_adamw_flat_steps": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int,
                                      c_float, c_float, c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
+    "orv_scatter_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "orv_sumsq": (c_int, [c_void_p, c_long, c_void_p, c_void_p]),
     "orv_head_transpose": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "orv_attention_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,

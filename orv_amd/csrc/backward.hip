@@ -826,6 +826,26 @@ extern "C" int orv_adamw_flat(void* p, const void* g, float* m, float* v, long n
                                 clip_coef, stream);
 }
 
+// ---- dst_s[j] = bf16(src[off_s + j]) for a list of segments s: the small fp32-accumulated gradients (biases, LayerNorm affine, qk-norm)
+//      leave the backward's arena straight into their places of the optimizer's flat bf16 gradient buffer - one launch.
+__global__ __launch_bounds__(256) void scatter_cast_kernel(const float* __restrict__ src, const long* __restrict__ off,
+                                                           const long* __restrict__ dst, const int* __restrict__ len) {
+    const int s_ = blockIdx.y;
+    const int n = len[s_];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    ((bf16_t*)dst[s_])[j] = f2bf(src[off[s_] + j]);
+}
+
+extern "C" int orv_scatter_f32_to_bf16(const float* src, const long* src_off, const long* dst_ptr, const int* len, int nseg,
+                                       int max_len, void* stream) {
+    ORV_REQUIRE(src && src_off && dst_ptr && len && nseg > 0 && max_len > 0, "orv_scatter_f32_to_bf16: bad arguments");
+    ORV_REQUIRE(nseg <= 65535, "orv_scatter_f32_to_bf16: %d segments (at most 65535 per call)", nseg);
+    hipLaunchKernelGGL(scatter_cast_kernel, dim3((max_len + 255) / 256, nseg), dim3(256), 0, (hipStream_t)stream, src, src_off,
+                       dst_ptr, len);
+    return orv_check_launch("orv_scatter_f32_to_bf16");
+}
+
 extern "C" int orv_sumsq(const void* g, long n, float* out, void* stream) {
     ORV_REQUIRE(g && out && n > 0, "orv_sumsq: bad arguments");
     const int blocks = (int)min((long)2048, (n + 2047) / 2048);

@@ -1424,6 +1424,12 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
         ORV_REQUIRE(g->cmap.rows == 0, "orv_gemm_bf16: epilogue 4 writes rows in place (no cmap)");
     }
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("ORV_GEMM_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
+    {   // tiles handed out from the END of the list (GemmArgs::walk_back).  ORV_GEMM_WALK_BACK: 0 never, 1 the gated-residual GEMMs
+        // only (out-projection, FFN2), 2 (default) every GEMM
+        static int wb = -1;
+        if (wb < 0) { const char* e = getenv("ORV_GEMM_WALK_BACK"); wb = e ? atoi(e) : 2; }
+        a.walk_back = (wb == 2 || (wb == 1 && g->epilogue == 2 && g->gate)) ? 1 : 0;
+    }
     hipStream_t st = (hipStream_t)stream;
     const GemmCand *first = nullptr, *second = nullptr;
     ORV_REQUIRE(plan_gemm(g->M, g->N, g->K, g->epilogue, g->qn_heads, first, second),

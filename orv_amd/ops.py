@@ -275,6 +275,34 @@ def transpose(src, R, C, ld_dst=None, out=None, ld_src=None, colsum=None):
     return out
 
 
+_scatter_tables = {}
+
+
+def scatter_f32_to_bf16(src, segments):
+    """``segments``: [(offset into ``src`` (fp32, flat), destination bf16 tensor (contiguous))] - every destination receives
+    bf16(src[offset : offset + numel]) in ONE launch.  The device-side tables are cached per (offsets, destinations) list: the
+    backward of a given model produces the same list every step."""
+    _need(src, torch.float32, "src")
+    if not segments:
+        return
+    key = (src.device.index, tuple((int(o), d.data_ptr(), d.numel()) for o, d in segments))
+    tab = _scatter_tables.get(key)
+    if tab is None:
+        if len(_scatter_tables) > 16:
+            _scatter_tables.clear()
+        for o, d in segments:
+            _need(d, BF16, "destination")
+            if not d.is_contiguous() or o < 0 or o + d.numel() > src.numel():
+                raise ValueError("scatter_f32_to_bf16: destinations must be contiguous and sources inside `src`")
+        dev = src.device
+        tab = (torch.tensor([k[0] for k in key[1]], dtype=torch.int64, device=dev),
+               torch.tensor([k[1] for k in key[1]], dtype=torch.int64, device=dev),
+               torch.tensor([k[2] for k in key[1]], dtype=torch.int32, device=dev), max(k[2] for k in key[1]))
+        _scatter_tables[key] = tab
+    check(lib().orv_scatter_f32_to_bf16(_p(src), _p(tab[0]), _p(tab[1]), _p(tab[2]), len(segments), tab[3], _stream()),
+          "orv_scatter_f32_to_bf16")
+
+
 def colsum(src, out, R, C, ld=None):
     _need(src, BF16, "src"), _need(out, torch.float32, "out")
     check(lib().orv_colsum(_p(src), ld or C, _p(out), R, C, _stream()), "orv_colsum")

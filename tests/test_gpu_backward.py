@@ -52,6 +52,25 @@ def test_transpose_and_colsum():
     close(acc, x[:, 64:192].sum(0), rtol=1e-3, afrac=1e-3)
 
 
+def test_scatter_f32_to_bf16_segments():
+    """orv_scatter_f32_to_bf16: fp32 arena segments -> bf16 destinations of different lengths, one launch; untouched neighbours."""
+    from orv_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    arena = torch.randn(5000, generator=g).to(dev)
+    flat = torch.full((4096,), 7.0, dtype=BF, device=dev)
+    segs = [(64, flat[10:74]), (1000, flat[128:128 + 1920].view(30, 64)), (3000, flat[3000:3001]), (3500, flat[3200:3200 + 300])]
+    for _ in range(2):                                   # the second call takes the cached tables
+        ops.scatter_f32_to_bf16(arena, segs)
+    ref = torch.full((4096,), 7.0)
+    for off, d in segs:
+        start = (d.data_ptr() - flat.data_ptr()) // 2
+        ref[start:start + d.numel()] = arena[off:off + d.numel()].cpu()
+    assert torch.equal(flat.float().cpu(), ref.to(BF).float())
+    with pytest.raises(ValueError):
+        ops.scatter_f32_to_bf16(arena, [(4990, flat[:64])])       # source range past the arena
+
+
 def test_gemm_dgrad_wgrad_via_transposes():
     """dX = dY W and dW = dY^T X through the NT GEMM + orv_transpose_bf16; GELU adjoint fused as epilogue 3."""
     from orv_amd import ops
