@@ -1372,6 +1372,11 @@ extern "C" int orv_gemm_kernel_name(int M, int N, int K, int epilogue, char* buf
 static int gemm_dispatch(GemmArgs a, const GemmCand* best, int epilogue, hipStream_t st) {
     a.tiles_n = a.N / best->bn;
     a.tiles_m = (a.M + best->bm - 1) / best->bm;
+    {
+        static int gm_env = -1;
+        if (gm_env < 0) { const char* e = getenv("ORV_GEMM_GM"); gm_env = e ? atoi(e) : 0; }
+        a.gm = gm_env > 0 ? gm_env : (a.K >= 4096 && a.tiles_n <= 16 ? 8 : 0);
+    }
     if (best->ring == 3) return launch_t8(a, best->bn, epilogue, st);
     if (best->ring == 2) {
         if (best->bn == 256) return launch_ph<256>(a, epilogue, st);
@@ -1408,6 +1413,7 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
     ORV_REQUIRE((g->epilogue != 2 && g->epilogue != 3) || g->R, "orv_gemm_bf16: epilogue 2/3 needs R");
     ORV_REQUIRE(g->epilogue != 2 || !g->gate || g->grp.seq > 0, "orv_gemm_bf16: gate needs grp.seq");
     GemmArgs a;
+    a.gm = 0;
     a.A = (const bf16_t*)g->A; a.lda = g->lda; a.W = (const bf16_t*)g->W; a.ldw = g->ldw;
     a.bias = (const bf16_t*)g->bias; a.C = (bf16_t*)g->C; a.ldc = g->ldc;
     a.M = g->M; a.N = g->N; a.K = g->K;

@@ -37,6 +37,9 @@ struct GemmArgs {
     // interleaved: FFN2 0.3405 -> 0.3319 ms, out-projection 0.1116 -> 0.1083 ms, LayerNorm-fed GEMMs unchanged (step 41.57 ->
     // 41.12 ms); the 2B training step another 1 % when the backward GEMMs do it too (profiles/r3_gemm_walk_back.txt).
     int walk_back;
+    int gm;   // super-tile height in tiles (0: GM).  8 for the long-K, narrow GEMM (FFN2: 10 column tiles, 120 K-tiles): in the model
+              // 0.3252 -> 0.3178 ms; every other per-block shape is best at or indifferent to 4 (sweep 1 / 2 / 3 / 4 / 6 / 8 / 13 in
+              // profiles/r3_gemm_walk_back.txt).  ORV_GEMM_GM overrides.
 };
 
 constexpr int BK = 64;
@@ -48,10 +51,11 @@ __device__ __forceinline__ void tile_of_index(const GemmArgs& p, int b, int nb, 
     const int q = nb >> 3, r = nb & 7, xcd = b & 7, j = b >> 3;
     int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     if (p.walk_back) L = nb - 1 - L;
-    const int per = GM * p.tiles_n;
+    const int gm = p.gm > 0 ? p.gm : GM;
+    const int per = gm * p.tiles_n;
     const int gid = L / per, rem = L % per;
-    const int first_m = gid * GM;
-    const int gsize = min(p.tiles_m - first_m, GM);
+    const int first_m = gid * gm;
+    const int gsize = min(p.tiles_m - first_m, gm);
     tm = first_m + rem % gsize;
     tn = rem / gsize;
 }
