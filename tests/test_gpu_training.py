@@ -286,6 +286,51 @@ def test_overlapped_gradient_exchange_hook_changes_nothing():
     assert results[0].abs().sum() > 0 and rel_l2(results[1], results[0]) <= 2e-3
 
 
+def test_two_forward_nodes_in_one_graph_sum_their_gradients():
+    """with the fused optimizer's gradient views registered, TWO DiTFunction nodes in one autograd graph (the
+    model called twice, one backward) must give g_A + g_B.  A segment is handed out for in-place writing once per step; the
+    second node gets a temporary and autograd accumulates - not 2 g_B through two aliases of one segment."""
+    from orv_amd import _state
+    from orv_amd.cogvideox_control import CogVideoXTransformer3DModelTraj
+    from orv_amd.optim import FusedAdamW
+    dev = torch.device("cuda:0")
+    cfg, extra, ins, w, outs = load_golden("fwd_actions")
+    g = torch.Generator().manual_seed(5)
+    wa = torch.randn(outs["sample"].shape, generator=g).to(dev)
+    wb = torch.randn(outs["sample"].shape, generator=g).to(dev)
+    hs_b = (ins["hidden_states"] + 0.5 * torch.randn(ins["hidden_states"].shape, generator=g)).to(dev, BF)
+    args = (ins["encoder_hidden_states"].to(dev, BF), {"actions": ins["actions"].to(dev)}, ins["timestep"].to(dev))
+    saved = _state._INPLACE_GRADS
+    grads = {}
+    try:
+        for mode in ("separate", "joint"):
+            _state._INPLACE_GRADS = mode == "joint"
+            m = CogVideoXTransformer3DModelTraj(**cfg)
+            m.load_state_dict(w)
+            m = m.to(dev, BF).train()
+            m.action_embed.forced_mask = torch.tensor(extra["mask"])
+            opt = FusedAdamW(m.parameters(), lr=1e-3)
+            opt._build() if opt._flat is None else None          # gradient views registered before any backward
+            big = m.transformer_blocks[0].ff.net[2].weight
+            if mode == "separate":                               # reference: two backward passes, gradients summed by autograd
+                for hs, ww in ((ins["hidden_states"].to(dev, BF), wa), (hs_b, wb)):
+                    (m(hs, *args, return_dict=False)[0].float() * ww).sum().backward()
+            else:                                                # one graph, two nodes, one backward
+                oa = m(ins["hidden_states"].to(dev, BF), *args, return_dict=False)[0]
+                ob = m(hs_b, *args, return_dict=False)[0]
+                ((oa.float() * wa).sum() + (ob.float() * wb).sum()).backward()
+            grads[mode] = {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None}
+            if mode == "joint":
+                assert len(opt._handed) > 0                      # the first node did write in place
+    finally:
+        _state._INPLACE_GRADS = saved
+    assert grads["separate"].keys() == grads["joint"].keys()
+    name = "transformer_blocks.0.ff.net.2.weight"
+    assert rel_l2(grads["joint"][name], grads["separate"][name]) <= 1e-2      # 2 g_B instead of g_A + g_B would be O(1) off
+    worst = max(rel_l2(grads["joint"][n], grads["separate"][n]) for n in grads["joint"] if grads["separate"][n].abs().sum() > 0)
+    assert worst <= 6e-2, worst
+
+
 def test_gaussian_sample_exact_with_injected_eps():
     """orv_gaussian_sample against ``(mean + exp(0.5 clamp(logvar, -30, 20)) * eps) * sf`` permuted to [B,F,C,H,W], element by
     element (DiagonalGaussianDistribution.sample x scaling factor, train...sft.py:887-895 / cogvideox_control.py:1173-1187).
