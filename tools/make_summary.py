@@ -1,7 +1,8 @@
-"""profiles/r2_summary.txt: ONE table per mode with, for every shipped kernel symbol, launches and average duration in the bench
+"""profiles/r<N>_summary.txt: ONE table per mode with, for every shipped kernel symbol, launches and average duration in the bench
 (HIP events / rocprofv3 stats), achieved TFLOP/s where the bench knows the FLOPs, and the PMC figures of the same command
-(effective clock, MFMA-busy fraction, fabric bytes per launch and TB/s).  usage: python tools/make_summary.py > profiles/r2_summary.txt"""
-import json, os, re
+(effective clock, MFMA-busy fraction, fabric bytes per launch and TB/s).  usage: python tools/make_summary.py [round, default 3] > profiles/r3_summary.txt"""
+import json, os, re, sys
+RN = sys.argv[1] if len(sys.argv) > 1 else "3"
 R = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 def last_json(path):
     for line in reversed(open(path).read().strip().splitlines()):
@@ -36,13 +37,13 @@ def table(title, stats_file, traffic_file, line):
               f"{f(t.get('clock_ghz'), 5, 2)} {f(t.get('mfma_busy'), 9, 2)} {f(mb / 1e6 if mb else None, 10, 1)} "
               f"{f(mb / us / 1e6 if mb and us else None, 5, 2)}")
     print()
-print("Round-2 per-kernel summary of the SHIPPED symbols (MI355X, CogVideoX-2B 320x480x17f, B=4).  calls / avg us / % time: rocprofv3\n"
+print(f"Round-{RN} per-kernel summary of the SHIPPED symbols (MI355X, CogVideoX-2B 320x480x17f, B=4).  calls / avg us / % time: rocprofv3\n"
       "--kernel-trace --stats of the bench command; TFLOP/s: algorithmic FLOPs / HIP-event time inside bench.py (same command, no\n"
       "profiler); GHz = GRBM_GUI_ACTIVE / 8 / duration, MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GUI_ACTIVE / 8), fabric MB =\n"
       "FETCH_SIZE x 2 + WRITE_SIZE per launch (L2 misses: Infinity Cache + HBM), from separate --pmc passes (tools/pmc_bench.sh).\n")
-d = last_json(os.path.join(R, "r2_bench_line_default.json"))
+d = last_json(os.path.join(R, f"r{RN}_bench_line_default.json"))
 print(f"headline: {d['ms_per_step']} ms/step, {d['value']} clip-steps/s, {d['achieved_tflops_attn_ffn']} TFLOP/s attention+FFN = {d['frac_mfma_peak_attn_ffn']} x peak\n")
-table("== denoise (python bench.py --no-vae) ==", "r2_bench_novae_kernel_stats_summary.txt", "hbm_traffic.json", d)
-t = last_json(os.path.join(R, "r2_train_2b_line.json"))
+table("== denoise (python bench.py --no-vae) ==", f"r{RN}_bench_novae_kernel_stats_summary.txt", "hbm_traffic.json", d)
+t = last_json(os.path.join(R, f"r{RN}_train_2b_line.json"))
 print(f"train: {t['ms_per_step']} ms/step, {t['value']} clips/s, peak {t['peak_hbm_gib']} GiB\n")
-table("== SFT step (python bench.py --mode train) ==", "r2_train_kernel_stats_summary.txt", "hbm_traffic_train.json", None)
+table("== SFT step (python bench.py --mode train) ==", f"r{RN}_train_kernel_stats_summary.txt", "hbm_traffic_train.json", None)
