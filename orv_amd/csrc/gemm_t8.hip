@@ -337,18 +337,32 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
             for (int c = 0; c < NBW; ++c) acc[a][b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 fa[2][4][2], fb[NBW][2];
 
+#ifdef ORV_T8_ABL_NOA1
+#define T8_READ_A(MH, S)                                                                                             \
+    _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                                 \
+        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
+            fa[MH][mb][kh] = (MH) ? fa[0][mb][kh] : *(const bf16x8*)(rdA + (S) * BUF + (MH) * HALF + mb * 2048 + kh * 1024);
+#else
 #define T8_READ_A(MH, S)                                                                                             \
     _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                                 \
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
             fa[MH][mb][kh] = *(const bf16x8*)(rdA + (S) * BUF + (MH) * HALF + mb * 2048 + kh * 1024);
+#endif
 #define T8_READ_B01(S)                                                                                               \
     _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                    \
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
             fb[t][kh] = *(const bf16x8*)(rdB + (S) * BUF + t * 2048 + kh * 1024);
+#ifdef ORV_T8_ABL_NOB23      // ablation builds (tools/t8_lds_abl.sh, wrong results): how much do the fragment reads cost?
+#define T8_READ_B23(S)                                                                                               \
+    _Pragma("unroll") for (int t = 0; t < NBW - 2; ++t)                                                              \
+        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
+            fb[2 + t][kh] = fb[t][kh];
+#else
 #define T8_READ_B23(S)                                                                                               \
     _Pragma("unroll") for (int t = 0; t < NBW - 2; ++t)                                                              \
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
             fb[2 + t][kh] = *(const bf16x8*)(rdB1 + (S) * BUF + t * 2048 + kh * 1024);
+#endif
     // (m half MH) x (blocks B0 .. B0 + NBK - 1), both k halves
 #define T8_MFMA(MH, B0, NBK)                                                                                         \
     _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                                 \

@@ -1,4 +1,5 @@
 #!/bin/bash
+# build first: VARIANTS="nob23:-DORV_T8_ABL_NOB23 noa1:-DORV_T8_ABL_NOA1 noboth:-DORV_T8_ABL_NOB23,-DORV_T8_ABL_NOA1" bash tools/t8_variants.sh
 # is the 192-wide t8 kernel bound by its LDS fragment reads?  ablation builds (wrong results): no B-block-2 read (22 -> 20 reads per
 # K-tile and wave), no second A-half read (22 -> 14), both (12); standalone, interleaved
 cd /root/repo/tools/bin; mkdir -p ../../gpurun_out
