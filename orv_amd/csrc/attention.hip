@@ -705,6 +705,302 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_pp_kernel(const AttnArgs p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The ping-pong kernel on v_mfma_f32_16x16x32_bf16 (fixed-shift softmax only).  Why: with nothing but MFMAs in the loop the part
+// sustains 1968 TFLOP/s on random bf16 operands with the 16-wide shape and 1747 with the 32-wide one (profiles/
+// r3_probe_mfma_shapes.txt) - 12.6 % more FLOPs per joule on a kernel that runs at the power cap (1.8 GHz).
+// Lane l = (c = l & 15, g = l >> 4).  A wave still owns 32 query rows, now as two 16-row blocks qb: row q0 + 16 qb + c.
+//   S^T block (kbk, qb) = K[16 kbk .. +15][:] . Q^T: the accumulator hands lane (c, g) the keys 16 kbk + 4 g + e (e < 4) of query
+//     (qb, c): 8 blocks x 4 = 32 scores per lane as before, 16 per query row, a row's 64 keys spread over the four lane groups -
+//     the row sum is reduced over g ONCE, after the last tile.
+//   K fragments (A operand, 16 keys x 32 d): one ds_read_b128 per (kbk, k-step), used by both query blocks.
+//   P^T (B operand, 32 keys x 16 queries) of key step s: k-group g carries keys 32 s + 4 g + e and 32 s + 16 + 4 g + e - the two
+//     accumulator quads of blocks 2 s and 2 s + 1, packed, straight from the softmax.
+//   V^T fragments (A operand, 16 d x 32 keys in THAT order): two ds_read_b64_tr_b16 per (db, s) - group g reads keys 32 s + 4 g .. + 3
+//     and 32 s + 16 + 4 g .. + 3 of d block db -, used by both query blocks.  Same 8 + 16 fragment reads per tile as the 32-wide
+//     form.  V image: the 32-byte segment of d block db of key row r sits at db ^ ((r >> 1) & 3), so the 8 key rows of half a wave's
+//     transposing read fall into 8 different bank groups.
+// Everything else (slots, DMA roles, barriers, the one-barrier phase shift of the second half) is attn_fwd_pp_kernel.
+// STATUS (profiles/r3_attention_pingpong.txt, box 10-13): bit-compatible results (same tests), the clock under the kernel rises
+// from 1.71-1.80 to 1.93-2.03 GHz - the power argument holds - but it needs 24 % more cycles (waves wait 60 % longer on
+// s_waitcnt / barriers with identical LDS, VALU and MFMA-busy counts), so it is 3.5-8 % SLOWER than the 32-wide kernel and stays
+// opt-in (ORV_ATTN_M16=1) until that schedule loss is found.
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA from inline asm in the scalar-base form: address = SGPR pair (wave-uniform tile base) + 32-bit per-lane byte offset.  One
+// VGPR per piece instead of a 64-bit pointer, and - as in attention_bwd.hip - invisible to hipcc's pass that puts s_waitcnt vmcnt(0)
+// in front of every ds_read_b64_tr_b16 that follows an LDS-DMA builtin; completion is owned by the explicit waits of the schedule.
+__device__ __forceinline__ void m16_glds16(const char* sbase, unsigned voff, const void* lds_dst) {
+    unsigned keep;
+    const unsigned long long u = (unsigned long long)(uintptr_t)sbase;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi_ = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    const unsigned long long su = ((unsigned long long)hi_ << 32) | lo;
+    const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(su), "s"(d) : "memory");
+}
+__device__ __forceinline__ float m16_sum_groups(float v) {          // sum over the four lane groups (lanes c, c + 16, c + 32, c + 48)
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__global__ __launch_bounds__(512, 4) void attn_fwd_m16_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * PP_SLOTS * TILE_BYTES];   // K slots | V slots
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wq = wave & 3;
+    const int c = lane & 15, g = lane >> 4;
+    const int nqt = (p.S + 255) / 256;
+    const int item = orv_xcd_item(blockIdx.x, gridDim.x);
+    const int bh = item / nqt, h = bh % p.H, b = bh / p.H;
+    const int q0 = (item % nqt) * 256 + wave * 32;
+    const int D = p.H * 64;
+    const long row0 = (long)b * p.S;
+    const bool active = q0 < p.S;
+
+    bf16x8 qf[2][2];                     // [query block][k-step]: d = 32 ks + 8 g .. + 7 of query row q0 + 16 qb + c
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qr = min(q0 + 16 * qb + c, p.S - 1);
+        const bf16_t* qp = p.qkv + (row0 + qr) * p.ld + h * 64 + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[qb][ks] = *(const bf16x8*)(qp + ks * 32);
+    }
+
+    // DMA source = wave-uniform tile base (scalar registers) + a 32-bit per-lane byte offset per piece: two VGPRs instead of two
+    // 64-bit pointers (those were what the register allocator spilled inside the tile loop, and their reload put an
+    // s_waitcnt vmcnt(0) between the two DMA instructions of a tile)
+    unsigned loff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int sr = wq * 16 + j * 8 + (lane >> 3), slot = lane & 7;
+        const int chunk = grp == 0 ? (slot ^ ((sr >> 1) & 7)) : (slot ^ (((sr >> 1) & 3) << 1));
+        loff[j] = (unsigned)((sr * (int)p.ld + chunk * 8) * 2);
+    }
+    const char* const tbase = (const char*)(p.qkv + row0 * p.ld + (grp == 0 ? D : 2 * D) + h * 64);
+    char* const sdst = smem + grp * PP_SLOTS * TILE_BYTES + wq * 2048;
+    const int nt = (p.S + KV - 1) / KV;
+    const bool ragged = (p.S & (KV - 1)) != 0;
+    auto stage = [&](int t) {
+        char* const d = sdst + (t % PP_SLOTS) * TILE_BYTES;
+        if (__builtin_expect(ragged && t == nt - 1, 0)) {
+            // keys past S read a valid row (their P is forced to 0): per-lane offsets from the batch base, rows clamped
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int sr = wq * 16 + j * 8 + (lane >> 3), slot = lane & 7;
+                const int chunk = grp == 0 ? (slot ^ ((sr >> 1) & 7)) : (slot ^ (((sr >> 1) & 3) << 1));
+                m16_glds16(tbase, (unsigned)((min(t * KV + sr, p.S - 1) * (int)p.ld + chunk * 8) * 2), d + j * 1024);
+            }
+        } else {
+            const char* const tb = tbase + (long)t * KV * p.ld * 2;
+            m16_glds16(tb, loff[0], d);
+            m16_glds16(tb, loff[1], d + 1024);
+        }
+    };
+
+    f32x4 oT[4][2], sT[4][2];            // O^T [d block][query block], S^T [key block][query block]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { oT[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; sT[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    union { bf16x8 v; uint32_t u[4]; } pf[2][2];      // [key step][query block]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pf[i][j].u[e] = 0u;
+    float l_run[2] = {0.f, 0.f};
+    // K fragment of (kbk, ks): row 16 kbk + c, 16-byte chunk 4 ks + g, swizzled by (row >> 1) & 7 = (c >> 1) & 7
+    const int k_row = c * 128, k_sw = (c >> 1) & 7;
+    // V^T fragment pieces: lane (c, g) addresses key 4 g + (c >> 2) (+ 32 s + 16 half) and d 16 db + 4 (c & 3); segment db ^ fz
+    const int v_fz = (2 * g + (c >> 3)) & 3;
+    const int v_base = (4 * g + (c >> 2)) * 128 + 8 * (c & 3);
+#define M16_BAR()                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    __builtin_amdgcn_s_barrier();                                                                 \
+    __builtin_amdgcn_sched_barrier(0);
+#define M16_FENCE() __builtin_amdgcn_sched_barrier(0);
+#ifdef ORV_M16_ABL_NOMFMA
+#define M16_MFMA(A, B, C) (C)
+#else
+#define M16_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
+#endif
+    auto seg_x = [&](int t, auto stage_k) {
+        __builtin_amdgcn_s_setprio(1);
+        const char* sK = smem + (t % PP_SLOTS) * TILE_BYTES + k_row;
+        auto kread = [&](int kbk, int ks) {
+#ifdef ORV_M16_ABL_NOK
+            return qf[kbk & 1][ks];
+#endif
+            return *(const bf16x8*)(sK + kbk * 2048 + (((4 * ks + g) ^ k_sw) * 16)); };
+        bf16x8 ka, kb_, kc, kd, ke, kf, kg, kh;          // K fragments: (key block 0..3, k-step 0) | (key block 0..3, k-step 1)
+        if (t > 0) {
+            const char* sV = smem + PP_SLOTS * TILE_BYTES + ((t - 1) % PP_SLOTS) * TILE_BYTES + v_base;
+            auto vread = [&](int db, int s_) {
+#ifdef ORV_M16_ABL_NOV
+                return qf[db & 1][s_];
+#endif
+                const char* a = sV + s_ * 4096 + ((db ^ v_fz) * 32);
+                return tr_read_pair(a, a + 2048);
+            };
+            bf16x8 v0 = vread(0, 0), v1 = vread(1, 0), v2 = vread(2, 0), v3 = vread(3, 0);
+            M16_FENCE()
+            oT[0][0] = M16_MFMA(v0, pf[0][0].v, oT[0][0]); oT[0][1] = M16_MFMA(v0, pf[0][1].v, oT[0][1]);
+            oT[1][0] = M16_MFMA(v1, pf[0][0].v, oT[1][0]); oT[1][1] = M16_MFMA(v1, pf[0][1].v, oT[1][1]);
+            M16_FENCE()
+            v0 = vread(0, 1); v1 = vread(1, 1);
+            M16_FENCE()
+            oT[2][0] = M16_MFMA(v2, pf[0][0].v, oT[2][0]); oT[2][1] = M16_MFMA(v2, pf[0][1].v, oT[2][1]);
+            oT[3][0] = M16_MFMA(v3, pf[0][0].v, oT[3][0]); oT[3][1] = M16_MFMA(v3, pf[0][1].v, oT[3][1]);
+            M16_FENCE()
+            v2 = vread(2, 1); v3 = vread(3, 1);
+            M16_FENCE()
+            stage_k();                                   // behind the last transposing read (see attn_fwd_pp_kernel)
+            M16_FENCE()
+            if (t < nt) { ka = kread(0, 0); kb_ = kread(1, 0); kc = kread(2, 0); kd = kread(3, 0); }
+            M16_FENCE()
+            oT[0][0] = M16_MFMA(v0, pf[1][0].v, oT[0][0]); oT[0][1] = M16_MFMA(v0, pf[1][1].v, oT[0][1]);
+            oT[1][0] = M16_MFMA(v1, pf[1][0].v, oT[1][0]); oT[1][1] = M16_MFMA(v1, pf[1][1].v, oT[1][1]);
+            M16_FENCE()
+            if (t < nt) { ke = kread(0, 1); kf = kread(1, 1); }      // the dying V fragments / P make room for the second k-step
+            M16_FENCE()
+            oT[2][0] = M16_MFMA(v2, pf[1][0].v, oT[2][0]); oT[2][1] = M16_MFMA(v2, pf[1][1].v, oT[2][1]);
+            oT[3][0] = M16_MFMA(v3, pf[1][0].v, oT[3][0]); oT[3][1] = M16_MFMA(v3, pf[1][1].v, oT[3][1]);
+            M16_FENCE()
+            if (t < nt) { kg = kread(2, 1); kh = kread(3, 1); }
+            M16_FENCE()
+        } else {
+            stage_k();
+            M16_FENCE()
+            ka = kread(0, 0); kb_ = kread(1, 0); kc = kread(2, 0); kd = kread(3, 0);
+            ke = kread(0, 1); kf = kread(1, 1); kg = kread(2, 1); kh = kread(3, 1);
+            M16_FENCE()
+        }
+        if (t < nt) {
+            // every K fragment of the tile is in flight before the first score MFMA: 16 MFMAs back to back
+            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+            sT[0][0] = M16_MFMA(ka, qf[0][0], z); sT[0][1] = M16_MFMA(ka, qf[1][0], z);
+            sT[1][0] = M16_MFMA(kb_, qf[0][0], z); sT[1][1] = M16_MFMA(kb_, qf[1][0], z);
+            sT[2][0] = M16_MFMA(kc, qf[0][0], z); sT[2][1] = M16_MFMA(kc, qf[1][0], z);
+            sT[3][0] = M16_MFMA(kd, qf[0][0], z); sT[3][1] = M16_MFMA(kd, qf[1][0], z);
+            M16_FENCE()
+            sT[0][0] = M16_MFMA(ke, qf[0][1], sT[0][0]); sT[0][1] = M16_MFMA(ke, qf[1][1], sT[0][1]);
+            sT[1][0] = M16_MFMA(kf, qf[0][1], sT[1][0]); sT[1][1] = M16_MFMA(kf, qf[1][1], sT[1][1]);
+            sT[2][0] = M16_MFMA(kg, qf[0][1], sT[2][0]); sT[2][1] = M16_MFMA(kg, qf[1][1], sT[2][1]);
+            sT[3][0] = M16_MFMA(kh, qf[0][1], sT[3][0]); sT[3][1] = M16_MFMA(kh, qf[1][1], sT[3][1]);
+            M16_FENCE()
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto seg_y = [&](int t) {
+        if (t == nt - 1 && (p.S & (KV - 1)) != 0) {
+            int kv0 = t * KV + 4 * g;
+            asm volatile("" : "+v"(kv0));
+#pragma unroll
+            for (int kbk = 0; kbk < 4; ++kbk)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (kv0 + 16 * kbk + e >= p.S) { sT[kbk][0][e] = -INFINITY; sT[kbk][1][e] = -INFINITY; }
+        }
+        float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+        for (int kbk = 0; kbk < 4; ++kbk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#ifdef ORV_M16_ABL_NOEXP
+                const float a = sT[kbk][0][e], b_ = sT[kbk][1][e];
+#else
+                const float a = fast_exp2(sT[kbk][0][e]), b_ = fast_exp2(sT[kbk][1][e]);
+#endif
+                sT[kbk][0][e] = a; sT[kbk][1][e] = b_;
+                ps0 += a; ps1 += b_;
+            }
+        l_run[0] += ps0; l_run[1] += ps1;
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                pf[s_][qb].u[0] = pack2bf(sT[2 * s_][qb][0], sT[2 * s_][qb][1]);
+                pf[s_][qb].u[1] = pack2bf(sT[2 * s_][qb][2], sT[2 * s_][qb][3]);
+                pf[s_][qb].u[2] = pack2bf(sT[2 * s_ + 1][qb][0], sT[2 * s_ + 1][qb][1]);
+                pf[s_][qb].u[3] = pack2bf(sT[2 * s_ + 1][qb][2], sT[2 * s_ + 1][qb][3]);
+            }
+    };
+
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    M16_BAR()
+    const bool act = __builtin_amdgcn_readfirstlane((int)active) != 0;
+    if (grp == 0) {
+        if (act) {
+            for (int t = 0; t < nt; ++t) {
+                seg_x(t, [&]() { if (t + 1 < nt) stage(t + 1); });
+                M16_BAR()
+                seg_y(t);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                M16_BAR()
+            }
+            seg_x(nt, [&]() {});
+        } else {
+            for (int t = 0; t < nt; ++t) {
+                if (t + 1 < nt) stage(t + 1);
+                M16_BAR()
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                M16_BAR()
+            }
+        }
+        M16_BAR()
+    } else {
+        M16_BAR()
+        if (act) {
+            for (int t = 0; t < nt; ++t) {
+                seg_x(t, [&]() {});
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                M16_BAR()
+                if (t + 1 < nt) stage(t + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                seg_y(t);
+                M16_BAR()
+            }
+            seg_x(nt, [&]() {});
+        } else {
+            for (int t = 0; t < nt; ++t) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                M16_BAR()
+                if (t + 1 < nt) stage(t + 1);
+                M16_BAR()
+            }
+        }
+    }
+#undef M16_BAR
+#undef M16_FENCE
+#undef M16_MFMA
+
+    // epilogue: lane (c, g) holds O^T[16 db + 4 g + e][query (qb, c)]; an even group keeps its d quad of db = 0 / 2 and takes the odd
+    // partner's (lane ^ 16), the odd group the other way round for db = 1 / 3: every lane stores 8 consecutive d = 16 bytes
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float l_tot = m16_sum_groups(l_run[qb]);
+        const float inv = 1.0f / l_tot;
+        const int q = q0 + 16 * qb + c;
+        bf16_t* op = p.out + (row0 + min(q, p.S - 1)) * p.ld_out + h * 64;
+#pragma unroll
+        for (int dp = 0; dp < 2; ++dp) {          // d block pair (2 dp, 2 dp + 1)
+            uint32_t x0 = pack2bf(oT[2 * dp][qb][0] * inv, oT[2 * dp][qb][1] * inv), x1 = pack2bf(oT[2 * dp][qb][2] * inv, oT[2 * dp][qb][3] * inv);
+            uint32_t y0 = pack2bf(oT[2 * dp + 1][qb][0] * inv, oT[2 * dp + 1][qb][1] * inv), y1 = pack2bf(oT[2 * dp + 1][qb][2] * inv, oT[2 * dp + 1][qb][3] * inv);
+            // v_permlane16_swap: lanes 16-31 (48-63) of the first operand <-> lanes 0-15 (32-47) of the second
+            { const auto r = __builtin_amdgcn_permlane16_swap(x0, y0, false, false); x0 = r[0]; y0 = r[1]; }
+            { const auto r = __builtin_amdgcn_permlane16_swap(x1, y1, false, false); x1 = r[0]; y1 = r[1]; }
+            // even group: x = own quad of block 2 dp, y = partner's quad of block 2 dp        -> d 32 dp + 4 g .. + 7
+            // odd group:  x = partner's quad of block 2 dp + 1, y = own quad of block 2 dp + 1 -> d 32 dp + 16 + 4 (g - 1) .. + 7
+            const int d0 = 32 * dp + ((g & 1) ? 16 + 4 * (g - 1) : 4 * g);
+            if (q < p.S) *(uint4*)(op + d0) = make_uint4(x0, x1, y0, y1);
+        }
+        if (p.lse && g == 0 && q < p.S) p.lse[((long)b * p.H + h) * p.S + q] = __log2f(l_tot) * 0.6931471805599453f;
+    }
+}
+
 }  // namespace
 
 extern "C" int orv_attention_fwd(const void* qkv, int ld_qkv, const void* vT, void* out, int ld_out, float* lse, int B,
@@ -756,7 +1052,11 @@ extern "C" int orv_attention_fwd_bounded(const void* qkv, int ld_qkv, void* out,
     dim3 grid(((S + 255) / 256) * H * B);
     static int use_pp = -1;
     if (use_pp < 0) { const char* e = getenv("ORV_ATTN_PP"); use_pp = (e && atoi(e) == 0) ? 0 : 1; }
-    if (use_pp && ld_out % 8 == 0 && ((uintptr_t)out & 15) == 0)
+    static int use_m16 = -1;         // ORV_ATTN_M16=1: the 16x16x32 form of the ping-pong kernel (A/B switch)
+    if (use_m16 < 0) { const char* e = getenv("ORV_ATTN_M16"); use_m16 = (e && atoi(e) != 0) ? 1 : 0; }
+    if (use_pp && use_m16 && ld_out % 8 == 0 && ((uintptr_t)out & 15) == 0)
+        hipLaunchKernelGGL(attn_fwd_m16_kernel, grid, dim3(512), 0, (hipStream_t)stream, a);
+    else if (use_pp && ld_out % 8 == 0 && ((uintptr_t)out & 15) == 0)
         hipLaunchKernelGGL((attn_fwd_pp_kernel<true>), grid, dim3(512), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL((attn_fwd_v2_kernel<true, true, true>), grid, dim3(512), 0, (hipStream_t)stream, a);

@@ -630,3 +630,18 @@ def test_attention_bound_too_large_takes_the_online_kernel():
     t = dq.float().cpu().view(B, S, 3, H, 64).permute(2, 0, 3, 1, 4)
     pr = torch.softmax(torch.einsum("bhqd,bhkd->bhqk", t[0], t[1]) * math.log(2.0), dim=-1)
     close(out, torch.einsum("bhqk,bhkd->bhqd", pr, t[2]).transpose(1, 2).reshape(B * S, H * 64))
+
+
+def test_attention_16x16x32_variant_matches_in_a_subprocess():
+    """The opt-in ping-pong kernel on v_mfma_f32_16x16x32_bf16 (ORV_ATTN_M16=1, read once per process): the bounded-attention
+    tests of this file, run again in a child process with the switch on, must pass against the same references."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("ORV_ATTN_M16") == "1":
+        pytest.skip("already the child")
+    env = dict(os.environ, ORV_ATTN_M16="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "bound", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout

@@ -42,12 +42,12 @@ __global__ __launch_bounds__(512) void k16(const bf16x8* in, float* out, int ite
   float s = 0; for (int i = 0; i < 32; i++) for (int e = 0; e < 4; e++) s += acc[i][e];
   out[t] = s;
 }
-template <class K> double run(K kern, int iters, const bf16x8* in, float* out) {
+template <class K> double run(K kern, int iters, const bf16x8* in, float* out, int threads = 512) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  kern<<<256, 512>>>(in, out, iters);
-  hipEventRecord(e0); for (int i = 0; i < 3; i++) kern<<<256, 512>>>(in, out, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+  kern<<<256, threads>>>(in, out, iters);
+  hipEventRecord(e0); for (int i = 0; i < 3; i++) kern<<<256, threads>>>(in, out, iters); hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
-  return 256.0 * 8 * iters * 32.0 * 16384.0 / ms / 1e9;      // both kernels: 128 x 64 x 32 MACs x 2 per iteration and wave
+  return 256.0 * (threads / 64) * iters * 32.0 * 16384.0 / ms / 1e9;      // both kernels: 128 x 64 x 32 MACs x 2 per iteration and wave
 }
 int main() {
   bf16x8* in; float* out; hipMalloc(&in, 4096 * 16); hipMalloc(&out, 256 * 512 * 4);
@@ -56,7 +56,9 @@ int main() {
   hipMemcpy(in, h, sizeof(h), hipMemcpyHostToDevice);
   for (int rep = 0; rep < 3; rep++)
     printf("random operands: 32x32x16 %.0f TFLOP/s | 16x16x32 %.0f TFLOP/s\n", run(k32, 60000, in, out), run(k16, 60000, in, out));
+  printf("one wave per SIMD (256 threads), random: 32x32x16 %.0f TFLOP/s | 16x16x32 %.0f TFLOP/s\n", run(k32, 60000, in, out, 256), run(k16, 60000, in, out, 256));
   hipMemset(in, 0, 4096 * 16);
+  printf("one wave per SIMD (256 threads), zero  : 32x32x16 %.0f TFLOP/s | 16x16x32 %.0f TFLOP/s\n", run(k32, 60000, in, out, 256), run(k16, 60000, in, out, 256));
   printf("zero operands  : 32x32x16 %.0f TFLOP/s | 16x16x32 %.0f TFLOP/s\n", run(k32, 60000, in, out), run(k16, 60000, in, out));
   return 0;
 }
