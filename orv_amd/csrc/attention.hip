@@ -37,6 +37,17 @@ struct AttnArgs {
 };
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// -DORV_SEG_TRACE (tools/attn_seg_trace.sh): per-wave time in the matrix segment, at the barrier behind it, in the vector segment and
+// at the barrier behind that, summed over the tiles (s_memrealtime ticks of 10 ns), written through the lse pointer
+#ifdef ORV_SEG_TRACE
+#define SEG_T(I) { const unsigned long long now_ = wall_clock64(); if ((I) > 0) seg_acc[(I) - 1] += now_ - seg_last; seg_last = now_; }
+#define SEG_DECL unsigned long long seg_acc[4] = {0, 0, 0, 0}, seg_last = 0;
+#define SEG_DUMP if (p.lse && lane == 0) { unsigned long long* tr_ = (unsigned long long*)p.lse + ((long)blockIdx.x * 8 + wave) * 4; for (int i_ = 0; i_ < 4; ++i_) tr_[i_] = seg_acc[i_]; }
+#else
+#define SEG_T(I)
+#define SEG_DECL
+#define SEG_DUMP
+#endif
 // max over this lane and lane ^ 32 without an LDS round trip
 __device__ __forceinline__ float max_with_partner_half(float v) {
     const unsigned u = __float_as_uint(v);
@@ -624,14 +635,20 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_pp_kernel(const AttnArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PP_BAR()
     const bool act = __builtin_amdgcn_readfirstlane((int)active) != 0;       // provably wave-uniform: real branches, no exec masking
+    SEG_DECL
     if (grp == 0) {
         if (act) {
             for (int t = 0; t < nt; ++t) {
+                SEG_T(0)
                 seg_x(t, [&]() { if (t + 1 < nt) stage(t + 1); });
+                SEG_T(1)
                 PP_BAR()
+                SEG_T(2)
                 seg_y(t);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K_{t+1} landed (this wave's pieces); visible after the barrier
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                SEG_T(3)   // K_{t+1} landed (this wave's pieces); visible after the barrier
                 PP_BAR()
+                SEG_T(4)
             }
             seg_x(nt, [&]() {});
         } else {
@@ -647,13 +664,18 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_pp_kernel(const AttnArgs p) {
         PP_BAR()
         if (act) {
             for (int t = 0; t < nt; ++t) {
+                SEG_T(0)
                 seg_x(t, [&]() {});
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // V_t landed (issued in Y_{t-1} / the prologue)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                SEG_T(1)   // V_t landed (issued in Y_{t-1} / the prologue)
                 PP_BAR()
+                SEG_T(2)
                 if (t + 1 < nt) stage(t + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 seg_y(t);
+                SEG_T(3)
                 PP_BAR()
+                SEG_T(4)
             }
             seg_x(nt, [&]() {});
         } else {
@@ -671,6 +693,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_pp_kernel(const AttnArgs p) {
     const float l_tot = sum_with_partner_half(l_run);
     const float inv = 1.0f / l_tot;
     const int q = q0 + l31;
+    SEG_DUMP
 #ifdef ORV_PP_TRACE
     // timeline build only (never the product library): (start, end, HW_ID | XCC_ID << 32, item) per workgroup through the lse pointer
     if (p.lse && tid == 0) {
@@ -679,6 +702,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_pp_kernel(const AttnArgs p) {
         tr[2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
         tr[3] = (unsigned long long)item;
     }
+    const bool write_lse = false;
+#elif defined(ORV_SEG_TRACE)
     const bool write_lse = false;
 #else
     const bool write_lse = true;
@@ -722,14 +747,10 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_pp_kernel(const AttnArgs p) {
 //     form.  V image: the 32-byte segment of d block db of key row r sits at db ^ ((r >> 1) & 3), so the 8 key rows of half a wave's
 //     transposing read fall into 8 different bank groups.
 // Everything else (slots, DMA roles, barriers, the one-barrier phase shift of the second half) is attn_fwd_pp_kernel.
-// STATUS (profiles/r3_attention_pingpong.txt, box 10-13): bit-compatible results (same tests), the clock under the kernel rises
-// from 1.71-1.80 to 1.93-2.03 GHz - the power argument holds - but it needs 24 % more cycles (waves wait 60 % longer on
-// s_waitcnt / barriers with identical LDS, VALU and MFMA-busy counts), so it is 3.5-8 % SLOWER than the 32-wide kernel and stays
-// opt-in (ORV_ATTN_M16=1) until that schedule loss is found.
-// ---------------------------------------------------------------------------------------------------------------
-// LDS-DMA from inline asm in the scalar-base form: address = SGPR pair (wave-uniform tile base) + 32-bit per-lane byte offset.  One
-// VGPR per piece instead of a 64-bit pointer, and - as in attention_bwd.hip - invisible to hipcc's pass that puts s_waitcnt vmcnt(0)
-// in front of every ds_read_b64_tr_b16 that follows an LDS-DMA builtin; completion is owned by the explicit waits of the schedule.
+// STATUS (profiles/r3_attention_pingpong.txt, box 10-15): same results (same tests); the clock under the kernel rises from 1.71-1.80
+// to 1.93-2.03 GHz - the power argument holds; with the row sums on the matrix pipe the tile loop is 6 % shorter than the 32-wide
+// kernel's (1.71 vs 1.82 us per tile and wave) and the kernel is level with it standalone (0.356-0.359 vs 0.348-0.353 ms on one box,
+// 0.358 vs 0.365 on another), but 4.5 % SLOWER in the model (0.337 vs 0.323 ms), so it stays opt-in (ORV_ATTN_M16=1).
 __device__ __forceinline__ void m16_glds16(const char* sbase, unsigned voff, const void* lds_dst) {
     unsigned keep;
     const unsigned long long u = (unsigned long long)(uintptr_t)sbase;
@@ -757,6 +778,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_m16_kernel(const AttnArgs p) 
     const int D = p.H * 64;
     const long row0 = (long)b * p.S;
     const bool active = q0 < p.S;
+#ifdef ORV_PP_TRACE
+    const unsigned long long trace_t0 = wall_clock64();
+#endif
 
     bf16x8 qf[2][2];                     // [query block][k-step]: d = 32 ks + 8 g .. + 7 of query row q0 + 16 qb + c
 #pragma unroll
@@ -811,6 +835,20 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_m16_kernel(const AttnArgs p) 
 #pragma unroll
             for (int e = 0; e < 4; ++e) pf[i][j].u[e] = 0u;
     float l_run[2] = {0.f, 0.f};
+#ifndef ORV_M16_VALUSUM
+    // Row sums on the matrix pipe: l^T (qb) += ones[16 x 32] . P^T (key step s, qb) - one extra MFMA per key step and query block
+    // (+12.5 % MFMAs) instead of 32 v_add_f32 per tile.  The per-segment timing (tools/attn_seg_trace.sh) shows why: the vector
+    // segment, not the matrix segment, is the long pole - the four waves of a SIMD need 4 x (32 quarter-rate v_exp_f32 + ~65 other
+    // VALU instructions) = ~3100 VALU cycles per tile against 2048 MFMA cycles.  Every row of the product carries the sum, so
+    // register 0 of any lane is the row sum of its query: no cross-lane reduction at the end.
+    f32x4 lT[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    union { bf16x8 v; uint32_t u[4]; } ones;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ones.u[e] = 0x3f803f80u;
+#define M16_LSUM(S_) { lT[0] = M16_MFMA(ones.v, pf[S_][0].v, lT[0]); lT[1] = M16_MFMA(ones.v, pf[S_][1].v, lT[1]); }
+#else
+#define M16_LSUM(S_)
+#endif
     // K fragment of (kbk, ks): row 16 kbk + c, 16-byte chunk 4 ks + g, swizzled by (row >> 1) & 7 = (c >> 1) & 7
     const int k_row = c * 128, k_sw = (c >> 1) & 7;
     // V^T fragment pieces: lane (c, g) addresses key 4 g + (c >> 2) (+ 32 s + 16 half) and d 16 db + 4 (c & 3); segment db ^ fz
@@ -848,6 +886,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_m16_kernel(const AttnArgs p) 
             M16_FENCE()
             oT[0][0] = M16_MFMA(v0, pf[0][0].v, oT[0][0]); oT[0][1] = M16_MFMA(v0, pf[0][1].v, oT[0][1]);
             oT[1][0] = M16_MFMA(v1, pf[0][0].v, oT[1][0]); oT[1][1] = M16_MFMA(v1, pf[0][1].v, oT[1][1]);
+            M16_LSUM(0)
             M16_FENCE()
             v0 = vread(0, 1); v1 = vread(1, 1);
             M16_FENCE()
@@ -862,6 +901,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_m16_kernel(const AttnArgs p) 
             M16_FENCE()
             oT[0][0] = M16_MFMA(v0, pf[1][0].v, oT[0][0]); oT[0][1] = M16_MFMA(v0, pf[1][1].v, oT[0][1]);
             oT[1][0] = M16_MFMA(v1, pf[1][0].v, oT[1][0]); oT[1][1] = M16_MFMA(v1, pf[1][1].v, oT[1][1]);
+            M16_LSUM(1)
             M16_FENCE()
             if (t < nt) { ke = kread(0, 1); kf = kread(1, 1); }      // the dying V fragments / P make room for the second k-step
             M16_FENCE()
@@ -914,7 +954,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_m16_kernel(const AttnArgs p) 
                 const float a = fast_exp2(sT[kbk][0][e]), b_ = fast_exp2(sT[kbk][1][e]);
 #endif
                 sT[kbk][0][e] = a; sT[kbk][1][e] = b_;
+#ifdef ORV_M16_VALUSUM
                 ps0 += a; ps1 += b_;
+#endif
             }
         l_run[0] += ps0; l_run[1] += ps1;
 #pragma unroll
@@ -932,14 +974,20 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_m16_kernel(const AttnArgs p) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     M16_BAR()
     const bool act = __builtin_amdgcn_readfirstlane((int)active) != 0;
+    SEG_DECL
     if (grp == 0) {
         if (act) {
             for (int t = 0; t < nt; ++t) {
+                SEG_T(0)
                 seg_x(t, [&]() { if (t + 1 < nt) stage(t + 1); });
+                SEG_T(1)
                 M16_BAR()
+                SEG_T(2)
                 seg_y(t);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                SEG_T(3)
                 M16_BAR()
+                SEG_T(4)
             }
             seg_x(nt, [&]() {});
         } else {
@@ -955,13 +1003,18 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_m16_kernel(const AttnArgs p) 
         M16_BAR()
         if (act) {
             for (int t = 0; t < nt; ++t) {
+                SEG_T(0)
                 seg_x(t, [&]() {});
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                SEG_T(1)
                 M16_BAR()
+                SEG_T(2)
                 if (t + 1 < nt) stage(t + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 seg_y(t);
+                SEG_T(3)
                 M16_BAR()
+                SEG_T(4)
             }
             seg_x(nt, [&]() {});
         } else {
@@ -977,11 +1030,24 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_m16_kernel(const AttnArgs p) 
 #undef M16_FENCE
 #undef M16_MFMA
 
+    SEG_DUMP
+#ifdef ORV_PP_TRACE
+    if (p.lse && tid == 0) {
+        unsigned long long* tr = (unsigned long long*)p.lse + (long)blockIdx.x * 4;
+        tr[0] = trace_t0; tr[1] = wall_clock64();
+        tr[2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
+        tr[3] = (unsigned long long)item;
+    }
+#endif
     // epilogue: lane (c, g) holds O^T[16 db + 4 g + e][query (qb, c)]; an even group keeps its d quad of db = 0 / 2 and takes the odd
     // partner's (lane ^ 16), the odd group the other way round for db = 1 / 3: every lane stores 8 consecutive d = 16 bytes
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
+#ifdef ORV_M16_VALUSUM
         const float l_tot = m16_sum_groups(l_run[qb]);
+#else
+        const float l_tot = lT[qb][0];
+#endif
         const float inv = 1.0f / l_tot;
         const int q = q0 + 16 * qb + c;
         bf16_t* op = p.out + (row0 + min(q, p.S - 1)) * p.ld_out + h * 64;
@@ -997,7 +1063,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_m16_kernel(const AttnArgs p) 
             const int d0 = 32 * dp + ((g & 1) ? 16 + 4 * (g - 1) : 4 * g);
             if (q < p.S) *(uint4*)(op + d0) = make_uint4(x0, x1, y0, y1);
         }
+#if !defined(ORV_SEG_TRACE) && !defined(ORV_PP_TRACE)
         if (p.lse && g == 0 && q < p.S) p.lse[((long)b * p.H + h) * p.S + q] = __log2f(l_tot) * 0.6931471805599453f;
+#endif
     }
 }
 

@@ -18,10 +18,11 @@ int main(int argc,char**argv){ int B=argc>1?atoi(argv[1]):4, S=argc>2?atoi(argv[
     hipEventRecord(e0); for(int i=0;i<it;i++) orv_attention_fwd_bounded(qkv,3*H*64,out,H*64,nullptr,B,S,H,sc,bd,nullptr); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms,e0,e1); ms/=it;
     printf("attention(bounded %.1f) B=%d S=%d H=%d: %.4f ms  %.1f TFLOP/s\n",bd,B,S,H,ms,4.0*B*H*(double)S*S*64/ms/1e9);
     if(getenv("TRACE")){   // library built with -DORV_PP_TRACE: per-workgroup (start, end, HW_ID | XCC_ID << 32, item) through the lse pointer
-      int nwg=((S+255)/256)*H*B; unsigned long long* tr; hipMalloc(&tr,(size_t)B*H*S*4+nwg*32); hipMemset(tr,0,nwg*32);
+      int nwg=((S+255)/256)*H*B; const int words = getenv("TRACE_WORDS") ? atoi(getenv("TRACE_WORDS")) : 4;   // u64 per workgroup
+      unsigned long long* tr; hipMalloc(&tr,(size_t)B*H*S*4+(size_t)nwg*words*8); hipMemset(tr,0,(size_t)nwg*words*8);
       orv_attention_fwd_bounded(qkv,3*H*64,out,H*64,(float*)tr,B,S,H,sc,bd,nullptr); hipDeviceSynchronize();
-      std::vector<unsigned long long> t(nwg*4); hipMemcpy(t.data(),tr,nwg*32,hipMemcpyDeviceToHost);
-      FILE* f=fopen(getenv("TRACE"),"w"); for(int i=0;i<nwg;i++) fprintf(f,"%d %llu %llu %llu %llu\n",i,t[i*4],t[i*4+1],t[i*4+2],t[i*4+3]); fclose(f); }
+      std::vector<unsigned long long> t((size_t)nwg*words); hipMemcpy(t.data(),tr,(size_t)nwg*words*8,hipMemcpyDeviceToHost);
+      FILE* f=fopen(getenv("TRACE"),"w"); for(int i=0;i<nwg;i++){ fprintf(f,"%d",i); for(int w=0;w<words;w++) fprintf(f," %llu",t[(size_t)i*words+w]); fprintf(f,"\n"); } fclose(f); }
     return 0; }
   for(int i=0;i<3;i++) orv_attention_fwd(qkv,3*H*64,vt_arg,out,H*64,nullptr,B,S,H,s_pad,sc,nullptr);
   hipEventRecord(e0); for(int i=0;i<20;i++) orv_attention_fwd(qkv,3*H*64,vt_arg,out,H*64,nullptr,B,S,H,s_pad,sc,nullptr); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms,e0,e1); ms/=20;
