@@ -285,15 +285,15 @@ def scatter_f32_to_bf16(src, segments):
     _need(src, torch.float32, "src")
     if not segments:
         return
+    for o, d in segments:                    # every call: a recycled address must not smuggle another dtype past the cached table
+        _need(d, BF16, "destination")
+        if not d.is_contiguous() or o < 0 or o + d.numel() > src.numel():
+            raise ValueError("scatter_f32_to_bf16: destinations must be contiguous and sources inside `src`")
     key = (src.device.index, tuple((int(o), d.data_ptr(), d.numel()) for o, d in segments))
     tab = _scatter_tables.get(key)
     if tab is None:
         if len(_scatter_tables) > 16:
             _scatter_tables.clear()
-        for o, d in segments:
-            _need(d, BF16, "destination")
-            if not d.is_contiguous() or o < 0 or o + d.numel() > src.numel():
-                raise ValueError("scatter_f32_to_bf16: destinations must be contiguous and sources inside `src`")
         dev = src.device
         tab = (torch.tensor([k[0] for k in key[1]], dtype=torch.int64, device=dev),
                torch.tensor([k[1] for k in key[1]], dtype=torch.int64, device=dev),
