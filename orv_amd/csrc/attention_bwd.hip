@@ -74,6 +74,19 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const bf16_t* __restrict_
     }
 }
 
+// -DORV_SEG_TRACE (tools/attn_bwd_seg_trace.sh): per-wave time in the matrix segment, at the barrier behind it, in the vector segment
+// and at the barrier behind that, summed over the tiles (s_memrealtime ticks of 10 ns); the buffer is handed over by
+// orv_debug_attn_bwd_trace(), which exists in such builds only
+#ifdef ORV_SEG_TRACE
+__device__ unsigned long long* g_bwd_trace = nullptr;
+#define SEG_T(I) { const unsigned long long now_ = wall_clock64(); if ((I) > 0) seg_acc[(I) - 1] += now_ - seg_last; seg_last = now_; }
+#define SEG_DECL unsigned long long seg_acc[4] = {0, 0, 0, 0}, seg_last = 0;
+#define SEG_DUMP(K) if (g_bwd_trace && lane == 0) { unsigned long long* tr_ = g_bwd_trace + ((long)(K) * gridDim.x * 8 + (long)blockIdx.x * 8 + wave) * 4; for (int i_ = 0; i_ < 4; ++i_) tr_[i_] = seg_acc[i_]; }
+#else
+#define SEG_T(I)
+#define SEG_DECL
+#define SEG_DUMP(K)
+#endif
 struct BwdArgs {
     const bf16_t* qkv; long ld;      // q' | k | v (after orv_qkv_prep)
     const bf16_t* qT; const bf16_t* kT; const bf16_t* doT;   // [B,H,64,s_pad]
@@ -360,6 +373,26 @@ __device__ __forceinline__ void glds4_asm(const void* gsrc, const void* lds_dst)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(d) : "memory");
 }
+// the same from a wave-uniform base (SGPR pair) + a 32-bit per-lane byte offset: one VGPR per stream instead of a 64-bit pointer
+__device__ __forceinline__ unsigned long long bw_uniform64(const void* q) {
+    const unsigned long long u = (unsigned long long)(uintptr_t)q;
+    const unsigned hi_ = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(u >> 32)), lo_ = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)u);
+    return ((unsigned long long)hi_ << 32) | lo_;        // (the builtin returns int: unsigned first, or bit 31 of the low word smears)
+}
+__device__ __forceinline__ void glds16_sv(const void* sbase, unsigned voff, const void* lds_dst) {
+    unsigned keep;
+    const unsigned long long su = bw_uniform64(sbase);
+    const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(su), "s"(d) : "memory");
+}
+__device__ __forceinline__ void glds4_sv(const void* sbase, unsigned voff, const void* lds_dst) {
+    unsigned keep;
+    const unsigned long long su = bw_uniform64(sbase);
+    const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(su), "s"(d) : "memory");
+}
 __device__ __forceinline__ int swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 typedef short v4i16 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 tr_pair(const char* a, const char* b) {
@@ -539,15 +572,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(const BwdArgs p)
         asm volatile("" ::"v"(sT[0]), "v"(sT[1]), "v"(dP[0]), "v"(dP[1]));
         return;
 #endif
-        const bool tail = ragged && t == nt - 1;
+        // keys past S (ragged last tile only): score -> -inf, P = 0.  A separate, uniform branch: folded into the element loop the
+        // compare + select pair (and the s_nop between them) ran for EVERY element of EVERY tile - 190 instead of 64 VALU
+        // instructions per tile in a segment that has the SIMD's VALU port to itself (tools/attn_bwd_seg_trace.py: 860-1070 ns)
+        if (__builtin_expect(ragged && t == nt - 1, 0)) {
+            int kv0 = t * 64 + 4 * hi;
+            asm volatile("" : "+v"(kv0));
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) >= p.S) sT[kb][r] = -INFINITY;
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pv = __builtin_amdgcn_exp2f(sT[kb][r]);
-                if (tail) pv = (t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.S) ? 0.f : pv;
-                sT[kb][r] = pv * dP[kb][r];      // dS^T = P (dP - delta)
-            }
+            for (int r = 0; r < 16; ++r) sT[kb][r] = __builtin_amdgcn_exp2f(sT[kb][r]) * dP[kb][r];      // dS^T = P (dP - delta)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -560,14 +600,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(const BwdArgs p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     BW_BAR()
     const bool act = __builtin_amdgcn_readfirstlane((int)(q0 < p.S)) != 0;
+    SEG_DECL
     if (grp == 0) {
         if (act) {
             for (int t = 0; t < nt; ++t) {
+                SEG_T(0)
                 seg_x(t, [&]() { stage(t + 1); });              // K_{t+1} -> slot of K_{t-2} (last read in the partners' X_{t-1})
+                SEG_T(1)
                 BW_BAR()
+                SEG_T(2)
                 seg_y(t);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                SEG_T(3)
                 BW_BAR()
+                SEG_T(4)
             }
             seg_x(nt, [&]() {});
         } else {
@@ -583,13 +629,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(const BwdArgs p)
         BW_BAR()
         if (act) {
             for (int t = 0; t < nt; ++t) {
+                SEG_T(0)
                 seg_x(t, [&]() {});
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // V_{t+1} landed (issued in Y_{t-1} / the prologue)
+                SEG_T(1)
                 BW_BAR()
+                SEG_T(2)
                 stage(t + 2);                                    // V_{t+2} -> slot of V_t (last read in this half's X_t)
                 BW_FENCE()
                 seg_y(t);
+                SEG_T(3)
                 BW_BAR()
+                SEG_T(4)
             }
             seg_x(nt, [&]() {});
         } else {
@@ -601,6 +652,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(const BwdArgs p)
             }
         }
     }
+    SEG_DUMP(0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int q = q0 + l31;
     if (q < p.S) store_row16(p.dqkv + (row0 + q) * p.ld_dqkv + h * 64 + hi * 8, dq, p.scale);
@@ -634,16 +686,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p
     const int nt = (p.S + 63) / 64;
     const bool ragged = (p.S & 63) != 0;
     const long hb = (long)(b * p.H + h);
-    auto src_of = [&](int j, int t) {
+    // DMA sources: wave-uniform base + 32-bit per-lane byte offsets (the 64-bit lane pointers of the first form were what the
+    // allocator spilled inside the tile loop, and their reload put s_waitcnt vmcnt(0) between the DMA instructions of a tile)
+    const long ldx = grp == 0 ? p.ld : p.ld_do;
+    const char* const bbase = (const char*)((grp == 0 ? p.qkv : p.dout) + row0 * ldx + h * 64);     // batch base of this head's columns
+    unsigned loff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
         const int sr = wq * 16 + j * 8 + (lane >> 3), slot = lane & 7;
-        const long r = row0 + min(t * 64 + sr, p.S - 1);
-        return (grp == 0 ? p.qkv + r * p.ld : p.dout + r * p.ld_do) + h * 64 + (slot ^ swz(sr)) * 8;
-    };
-    const bf16_t* const sbase0 = src_of(0, 0);
-    const bf16_t* const sbase1 = src_of(1, 0);
-    const long tstep = 64 * (grp == 0 ? p.ld : p.ld_do);
+        loff[j] = (unsigned)((sr * (int)ldx + (slot ^ swz(sr)) * 8) * 2);
+    }
     char* const sdst = smem + grp * 3 * TILE + wq * 2048;
-    const float* const vsrc = (grp == 0 ? p.neg_lse2 : p.neg_delta) + hb * p.s_pad + lane;
+    const char* const vbase = (const char*)((grp == 0 ? p.neg_lse2 : p.neg_delta) + hb * p.s_pad);
     char* const vdst = smem + 6 * TILE + grp * 3 * 256;
     auto stage = [&](int t) {
         if (t >= nt) return;
@@ -652,14 +706,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p
 #endif
         char* const d = sdst + (t % 3) * TILE;
         if (__builtin_expect(ragged && t == nt - 1, 0)) {
-            glds16_asm(src_of(0, t), d);
-            glds16_asm(src_of(1, t), d + 1024);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {          // rows past S read a valid row (masked in the vector segment)
+                const int sr = wq * 16 + j * 8 + (lane >> 3), slot = lane & 7;
+                glds16_sv(bbase, (unsigned)((min(t * 64 + sr, p.S - 1) * (int)ldx + (slot ^ swz(sr)) * 8) * 2), d + j * 1024);
+            }
         } else {
-            glds16_asm(sbase0 + (long)t * tstep, d);
-            glds16_asm(sbase1 + (long)t * tstep, d + 1024);
+            const char* const tb = bbase + (long)t * 64 * ldx * 2;
+            glds16_sv(tb, loff[0], d);
+            glds16_sv(tb, loff[1], d + 1024);
         }
         // the tile's 64-float vector travels by LDS-DMA too (a register round trip would put a vmcnt(0) behind the tile loads)
-        if (wq == 0) glds4_asm(vsrc + t * 64, vdst + (t % 3) * 256);
+        if (wq == 0) glds4_sv(vbase + (long)t * 256, (unsigned)(lane * 4), vdst + (t % 3) * 256);
     };
     f32x16 dk[2], dv[2], sS[2], dP[2];
 #pragma unroll
@@ -772,14 +830,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p
         asm volatile("" ::"v"(sS[0]), "v"(sS[1]), "v"(dP[0]), "v"(dP[1]));
         return;
 #endif
-        const bool tail = ragged && t == nt - 1;
+        // (rows of keys >= S compute garbage that is never stored; only query rows >= S must not contribute: ragged last tile only,
+        // as a uniform branch ahead of the element loop - see attn_bwd_dq_pp_kernel)
+        if (__builtin_expect(ragged && t == nt - 1, 0)) {
+            int qv0 = t * 64 + 4 * hi;
+            asm volatile("" : "+v"(qv0));
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (qv0 + qb * 32 + (r & 3) + 8 * (r >> 2) >= p.S) sS[qb][r] = -INFINITY;
+        }
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                // (rows of keys >= S compute garbage that is never stored; only query rows >= S must not contribute)
-                float pv = __builtin_amdgcn_exp2f(sS[qb][r]);
-                if (tail) pv = (t * 64 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.S) ? 0.f : pv;
+                const float pv = __builtin_amdgcn_exp2f(sS[qb][r]);
                 sS[qb][r] = pv;                 // P
                 dP[qb][r] = pv * dP[qb][r];     // dS
             }
@@ -798,14 +864,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     BW_BAR()
     const bool act = __builtin_amdgcn_readfirstlane((int)(k0 < p.S)) != 0;
+    SEG_DECL
     if (grp == 0) {
         if (act) {
             for (int t = 0; t < nt; ++t) {
+                SEG_T(0)
                 seg_x(t, [&]() { stage(t + 1); });
+                SEG_T(1)
                 BW_BAR()
+                SEG_T(2)
                 seg_y(t);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                SEG_T(3)
                 BW_BAR()
+                SEG_T(4)
             }
             seg_x(nt, [&]() {});
         } else {
@@ -821,13 +893,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p
         BW_BAR()
         if (act) {
             for (int t = 0; t < nt; ++t) {
+                SEG_T(0)
                 seg_x(t, [&]() {});
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                SEG_T(1)
                 BW_BAR()
+                SEG_T(2)
                 stage(t + 2);                                    // dO_{t+2} -> slot of dO_{t-1} (last read in this half's X_t)
                 BW_FENCE()
                 seg_y(t);
+                SEG_T(3)
                 BW_BAR()
+                SEG_T(4)
             }
             seg_x(nt, [&]() {});
         } else {
@@ -839,6 +916,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p
             }
         }
     }
+    SEG_DUMP(1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int key = k0 + l31;
     if (key < p.S) {
@@ -967,6 +1045,13 @@ extern "C" int orv_head_transpose(const void* src, int ld, int col0, void* dst, 
 // qT / kT / doT (per-head transposed copies written by orv_head_transpose) feed the two-pass kernels of rounds 1-2 only; with all
 // three NULL - what the host passes since round 3 - the ping-pong kernels read K^T / Q'^T / dO^T with transposing LDS reads from the
 // row-major tiles.  ORV_ATTN_BWD_PP=0 + non-NULL copies: the old kernels (A/B).
+#ifdef ORV_SEG_TRACE
+extern "C" int orv_debug_attn_bwd_trace(void* buf) {      // variant builds only: where the kernels leave their segment times
+    unsigned long long* q = (unsigned long long*)buf;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_trace), &q, sizeof(q)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 namespace {
 // per-device side stream + fork / join events of orv_attention_bwd (created on first use, kept)
 struct BwdSide { hipStream_t stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool ok = false, tried = false; };
