@@ -132,10 +132,81 @@ def cpu_baseline(cfg, layers, threads):
     dt_bf, per_bf = timed(max(1, layers // 3), best, torch.bfloat16)
     torch.set_num_threads(threads)
     return {"value": 1.0 / per_step, "unit": "denoise-steps/s", "cores": best, "kind": "port",
-            "sample": f"1 clip x 1 step, fp32 eager PyTorch oracle, {layers}/30 blocks timed ({dt:.2f} s) and scaled to 30; "
+            "sample": f"1 clip x 1 step, fp32 eager PyTorch oracle, {layers}/30 blocks timed ({dt:.2f} s)" + ("" if layers == 30 else " and scaled to 30") + "; "
                       f"threads = best of a one-block sweep",
             "s_per_step": per_step, "thread_sweep_s_per_block": {str(k): round(v, 3) for k, v in sweep.items()},
             "variants": [{"dtype": "bf16", "cores": best, "s_per_step": per_bf, "sample": f"{max(1, layers // 3)}/30 blocks ({dt_bf:.2f} s)"}]}
+
+
+def live_pmc(dom_symbol, timeout_s=420):
+    """MFMA-busy fraction, clock and fabric bytes per launch of the dominant kernel symbol, measured NOW: three separate
+    `rocprofv3 --pmc` passes (SQ + GRBM | FETCH_SIZE | WRITE_SIZE; no tracing flags - MI355X_MICROARCH.md "rocprofv3 PMC slots")
+    of a two-step eager run of this same script in a child process.  FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64
+    B) and WRITE_SIZE calibrated on ln_mod_kernel's known write volume, as tools/pmc_bench.py does.  Returns None when
+    rocprofv3 is not on PATH or a pass fails; the caller then falls back to the committed profile."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    out = tempfile.mkdtemp(prefix="orv_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--eager", "--no-legs", "--no-vae",
+             "--no-cpu-baseline", "--no-pmc"]
+    sym = lambda name: name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
+    res = {}
+    t_start = time.time()
+    try:
+        for name, ctrs in (("sq", ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]), ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])):
+            left = timeout_s - (time.time() - t_start)
+            if left < 30:
+                break
+            subprocess.run([exe, "--pmc", *ctrs, "--output-format", "csv", "-d", out, "-o", name, "--", *child], cwd="/tmp", env=env,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, stdin=subprocess.DEVNULL, timeout=left, check=True)
+            agg = collections.defaultdict(lambda: collections.defaultdict(float))
+            dur, seen = collections.defaultdict(float), set()
+            n = collections.defaultdict(int)
+            for f in glob.glob(os.path.join(out, "**", f"{name}_counter_collection.csv"), recursive=True):
+                with open(f, newline="") as fh:
+                    for r in csv.DictReader(fh):
+                        k = sym(r["Kernel_Name"])
+                        if k != dom_symbol and not k.startswith("ln_mod_kernel"):
+                            continue
+                        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                        if r["Dispatch_Id"] not in seen:
+                            seen.add(r["Dispatch_Id"])
+                            n[k] += 1
+                            dur[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            res[name] = (agg, dur, n)
+        if "sq" not in res or dom_symbol not in res["sq"][0]:
+            return None
+        agg, dur, n = res["sq"]
+        gui = agg[dom_symbol]["GRBM_GUI_ACTIVE"] / 8.0
+        r = {"mfma_busy": round(agg[dom_symbol]["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * gui), 4) if gui else None,
+             "clock_ghz": round(gui / dur[dom_symbol], 3) if dur[dom_symbol] else None, "launches_under_pmc": n[dom_symbol],
+             "avg_us_under_pmc": round(dur[dom_symbol] / n[dom_symbol] / 1e3, 2), "traffic": None}
+        if "fetch" in res and "write" in res and dom_symbol in res["fetch"][0] and dom_symbol in res["write"][0]:
+            fa, _, fn = res["fetch"]
+            wa, _, wn = res["write"]
+            cal = 1.0
+            lnk = next((k for k in wa if k.startswith("ln_mod_kernel")), None)
+            if lnk and wn[lnk]:
+                known = 4 * 3226 * 1920 * 2
+                meas = wa[lnk]["WRITE_SIZE"] / wn[lnk] * 1024
+                if meas > 0 and 0.9 < known / meas < 1.1:
+                    cal = known / meas
+            fb = 2.0 * 1024 * fa[dom_symbol]["FETCH_SIZE"] / fn[dom_symbol]
+            wb = cal * 1024 * wa[dom_symbol]["WRITE_SIZE"] / wn[dom_symbol]
+            r.update(traffic=int(fb + wb), fetch_bytes=int(fb), write_bytes=int(wb), write_calibration=round(cal, 4))
+        return r
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
 
 
 def ranks_seen(world, dev):
@@ -303,13 +374,14 @@ def main():
     ap.add_argument("--graph", action="store_true", help="(default since round 3) replay the transformer forward from a HIP graph")
     ap.add_argument("--eager", action="store_true", help="time the eager launch path instead of the HIP-graph replay")
     ap.add_argument("--no-legs", action="store_true", help="skip the b1 / train legs reported beside the headline (N = 1 only)")
-    ap.add_argument("--cpu-baseline-layers", type=int, default=6)
+    ap.add_argument("--cpu-baseline-layers", type=int, default=30, help="blocks of the CPU oracle that are timed (30 = the whole step)")
     ap.add_argument("--model", choices=["2b", "5b"], default="2b",
                     help="2b = the headline (BASELINE configs[1]/[2]); 5b = configs[4] (CogVideoX1.5-5B, DROID 256x384x29f, p_t=2, "
                          "RoPE, ofs) - train mode only")
     ap.add_argument("--grad-ckpt", dest="grad_ckpt", action="store_true",
                     help="train mode: gradient checkpointing (block inputs kept, activations recomputed in the backward)")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE-decode leg (frames/s including decode)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the three live rocprofv3 --pmc passes for roofline.traffic / mfma_busy")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch the ranks, rendezvous (gloo, no GPU work), print the ranks seen and exit: checks the launcher")
     args = ap.parse_args()
@@ -395,12 +467,21 @@ def main():
     for i in range(max(args.warmup, 3 if use_graph else 0)):        # a graph needs one eager + one capturing call before it replays
         lat = step(i, lat)
     barrier()
+    # per-step HIP events on the launch stream (median + p10 / p90): K + 1 events around the K steps; recording an event
+    # is a stream marker, not a synchronisation - the loop below is still one uninterrupted submission sequence
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     lat = latents
+    evs[0].record()
     for i in range(args.steps):
         lat = step(i, lat)
+        evs[i + 1].record()
     barrier()
     wall = time.perf_counter() - t0
+    step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+    pct = lambda q: step_ms[min(len(step_ms) - 1, max(0, int(round(q * (len(step_ms) - 1)))))]
+    step_stats = {"median_ms": round(pct(0.5), 3), "p10_ms": round(pct(0.1), 3), "p90_ms": round(pct(0.9), 3),
+                  "min_ms": round(step_ms[0], 3), "max_ms": round(step_ms[-1], 3)}
     assert torch.isfinite(lat.float()).all(), "non-finite latents"
     # per-kernel timeline: eager loop, outside the timed region (same kernels, same shapes, same stream)
     n_tl = args.steps if not use_graph else min(args.steps, 10)
@@ -440,9 +521,75 @@ def main():
         legs["b1"] = {"workload": "configs[1] at B = 1 (the demo entry point), 20 steps", "ms_per_step": round(1e3 * (time.perf_counter() - tb) / 20, 3),
                       "timed_path": "hip-graph replay" if use_graph else "eager"}
         del s1, x1
-        # train: configs[2] on this GPU (last: the fused optimizer moves the parameters into its flat buffers)
         model.action_embed.forced_mask = torch.zeros(B, dtype=torch.bool)
+
+        def timed_steps(stepfn, x0, n_warm, n):
+            x = x0
+            for i in range(n_warm):
+                x = stepfn(i, x)
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for i in range(n):
+                x = stepfn(i, x)
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t_) / n
+
+        # attn_online: the same headline step when the qk-LayerNorm parameters give NO usable score bound (a checkpoint whose
+        # max|gamma_q| max|gamma_k| exceeds ~7.6: the fixed-shift softmax is not valid and every block runs the online-softmax
+        # kernel) - Attention.score_bound is overridden to "unknown" for this leg only
+        from orv_amd import cogvideox_control as cc
+        keep_sb = cc.Attention.score_bound
+        try:
+            cc.Attention.score_bound = lambda self, scale: None
+            so = make_step(GraphedTransformer(model) if use_graph else model, B, image_latents, prompt, controls)
+            legs["attn_online"] = {"workload": "configs[1] at B = %d with the online-softmax attention kernel in every block (no score bound), 10 steps" % B,
+                                   "ms_per_step": round(timed_steps(so, latents, 3, 10), 3),
+                                   "fixed_shift_valid_up_to_log2_units": 90.0, "random_init_bound_log2_units": round(float(keep_sb(model.transformer_blocks[0].attn1, 0.125)), 2)}
+            del so
+        finally:
+            cc.Attention.score_bound = keep_sb
+        # cond: BASELINE configs[3] (config/traj_image_condfull_2b_finetune.yaml: visual_guidance, control_keys depth + label;
+        # cogvideox_control.py:828-858) - a second 2B model with the guidance fuse, depth / label maps through the same patch-embed
+        try:
+            torch.manual_seed(43)
+            mc = build_model({**cfg, "visual_guidance": True, "num_control_keys": 2}, dev)
+            mc.action_embed.forced_mask = torch.zeros(B, dtype=torch.bool)
+            gcond = torch.Generator().manual_seed(44)
+            depths = torch.randn(B, 5, 32, 40, 60, generator=gcond).to(dev, torch.bfloat16)
+            labels = torch.randn(B, 5, 32, 40, 60, generator=gcond).to(dev, torch.bfloat16)
+            sc = make_step(GraphedTransformer(mc) if use_graph else mc, B, image_latents, prompt,
+                           {"actions": actions, "depths": depths, "labels": labels})
+            legs["cond"] = {"workload": "configs[3]: occupancy-conditioned CogVideoX-2B (visual_guidance, depth + label control maps), B = %d, 5 steps" % B,
+                            "ms_per_step": round(timed_steps(sc, latents, 3, 5), 3), "timed_path": "hip-graph replay" if use_graph else "eager"}
+            del sc, mc, depths, labels
+        except Exception as e:      # a leg must never take the headline line down
+            legs["cond"] = {"error": repr(e)[:300]}
+        # train: configs[2] on this GPU (the fused optimizer moves the parameters into its flat buffers: after the inference legs)
         legs["train"] = train_mode(args, model, latents, image_latents, prompt, actions, sched, dev, rank, world, leg=(3, 5))
+        # train_5b_ckpt: configs[4] (CogVideoX1.5-5B, DROID 256x384x29f, p_t = 2, RoPE, ofs, activation checkpointing), 1 + 2 steps
+        try:
+            import copy
+            import gc
+            del fwd, step, eager_step
+            model = None
+            gc.collect()
+            torch.cuda.empty_cache()
+            a5 = copy.copy(args)
+            a5.grad_ckpt = True
+            cfg5 = {**CFG_5B, "num_layers": 42}
+            m5 = build_model(cfg5, dev)
+            m5.action_embed.forced_mask = torch.zeros(B, dtype=torch.bool)
+            l5, il5, p5, ac5 = synthetic_inputs(B, dev, torch.bfloat16, frames=8, h=32, w=48)
+            sched5 = schedulers.CogVideoXDDIMScheduler(**{**SCHED, "snr_shift_scale": 1.0})
+            r5 = train_mode(a5, m5, l5, il5, p5, ac5, sched5, dev, rank, world, cfg=cfg5, leg=(1, 2))
+            r5["workload"] = ("configs[4]: CogVideoX1.5-5B SFT step, DROID 256x384x29f latents [B,8,16,32,48], p_t=2, RoPE, ofs, bf16 "
+                              "params + grads, activation checkpointing (block-level recompute)")
+            S5 = 226 + (8 // 2) * 16 * 24
+            r5["achieved_tflops_attn_ffn"] = round(r5["clips_per_sec"] * 3.0 * flops_per_sample(cfg5, S5) / 1e12, 1)
+            legs["train_5b_ckpt"] = r5
+            del m5
+        except Exception as e:
+            legs["train_5b_ckpt"] = {"error": repr(e)[:300]}
 
     if rank == 0:
         S = 226 + 3000
@@ -484,21 +631,34 @@ def main():
         if dom:
             dom["avg_ms"] = round(dom["total_ms"] / dom["launches"], 4)
             dom["tflops"] = round(dom["flop"] / dom["total_ms"] / 1e9, 1)
-        # PMC figures of the dominant symbol come from the committed profile of this same command (tools/pmc_bench.sh: separate
-        # rocprofv3 --pmc passes); they are not re-measured live
+        # PMC figures of the dominant symbol: measured live (three rocprofv3 --pmc passes of a two-step child run) when rocprofv3 is
+        # on PATH, else read from the committed profile of this same command (tools/pmc_bench.sh)
         traffic = mfma_busy = clock = None
+        pmc_source = None
+        if dom and world == 1 and not args.no_pmc and args.layers == 30:
+            pm = live_pmc(dom["kernel"])
+            if pm is not None:
+                traffic, mfma_busy, clock = pm.get("traffic"), pm.get("mfma_busy"), pm.get("clock_ghz")
+                pmc_source = {"how": "live: rocprofv3 --pmc passes (SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE | FETCH_SIZE | WRITE_SIZE) of a "
+                                     "two-step eager child run after the timed region; FETCH x 2, WRITE calibrated on ln_mod_kernel", **pm}
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if dom and os.path.exists(prof):
+        if dom and (traffic is None or mfma_busy is None) and os.path.exists(prof):
             try:
                 ent = json.load(open(prof)).get(dom["kernel"])
                 if ent is not None:
-                    traffic, mfma_busy, clock = int(ent.get("total_bytes")), ent.get("mfma_busy"), ent.get("clock_ghz")
+                    if traffic is None:
+                        traffic = int(ent.get("total_bytes"))
+                    if mfma_busy is None:
+                        mfma_busy, clock = ent.get("mfma_busy"), ent.get("clock_ghz")
+                    pmc_source = pmc_source or ("roofline.traffic / mfma_busy / clock_ghz_under_pmc are read from profiles/hbm_traffic.json "
+                                                "(separate rocprofv3 --pmc passes of this command, tools/pmc_bench.sh), not re-measured in this run")
             except Exception:
-                traffic = mfma_busy = clock = None
+                pass
         line = {
             "metric": "denoise-steps/sec", "value": round(value, 3), "unit": "steps/s (clips x denoise steps per second)",
             "n_gpus": world, "ranks_seen": seen, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * wall / args.steps, 3),
+            "ms_per_step": round(1e3 * wall / args.steps, 3), **step_stats,
+            "step_stats": "median / p10 / p90 / min / max of the K per-step HIP-event intervals on the launch stream (rank 0)",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "frames_per_sec": round(17.0 * world * B * args.steps / 50.0 / wall, 3),
             "achieved_tflops_attn_ffn": round(value * fl / 1e12, 1),
@@ -517,10 +677,10 @@ def main():
             "eager_ms_per_step": round(eager_ms, 3),
             "kernel_timeline": f"HIP events on the launch stream over a separate eager loop of {n_tl} steps after the timed region",
             "lib": {"path": os.path.relpath(LIB_PATH, ROOT), "orv_version": int(lib().orv_version())},
-            "pmc_source": "roofline.traffic / mfma_busy / clock_ghz_under_pmc are read from profiles/hbm_traffic.json (separate rocprofv3 "
-                          "--pmc passes of this command, tools/pmc_bench.sh), not re-measured in this run",
+            "pmc_source": pmc_source,
             "vae_decode": vae_leg,
-            "b1": legs.get("b1"), "train": legs.get("train"),
+            "b1": legs.get("b1"), "attn_online": legs.get("attn_online"), "cond": legs.get("cond"), "train": legs.get("train"),
+            "train_5b_ckpt": legs.get("train_5b_ckpt"),
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = max(1, (os.cpu_count() or 2) // 2)

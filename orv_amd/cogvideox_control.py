@@ -875,13 +875,17 @@ class GraphedTransformer:
         return out
 
     def _weights_version(self):
-        """In-place edits bump ``_version``; storage moves (``p.data = ...``: FusedAdamW's flat layout, ``.to()``) change
-        ``data_ptr``.  The parameter list is collected once (the module walk is the expensive part of this key on the B = 1
-        path the graph exists to speed up)."""
+        """In-place edits bump ``_version``; storage moves (``p.data = ...``: FusedAdamW's flat layout, ``.to()``,
+        ``load_state_dict(assign=True)``) change ``data_ptr``; parameters added, removed or replaced change the module's
+        parameter COUNT or identities.  The parameter list is cached (the module walk is the expensive part of this key on the
+        B = 1 path the graph exists to speed up) and re-collected whenever the cheap count no longer matches; every data_ptr
+        enters the key (a sampled subset missed moves of the unsampled ones)."""
         ps = getattr(self, "_plist", None)
-        if ps is None:
+        n_now = sum(len(m._parameters) for m in self.tr.modules())
+        if ps is None or self._pcount != n_now:
             ps = self._plist = list(self.tr.parameters())
-        return sum(p._version for p in ps), sum(p.data_ptr() for p in ps[::8]) & 0xFFFFFFFFFFFF
+            self._pcount = n_now
+        return (sum(p._version for p in ps), hash(tuple(p.data_ptr() for p in ps)), hash(tuple(map(id, ps))))
 
     def __call__(self, hidden_states, encoder_hidden_states, timestep, **kw):
         kw = dict(kw, hidden_states=hidden_states, encoder_hidden_states=encoder_hidden_states, timestep=timestep)

@@ -7,6 +7,7 @@
 // the accumulator init, and feed dS / P back into the next MFMA as its B operand straight from accumulator registers.
 // Operands whose contraction index is the sequence (K^T, Q^T, dO^T) come from per-head transposed copies
 // [B,H,64,s_pad] written by orv_head_transpose in the key order the accumulator layout produces (bits 2<->3 exchanged).
+#include <mutex>
 #include "common.hpp"
 #include <stdlib.h>
 
@@ -1055,6 +1056,9 @@ extern "C" int orv_debug_attn_bwd_trace(void* buf) {      // variant builds only
 namespace {
 // per-device side stream + fork / join events of orv_attention_bwd (created on first use, kept)
 struct BwdSide { hipStream_t stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool ok = false, tried = false; };
+// Initialisation is serialised (two host threads may call orv_attention_bwd on one device); the events are shared per device, so the
+// fork / join sequence itself runs under the same mutex: record + wait pairs of two callers must not interleave.
+std::mutex g_bwd_side_mutex;
 BwdSide* bwd_side() {
     static BwdSide sides[16];
     int dev = 0;
@@ -1096,15 +1100,23 @@ extern "C" int orv_attention_bwd(const void* qkv, int ld_qkv, const void* qT, co
         // the other's workgroups (fork / join by events, legal under stream capture).  ORV_ATTN_BWD_FORK=0: back to back.
         static int fork = -1;
         if (fork < 0) { const char* e = getenv("ORV_ATTN_BWD_FORK"); fork = (e && atoi(e) == 0) ? 0 : 1; }
+        std::lock_guard<std::mutex> lock(g_bwd_side_mutex);
         BwdSide* side = fork ? bwd_side() : nullptr;
-        if (side) {
-            hipEventRecord(side->ev_fork, st);
-            hipStreamWaitEvent(side->stream, side->ev_fork, 0);
+        // a failed fork (event record / wait refused) must not let the dK / dV pass run unordered against its inputs: fall back to
+        // the back-to-back launch on the caller's stream
+        const bool forked = side && hipEventRecord(side->ev_fork, st) == hipSuccess &&
+                            hipStreamWaitEvent(side->stream, side->ev_fork, 0) == hipSuccess;
+        if (forked) {
             hipLaunchKernelGGL(attn_bwd_dkv_pp_kernel, grid, dim3(512), 0, side->stream, a);
             hipLaunchKernelGGL(attn_bwd_dq_pp_kernel, grid, dim3(512), 0, st, a);
-            hipEventRecord(side->ev_join, side->stream);
-            hipStreamWaitEvent(st, side->ev_join, 0);
+            if (hipEventRecord(side->ev_join, side->stream) != hipSuccess || hipStreamWaitEvent(st, side->ev_join, 0) != hipSuccess) {
+                // the join could not be queued: dqkv must not be consumed before the side pass is done
+                (void)hipStreamSynchronize(side->stream);
+                orv_set_error("orv_attention_bwd: joining the dK / dV side stream failed (%s)", hipGetErrorString(hipGetLastError()));
+                return ORV_EDEVICE;
+            }
         } else {
+            (void)hipGetLastError();
             hipLaunchKernelGGL(attn_bwd_dq_pp_kernel, grid, dim3(512), 0, st, a);
             hipLaunchKernelGGL(attn_bwd_dkv_pp_kernel, grid, dim3(512), 0, st, a);
         }

@@ -666,6 +666,9 @@ extern "C" int orv_transpose_colsum_bf16(const void* src, int ld_src, void* dst,
                                          void* stream) {
     ORV_REQUIRE(src && dst && colsum && R > 0 && C > 0, "orv_transpose_colsum_bf16: bad arguments");
     ORV_REQUIRE(ld_src % 8 == 0 && ld_dst % 8 == 0 && ld_dst >= R && C % 8 == 0, "orv_transpose_colsum_bf16: misaligned");
+    // 16-byte loads from src / stores to dst (a column slice of a wider tensor is a legal view and would fault here); colsum is
+    // ACCUMULATED with fp32 atomics: the caller zeroes it (ops.transpose_colsum does)
+    ORV_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "orv_transpose_colsum_bf16: src and dst must be 16-byte aligned");
     constexpr int RT = 4;
     const int row_tiles = (ld_dst + 63) / 64;
     dim3 grid((row_tiles + RT - 1) / RT, (C + 63) / 64);

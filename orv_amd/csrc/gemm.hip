@@ -1430,6 +1430,15 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
         ORV_REQUIRE(g->cmap.rows == 0, "orv_gemm_bf16: epilogue 4 writes rows in place (no cmap)");
     }
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("ORV_GEMM_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
+    {   // ORV_T8_STAGGER="groups,ns": start stagger of the t8 workgroups; ORV_T8_GRID: cap of persistent workgroups (experiments)
+        static int sg = -1, st_ticks = 0, gcap = 0;
+        if (sg < 0) {
+            sg = 0;
+            if (const char* e = getenv("ORV_T8_STAGGER")) { int ns = 0; if (sscanf(e, "%d,%d", &sg, &ns) == 2) st_ticks = ns / 10; else sg = 0; }
+            if (const char* e = getenv("ORV_T8_GRID")) gcap = atoi(e);
+        }
+        a.stagger_groups = sg; a.stagger_ticks = st_ticks; a.grid_cap = gcap;
+    }
     {   // tiles handed out from the END of the list (GemmArgs::walk_back).  ORV_GEMM_WALK_BACK: 0 never, 1 the gated-residual GEMMs
         // only (out-projection, FFN2), 2 (default) every GEMM
         static int wb = -1;

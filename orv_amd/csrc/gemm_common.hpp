@@ -37,6 +37,10 @@ struct GemmArgs {
     // interleaved: FFN2 0.3405 -> 0.3319 ms, out-projection 0.1116 -> 0.1083 ms, LayerNorm-fed GEMMs unchanged (step 41.57 ->
     // 41.12 ms); the 2B training step another 1 % when the backward GEMMs do it too (profiles/r3_gemm_walk_back.txt).
     int walk_back;
+    // Start stagger of the persistent t8 workgroups (gemm_t8.hip): workgroup group g = (blockIdx / 8) % stagger_groups begins its first
+    // tile g * stagger_ticks (10 ns each) late, so the epilogue store bursts of the groups do not coincide.  0 / 1 groups: off.
+    int stagger_groups, stagger_ticks;
+    int grid_cap;   // > 0: at most this many persistent workgroups (experiment knob, ORV_T8_GRID)
     int gm;   // super-tile height in tiles (0: GM).  8 for the long-K, narrow GEMM (FFN2: 10 column tiles, 120 K-tiles): in the model
               // 0.3252 -> 0.3178 ms; every other per-block shape is best at or indifferent to 4 (sweep 1 / 2 / 3 / 4 / 6 / 8 / 13 in
               // profiles/r3_gemm_walk_back.txt).  ORV_GEMM_GM overrides.

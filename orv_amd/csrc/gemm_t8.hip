@@ -51,6 +51,11 @@ __device__ __forceinline__ void t8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][4
     constexpr int NP = BN == 256 ? 2 : 1;            // 8-column pieces per row
     constexpr bool TAIL = BN == 192;                 // plus one 4-column piece
     const int g = lane >> 4, r16 = lane & 15;
+#ifdef ORV_T8_ABL_NOSTORE    // ablation build (tools/t8_epi_abl.sh, wrong results): the epilogue computes everything, no store is executed
+    const bool st_ok = p.M < 0;
+#else
+    constexpr bool st_ok = true;
+#endif
     int col8[NP];
 #pragma unroll
     for (int P = 0; P < NP; ++P) col8[P] = nbase + 32 * P + 8 * g;
@@ -103,7 +108,7 @@ __device__ __forceinline__ void t8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][4
                 for (int P = 0; P < NP; ++P)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { v[P][e] = acc[mh][mb][2 * P + (e >> 2)][e & 3] + b8[P][e]; s += v[P][e]; }
-                if (p.Y && valid) {
+                if (p.Y && valid && st_ok) {
 #pragma unroll
                     for (int P = 0; P < NP; ++P) *(uint4*)(p.Y + orow * p.ldy + col8[P]) = pack8(v[P]);
                 }
@@ -120,7 +125,7 @@ __device__ __forceinline__ void t8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][4
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[P][e] = (v[P][e] * rstd * ga[P][e] + be[P][e]) * post;
                 }
-                if (valid) {
+                if (valid && st_ok) {
 #pragma unroll
                     for (int P = 0; P < NP; ++P) *(uint4*)(p.C + orow * p.ldc + col8[P]) = pack8(v[P]);
                 }
@@ -198,7 +203,7 @@ __device__ __forceinline__ void t8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][4
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = acc[mh][mb][2 * P + (e >> 2)][e & 3] + b8[P][e];
-                    if (yrow && valid[mb]) *(uint4*)(yrow + col8[P]) = pack8(v);
+                    if (yrow && valid[mb] && st_ok) *(uint4*)(yrow + col8[P]) = pack8(v);
                     if (EPI == 1) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
@@ -221,13 +226,13 @@ __device__ __forceinline__ void t8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][4
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] *= gelu_tanh_grad(rv[e]);
                     }
-                    if (valid[mb]) *(uint4*)(crow + col8[P]) = pack8(v);
+                    if (valid[mb] && st_ok) *(uint4*)(crow + col8[P]) = pack8(v);
                 }
                 if (TAIL) {
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[mh][mb][BN / 64 - 1][e] + b4[e];
-                    if (yrow && valid[mb]) *(uint2*)(yrow + col4) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                    if (yrow && valid[mb] && st_ok) *(uint2*)(yrow + col4) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
                     if (EPI == 1) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
@@ -244,7 +249,7 @@ __device__ __forceinline__ void t8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][4
                             for (int e = 0; e < 4; ++e) v[e] *= gelu_tanh_grad(rv[e]);
                         }
                     }
-                    if (valid[mb]) *(uint2*)(crow + col4) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                    if (valid[mb] && st_ok) *(uint2*)(crow + col4) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
                 }
             }
         }
@@ -433,6 +438,12 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
         T8_ISSUE_B0(1) T8_ISSUE_A0(1)
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     }
+    if (p.stagger_groups > 1) {
+        // the prologue's DMA is in flight; this workgroup's group waits its share of the stagger before the first K-tile
+        const int grp_ = (blockIdx.x >> 3) % p.stagger_groups;
+        const unsigned long long t0_ = wall_clock64(), dt_ = (unsigned long long)grp_ * (unsigned)p.stagger_ticks;
+        while (wall_clock64() - t0_ < dt_) __builtin_amdgcn_s_sleep(16);
+    }
     T8_BAR()
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -444,6 +455,9 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
         if (wr == 0) { T8_BAR() }             // ... and both halves run their epilogues side by side
         int tm, tn;
         tile_of_index(p, tile, ntiles, tm, tn);
+#ifdef ORV_T8_ABL_NOEPI      // ablation build: no epilogue at all (the accumulators stay live through the never-taken call)
+        if (p.M < 0)
+#endif
         t8_epilogue<BN, EPI>(p, acc, tm * 256 + wr * 128, tn * BN + wc * (BN / 4), lane);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -463,7 +477,8 @@ int launch_one(const GemmArgs& a, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)gemm_t8_kernel<BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
-    const int grid = min(a.tiles_m * a.tiles_n, orv_num_cus());
+    int grid = min(a.tiles_m * a.tiles_n, orv_num_cus());
+    if (a.grid_cap > 0) grid = min(grid, a.grid_cap);
     hipLaunchKernelGGL((gemm_t8_kernel<BN, EPI>), dim3(grid), dim3(512), smem, st, a);
     return orv_check_launch("orv_gemm_bf16");
 }

@@ -4,12 +4,12 @@
 
 MI355X layout: every trainable parameter becomes a view into ONE flat bf16 buffer (segments padded to 2048 elements), with
 flat bf16 gradient and fp32 moment buffers beside it (1.69 B parameters: 3.4 + 3.4 + 6.8 + 6.8 GB of the 288 GB).  A step
-is then: gather the autograd gradients into the flat buffer (multi-tensor copy) -> optional RCCL all-reduce of the flat
-buffer in 256 MB pieces -> ONE ``orv_sumsq`` -> clip coefficient on the device (no host sync before the update) -> ONE
+is then: gather the autograd gradients into the flat buffer (multi-tensor copy) -> optional RCCL all-reduce (SUM; the 1 / world of the
+average is folded into the clip coefficient) of the flat buffer in 256 MB pieces -> ONE ``orv_sumsq`` -> clip coefficient on the device (no host sync before the update) -> ONE
 ``orv_adamw_flat`` (clip + moments + decoupled decay + bf16 write, 16-byte accesses).  Parameters that received no gradient
 in a step are skipped exactly as ``torch.optim.AdamW`` skips them (segment activity mask) and every parameter carries its
-OWN step count for the bias correction (``state[p]["step"]`` in torch).  Under data parallel a parameter is active iff it has a gradient on ANY rank (one tiny MAX all-reduce of the usage mask: DDP's
-``find_unused_parameters`` bookkeeping, which the reference enables, base_train.yaml:181); a rank without one contributes zeros,
+OWN step count for the bias correction (``state[p]["step"]`` in torch).  Under data parallel a parameter is active iff it has a gradient on ANY rank (the usage mask rides in the last segment of the flat gradient buffer, so it arrives with the gradient
+exchange itself: DDP's ``find_unused_parameters`` bookkeeping, which the reference enables, base_train.yaml:181); a rank without one contributes zeros,
 so the collective schedule and the update are identical on all ranks and equal to the single-GPU trajectory.  Moments
 are fp32 (the reference keeps them in the parameter dtype)."""
 from __future__ import annotations
@@ -50,9 +50,12 @@ class FusedAdamW:
             offs.append(o)
             o += (p.numel() + _SEG - 1) // _SEG * _SEG
         total = o
+        # the gradient buffer carries one more segment: the usage mask of this rank (1.0 per parameter with a gradient), so that
+        # under data parallel "used on ANY rank" arrives with the gradient exchange itself (SUM > 0) instead of a second collective
+        tail = (len(self.params) + _SEG - 1) // _SEG * _SEG
         flat_p = torch.zeros(total, dtype=torch.bfloat16, device=dev)
         views_p, views_g = [], []
-        flat_g = torch.zeros(total, dtype=torch.bfloat16, device=dev)
+        flat_g = torch.zeros(total + tail, dtype=torch.bfloat16, device=dev)
         for p, off in zip(self.params, offs):
             v = flat_p[off:off + p.numel()].view(p.shape)
             v.copy_(p.data)
@@ -60,7 +63,8 @@ class FusedAdamW:
             views_p.append(v)
             views_g.append(flat_g[off:off + p.numel()].view(p.shape))
         self._flat = dict(
-            p=flat_p, g=flat_g, m=torch.zeros(total, dtype=torch.float32, device=dev),
+            p=flat_p, g=flat_g, g_params=flat_g[:total], g_mask=flat_g[total:total + len(self.params)],
+            reduce_starts=offs + [total, total + tail], m=torch.zeros(total, dtype=torch.float32, device=dev),
             v=torch.zeros(total, dtype=torch.float32, device=dev), views_g=views_g,
             seg_start=torch.tensor(offs + [total], dtype=torch.int64, device=dev),
             active=torch.zeros(len(self.params), dtype=torch.uint8, device=dev), active_host=[False] * len(self.params),
@@ -78,7 +82,7 @@ class FusedAdamW:
             self._build()
         f = self._flat
         index = {id(p): i for i, p in enumerate(self.params)}
-        red = FlatGradReducer(f["g"], f["seg_start"].tolist())
+        red = FlatGradReducer(f["g"], f["reduce_starts"])      # parameter segments + the usage-mask segment (sent by finish())
         filled = set()
 
         def hook(params, grads):
@@ -147,30 +151,40 @@ class FusedAdamW:
         if srcs:
             torch._foreach_copy_(dsts, srcs)
         self._dirty.update(i for i, h in enumerate(has_grad) if h)
+        world = 1
         if distributed:
             # Data parallel: a parameter is updated iff it has a gradient on ANY rank (DDP's local_used_map with
             # find_unused_parameters, /root/reference/config/base_train.yaml:181): a rank without one contributes zeros, and
             # a parameter unused on every rank is skipped as torch.optim.AdamW skips grad-None parameters (no decay, no
-            # moment decay, no step-count increment) - the same trajectory as the single-GPU run.  The mask travels as one
-            # tiny MAX all-reduce issued at the same point on every rank; it stays on the device.
+            # moment decay, no step-count increment) - the same trajectory as the single-GPU run.  The mask rides in the last
+            # segment of the gradient buffer (1.0 where this rank has a gradient; SUM over ranks > 0 <=> used somewhere), so
+            # the step issues gradient collectives only, at the same points on every rank; it stays on the device.
             import torch.distributed as dist
-            used = torch.tensor(has_grad, dtype=torch.uint8, device=dev)
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                dist.all_reduce(used, op=dist.ReduceOp.MAX)
-            f["active"].copy_(used)
+            if dist.is_available() and dist.is_initialized():
+                world = dist.get_world_size()
+            f["g_mask"].copy_(torch.tensor(has_grad, dtype=torch.bfloat16))
+            if overlap is not None:
+                overlap[0].finish(average=False)         # the rest of the buffer (mask segment included), wait
+            else:
+                from .sharding import allreduce_flat_
+                allreduce_flat_(f["g"], _AR_CHUNK, average=False)
+            f["active"].copy_((f["g_mask"] > 0).to(torch.uint8))
             f["active_host"] = None                      # device-side mask: the host copy is unknown
+            if world > 1:
+                # the exchange wrote the summed gradient into EVERY segment, also those this rank has no gradient for: all of
+                # them hold data now and must be zeroed before the next exchange / norm unless a new gradient overwrites them
+                self._dirty.update(range(len(self.params)))
         elif has_grad != f["active_host"]:
             f["active"].copy_(torch.tensor(has_grad, dtype=torch.uint8))
             f["active_host"] = has_grad
-        if overlap is not None:
-            overlap[0].finish()                          # the rest of the buffer, wait, average
-        elif average_over and average_over > 1:
-            from .sharding import allreduce_flat_
-            allreduce_flat_(f["g"], _AR_CHUNK)
+        # The buffer holds the SUM over ranks; the 1 / world of the average is folded into the coefficient handed to the update
+        # kernel (no separate pass over 3.4 GB): norm of the mean gradient = norm of the sum / world.
         ss = torch.zeros(1, dtype=torch.float32, device=dev)
-        ops.sumsq(f["g"], ss)
-        norm = ss.sqrt()
+        ops.sumsq(f["g_params"], ss)
+        norm = ss.sqrt() / world
         clip = torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0) if self.max_grad_norm else torch.ones_like(norm)
+        if world > 1:
+            clip = clip / world
         self.step_count += 1
         f["seg_step"].add_(f["active"].to(torch.int32))          # per-parameter step counts (torch.optim.AdamW state["step"])
         ops.adamw_flat(f["p"], f["g"], f["m"], f["v"], f["seg_start"], f["active"], self.param_groups[0]["lr"], self.betas[0],

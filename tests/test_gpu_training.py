@@ -282,7 +282,7 @@ def test_overlapped_gradient_exchange_hook_changes_nothing():
             red, filled = opt._overlap
             assert len(filled) >= 12 and all(red.ready_flag[i] for i in filled)   # the 6 big weights of each block
         opt.step(average_over=1)
-        results.append(opt._flat["g"].clone())
+        results.append(opt._flat["g_params"].clone())     # without the usage-mask segment behind the parameter segments
     # the same gradients reach the flat buffer on both paths (fp32 atomics in a few bias / table sums make single runs differ in
     # the last bf16 bit, so not bit-equal - and AdamW's first step would turn such a flip into +-lr)
     assert results[0].abs().sum() > 0 and rel_l2(results[1], results[0]) <= 2e-3
