@@ -251,10 +251,25 @@ int orv_attention_fwd(const void* qkv, int ld_qkv, const void* vT, void* out, in
                       int H, int s_pad, float scale, void* stream);
 /* The same attention (V read in place) when the caller can BOUND the scores: |q . k| * scale * log2(e) <= score_bound for every
  * (query, key) of the call.  ORV always applies the per-head qk LayerNorm (cogvideox_control.py:243-247), so the bound follows
- * from norm_q / norm_k's affine parameters alone.  With the fused scale (q pre-multiplied) and score_bound <= 40 the softmax
- * uses the bound as a FIXED shift (no running max, no rescale); otherwise identical to orv_attention_fwd.  lse as there. */
+ * from norm_q / norm_k's affine parameters alone.  With the fused scale (q pre-multiplied) and score_bound <= 90 (16-byte aligned
+ * output; <= 60 otherwise) the softmax runs WITHOUT a running max or rescale (P = exp2(s) stays a normal fp32 / bf16 number);
+ * otherwise identical to orv_attention_fwd.  lse as there. */
 int orv_attention_fwd_bounded(const void* qkv, int ld_qkv, void* out, int ld_out, float* lse, int B, int S, int H, float scale,
                               float score_bound, void* stream);
+/* orv_attention_fwd_bounded with a workspace: at shapes whose grid ends in a small extra round of workgroups (the headline shape:
+ * 1560 workgroups on 512 slots) the items of that round are cut into key ranges whose unnormalised partial results meet in `ws`
+ * (fixed summation order: deterministic).  ws >= orv_attention_ws_bytes(B, S, H) bytes, 256-byte aligned, reusable across calls on one
+ * stream; ws == NULL or an unsplit shape (ws_bytes 0): exactly orv_attention_fwd_bounded. */
+size_t orv_attention_ws_bytes(int B, int S, int H);
+int orv_attention_fwd_bounded_ws(const void* qkv, int ld_qkv, void* out, int ld_out, float* lse, int B, int S, int H, float scale,
+                                 float score_bound, void* ws, size_t ws_bytes, void* stream);
+/* Largest score_bound for which orv_attention_fwd_bounded(_dev) runs the fixed-shift softmax (16-byte aligned out: 90; else 60). */
+float orv_attention_static_limit(int aligned_out);
+/* orv_attention_fwd_bounded with the bound as ONE fp32 in device memory (the training step recomputes the per-layer bounds on the
+ * device after every optimizer update, train_cogvideox_control_to_video_sft.py:1095-1104: no device -> host read per step).  Both
+ * softmax forms are launched; the workgroups of the one the scalar does not select exit at once. */
+int orv_attention_fwd_bounded_dev(const void* qkv, int ld_qkv, void* out, int ld_out, float* lse, int B, int S, int H, float scale,
+                                  const float* score_bound_dev, void* stream);
 
 /* -- sampler ---------------------------------------------------------------------------------- */
 /* One fused scheduler update on n elements (cogvideox_control.py:1433-1459 + diffusers

@@ -64,6 +64,11 @@ SIGNATURES = {
     "orv_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                   c_float, c_void_p]),
     "orv_attention_fwd_bounded": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p]),
+    "orv_attention_static_limit": (c_float, [c_int]),
+    "orv_attention_ws_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
+    "orv_attention_fwd_bounded_ws": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p,
+                                             ctypes.c_size_t, c_void_p]),
+    "orv_attention_fwd_bounded_dev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "orv_transpose_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "orv_transpose_colsum_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "orv_colsum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),

@@ -113,6 +113,18 @@ class Attention(_NoForward):
             prime_score_bounds([self], scale)
         return self._bound[1]
 
+    def score_bound_dev(self, scale: float):
+        """``score_bound`` as a one-element fp32 DEVICE tensor (``prime_score_bounds(..., on_device=True)``): the training
+        forward hands it to ``orv_attention_fwd_bounded_dev`` - the bound changes with every optimizer step and must not cost a
+        blocking device -> host read per step."""
+        if self.norm_q is None or self.norm_k is None:
+            return None
+        key = self._bound_key(scale)
+        bd = getattr(self, "_bound_dev", None)
+        if bd is None or bd[0] != key:
+            prime_score_bounds([self], scale, on_device=True)
+        return self._bound_dev[1]
+
     def _bound_key(self, scale):
         ps = (self.norm_q.weight, self.norm_q.bias, self.norm_k.weight, self.norm_k.bias)
         return tuple((w.data_ptr(), w._version) for w in ps) + (_state.weights_epoch[0], float(scale))
@@ -130,10 +142,15 @@ class Attention(_NoForward):
         return self._packed[1], self._packed[2]
 
 
-def prime_score_bounds(attns, scale: float) -> None:
-    """``Attention.score_bound`` for many modules with ONE device -> host copy (a model has 30-84 of them and, under training,
-    the bound changes with every optimizer step): stale entries are recomputed together on the device and read back once."""
-    todo = [a for a in attns if a.norm_q is not None and a.norm_k is not None and (a._bound is None or a._bound[0] != a._bound_key(scale))]
+def prime_score_bounds(attns, scale: float, on_device: bool = False) -> None:
+    """``Attention.score_bound`` for many modules with ONE device -> host copy (a model has 30-84 of them): stale entries are
+    recomputed together on the device and read back once.  ``on_device=True`` (training, where the bound changes with every
+    optimizer step): NO host copy at all - every module gets a one-element view of the device vector (``score_bound_dev``)."""
+    if on_device:
+        todo = [a for a in attns if a.norm_q is not None and a.norm_k is not None
+                and (getattr(a, "_bound_dev", None) is None or a._bound_dev[0] != a._bound_key(scale))]
+    else:
+        todo = [a for a in attns if a.norm_q is not None and a.norm_k is not None and (a._bound is None or a._bound[0] != a._bound_key(scale))]
     if not todo:
         return
     with torch.no_grad():
@@ -144,7 +161,12 @@ def prime_score_bounds(attns, scale: float) -> None:
         rt = math.sqrt(todo[0].dim_head)
         nq = rt * gq.abs().amax(dim=1) + bq.norm(dim=1)
         nk = rt * gk.abs().amax(dim=1) + bk.norm(dim=1)
-        vals = (1.02 * float(scale) * LOG2E * nq * nk).tolist()
+        vals = (1.02 * float(scale) * LOG2E * nq * nk).contiguous()
+        if on_device:
+            for i, a in enumerate(todo):
+                a._bound_dev = (a._bound_key(scale), vals[i:i + 1])
+            return
+        vals = vals.tolist()
     for a, v in zip(todo, vals):
         a._bound = (a._bound_key(scale), float(v))
 
@@ -500,8 +522,12 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             s_pad = (S + 63) // 64 * 64
             M = B * S
             e = lambda *shape, dt=BF16: torch.empty(*shape, dtype=dt, device=dev)
+            # attention workspace: partial results of the key-split last round (orv_attention_fwd_bounded_ws); None when the shape's
+            # grid has no small last round (B = 1, B = 2, the 5B widths)
+            nb = ops.attention_ws_bytes(B, S, H)
             self._ws = {key: dict(x=e(M, D), xn=e(M, D), qkv=e(M, 3 * D), att=e(M, D), h=e(M, 4 * D), vis=e(B * Nv, D),
-                                  vis2=e(B * Nv, D), s_pad=s_pad)}
+                                  vis2=e(B * Nv, D), s_pad=s_pad,
+                                  attn_ws=torch.empty(nb, dtype=torch.uint8, device=dev) if nb else None)}
         return self._ws[key]
 
     def _view_pos_table(self, pos, n_view, T, P, dev):
@@ -767,7 +793,7 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             ops.layernorm_modulate(x, xn, blk.norm1.norm.weight, blk.norm1.norm.bias, m1[..., D:2 * D], m1[..., :D],
                                    mb, mg, grp, B, D, c.norm_eps)
             self._qkv_projection(at, xn, qkv, rope, B, S, heads, Nt, s_pad, scale)
-            ops.attention_fwd(qkv, None, att, B, S, heads, s_pad, 1.0 / LOG2E, score_bound=at.score_bound(scale))
+            ops.attention_fwd(qkv, None, att, B, S, heads, s_pad, 1.0 / LOG2E, score_bound=at.score_bound(scale), ws=ws["attn_ws"])
             ops.gemm(att, at.to_out[0].weight, at.to_out[0].bias, x, M, D, D, epilogue=2, R=x, ldr=D,
                      gate=m1[..., 2 * D:], gate_b=mb, gate_g=mg, grp=grp)
             ops.layernorm_modulate(x, xn, blk.norm2.norm.weight, blk.norm2.norm.bias, m2[..., D:2 * D], m2[..., :D],

@@ -34,7 +34,24 @@ struct AttnArgs {
     float scale_log2;  // scale * log2(e)
     float scale;
     float shift;       // STATIC kernels: fixed softmax shift in log2 units (>= every score the caller can produce)
+    // orv_attention_fwd_bounded_dev: the score bound lives in device memory (training: it changes with every optimizer step and must
+    // not cost a device -> host read).  Both softmax forms are launched; each workgroup reads the scalar and the form it does not
+    // select returns at once (guard_dev == nullptr: no guard).
+    const float* guard_dev;
+    float guard_limit;
+    // key-split tail of attn_fwd_pp_kernel<true, true> (orv_attention_fwd_bounded_ws): workgroups [0, n_full) are whole items; the
+    // items from n_full on are cut into ks key ranges each (workgroup n_full + r * ks + part), whose unnormalised partial
+    // outputs meet in ws_o / ws_l; ws_cnt[r] counts the arrivals of item r (zeroed by the launch function).
+    float* ws_o; float* ws_l; unsigned* ws_cnt;
+    int n_full, ks;
 };
+// true = this kernel form is the one the device-side bound selects
+__device__ __forceinline__ bool attn_guard_selects(const AttnArgs& p, bool static_form) {
+    if (!p.guard_dev) return true;
+    const float b = *p.guard_dev;
+    const bool fits = b > 0.f && b <= p.guard_limit;      // NaN / non-positive: the online form
+    return fits == static_form;
+}
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 // -DORV_SEG_TRACE (tools/attn_seg_trace.sh): per-wave time in the matrix segment, at the barrier behind it, in the vector segment and
@@ -227,7 +244,7 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const char* a, const char* b) {
 // four 64-vectors - and the softmax uses that bound as its FIXED shift: P = exp2(s - shift) <= 1, no running max, no rescale
 // branch, no m_run dependency between tiles; -shift rides in the accumulator init of the QK^T MFMAs, so the 32 v_sub and the
 // 21-instruction max tree per 64-key tile are gone (10.9 -> ~7 VALU instructions per MFMA).  fp32 l / O accumulate 2^-2 shift ... 1
-// without loss for shift <= 40 (the entry point falls back to the online kernel above that).
+// without loss for shift <= 60 (P >= 2^-120 stays a normal number; the entry point falls back to the online kernel above that).
 template <bool LAZY, bool FUSED, bool STATIC = false>
 __global__ __launch_bounds__(512, 4) void attn_fwd_v2_kernel(const AttnArgs p) {
     static_assert(!STATIC || FUSED, "the fixed-shift softmax is built for the pre-multiplied q only");
@@ -397,8 +414,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_v2_kernel(const AttnArgs p) {
 //   * DMA roles: waves 0-3 stage the K tiles (K_{t+1} issued in their X_t behind the transposing reads, waited at the end of
 //     Y_t), waves 4-7 the V tiles (V_{t+1} issued in their Y_t, waited at the end of their X_{t+1}).  Two 8-KiB slots per operand
 //     (32 KiB: unchanged).
-//   * STATIC (the caller bounds |score| by <= 40 log2 units, see orv_attention_fwd_bounded): P = exp2(s) with NO shift at all - P <=
-//     2^40, l <= S 2^40, O <= l max|v| are far inside fp32 / bf16 range and a common factor cancels in O / l; otherwise the online
+//   * STATIC (the caller bounds |score| by <= 90 log2 units, see orv_attention_fwd_bounded): P = exp2(s) with NO shift at all - P in
+//     [2^-90, 2^90], l <= S 2^90, O <= l max|v| stay normal, finite fp32 / bf16 numbers and a common factor cancels in O / l; otherwise the online
 //     softmax with the lazy rescale, taken in Y_t between PV_{t-1} and PV_t, i.e. with every pending product already in O (cdna
 //     guide T13 ordering).
 //   * epilogue: O rows leave as 16-byte pieces (two 8-byte column groups exchanged between lane and lane ^ 32, guide T21).
@@ -408,15 +425,24 @@ constexpr int PP_SLOTS = 2;        // K / V tiles resident per operand (tile t i
 // ds_read_b64_tr_b16 that follows a DMA builtin cannot drain the stream) and counted vmcnt(2) waits - 0.365-0.373 ms against
 // 0.344-0.349 ms standalone, 0.3395 against 0.3275 ms in the model (profiles/r3_attention_pingpong.txt): the loop does not wait
 // for the DMA, and the third slot pair costs more than it hides.
-template <bool STATIC>
+template <bool STATIC, bool SPLIT = false>
 __global__ __launch_bounds__(512, 4) void attn_fwd_pp_kernel(const AttnArgs p) {
+    static_assert(STATIC || !SPLIT, "partial results add only under the shift-free softmax");
     __shared__ __attribute__((aligned(16))) char smem[2 * PP_SLOTS * TILE_BYTES];   // K slots | V slots
+    if (!attn_guard_selects(p, STATIC)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wq = wave & 3;
     const int l31 = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
     const int nqt = (p.S + 255) / 256;
-    const int item = orv_xcd_item(blockIdx.x, gridDim.x);
+    // SPLIT: the grid is n_full whole items (the dispatcher's full rounds of 2 workgroups per CU) + the remaining items cut into ks key
+    // ranges each, dispatched LAST: what used to be a nearly empty extra round of full-length workgroups becomes ks-times shorter
+    // pieces that fill the slots the earlier rounds free.  part < 0: a whole item.
+    int item, part = -1, rest = 0;
+    if (SPLIT && (int)blockIdx.x >= p.n_full) {
+        const int r_ = blockIdx.x - p.n_full;
+        rest = r_ / p.ks; part = r_ % p.ks; item = p.n_full + rest;
+    } else item = orv_xcd_item(blockIdx.x, SPLIT ? p.n_full : gridDim.x);
     const int bh = item / nqt, h = bh % p.H, b = bh / p.H;
     const int q0 = (item % nqt) * 256 + wave * 32;
     const int D = p.H * 64;
@@ -448,6 +474,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_pp_kernel(const AttnArgs p) {
     char* const sdst = smem + grp * PP_SLOTS * TILE_BYTES + wq * 2048;
     const int nt = (p.S + KV - 1) / KV;
     const bool ragged = (p.S & (KV - 1)) != 0;
+    // key tiles [t_lo, t_hi) of this workgroup (a whole item: all of them)
+    const int t_lo = (SPLIT && part >= 0) ? (int)((long)part * nt / p.ks) : 0;
+    const int t_hi = (SPLIT && part >= 0) ? (int)((long)(part + 1) * nt / p.ks) : nt;
     // this half's operand tile t -> slot t % 2.  The tile offset is wave-uniform (scalar unit): per tile and piece one 64-bit
     // vector add instead of a 64-bit multiply + clamp (that address arithmetic was ~20 % of the kernel's VALU instructions); only
     // the ragged last tile recomputes its clamped addresses (nothing but the two tile-0 pointers stays live across the loop).
@@ -495,7 +524,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_pp_kernel(const AttnArgs p) {
         const char* sK = smem + (t % PP_SLOTS) * TILE_BYTES + row_off;
         auto kread = [&](int kb, int ks) { return *(const bf16x8*)(sK + kb * 4096 + (((ks * 2 + hi) ^ sw) * 16)); };
         bf16x8 k0, k1, k2, k3;
-        if (t > 0) {
+        if (t > t_lo) {
             const char* sV = smem + PP_SLOTS * TILE_BYTES + ((t - 1) % PP_SLOTS) * TILE_BYTES;
             bf16x8 va0 = tr_read_pair(sV + v_off0, sV + 8 * 128 + v_off0), va1 = tr_read_pair(sV + v_off1, sV + 8 * 128 + v_off1);
             bf16x8 vb0 = tr_read_pair(sV + 2048 + v_off0, sV + 2048 + 8 * 128 + v_off0), vb1 = tr_read_pair(sV + 2048 + v_off1, sV + 2048 + 8 * 128 + v_off1);
@@ -515,12 +544,12 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_pp_kernel(const AttnArgs p) {
             // ds_read_b128 are left alone - so issued here the only such wait is next segment's, long after the data landed
             stage_k();
             PP_FENCE()
-            if (t < nt) { k0 = kread(0, 0); k1 = kread(0, 1); }
+            if (t < t_hi) { k0 = kread(0, 0); k1 = kread(0, 1); }
             PP_FENCE()
             oT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0, pf[2].v, oT[0], 0, 0, 0);
             oT[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1, pf[2].v, oT[1], 0, 0, 0);
             PP_FENCE()
-            if (t < nt) { k2 = kread(0, 2); k3 = kread(0, 3); }
+            if (t < t_hi) { k2 = kread(0, 2); k3 = kread(0, 3); }
             PP_FENCE()
             oT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb0, pf[3].v, oT[0], 0, 0, 0);
             oT[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb1, pf[3].v, oT[1], 0, 0, 0);
@@ -531,7 +560,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_pp_kernel(const AttnArgs p) {
             k0 = kread(0, 0); k1 = kread(0, 1); k2 = kread(0, 2); k3 = kread(0, 3);
             PP_FENCE()
         }
-        if (t < nt) {
+        if (t < t_hi) {
             f32x16 z;
 #pragma unroll
             for (int e = 0; e < 16; ++e) z[e] = 0.f;
@@ -631,16 +660,16 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_pp_kernel(const AttnArgs p) {
     //            waited at the end of Y_t, read from I_2t+2
     //   V_{t+1}: second half, in its Y_t (I_2t+2), into the slot of V_{t-1} (last read by PV_{t-1} in I_2t+1); waited at the end of
     //            its X_{t+1} (I_2t+3), read from I_2t+4
-    stage(0);
+    stage(t_lo);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PP_BAR()
     const bool act = __builtin_amdgcn_readfirstlane((int)active) != 0;       // provably wave-uniform: real branches, no exec masking
     SEG_DECL
     if (grp == 0) {
         if (act) {
-            for (int t = 0; t < nt; ++t) {
+            for (int t = t_lo; t < t_hi; ++t) {
                 SEG_T(0)
-                seg_x(t, [&]() { if (t + 1 < nt) stage(t + 1); });
+                seg_x(t, [&]() { if (t + 1 < t_hi) stage(t + 1); });
                 SEG_T(1)
                 PP_BAR()
                 SEG_T(2)
@@ -650,10 +679,10 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_pp_kernel(const AttnArgs p) {
                 PP_BAR()
                 SEG_T(4)
             }
-            seg_x(nt, [&]() {});
+            seg_x(t_hi, [&]() {});
         } else {
-            for (int t = 0; t < nt; ++t) {
-                if (t + 1 < nt) stage(t + 1);
+            for (int t = t_lo; t < t_hi; ++t) {
+                if (t + 1 < t_hi) stage(t + 1);
                 PP_BAR()
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 PP_BAR()
@@ -663,26 +692,26 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_pp_kernel(const AttnArgs p) {
     } else {
         PP_BAR()
         if (act) {
-            for (int t = 0; t < nt; ++t) {
+            for (int t = t_lo; t < t_hi; ++t) {
                 SEG_T(0)
                 seg_x(t, [&]() {});
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 SEG_T(1)   // V_t landed (issued in Y_{t-1} / the prologue)
                 PP_BAR()
                 SEG_T(2)
-                if (t + 1 < nt) stage(t + 1);
+                if (t + 1 < t_hi) stage(t + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 seg_y(t);
                 SEG_T(3)
                 PP_BAR()
                 SEG_T(4)
             }
-            seg_x(nt, [&]() {});
+            seg_x(t_hi, [&]() {});
         } else {
-            for (int t = 0; t < nt; ++t) {
+            for (int t = t_lo; t < t_hi; ++t) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 PP_BAR()
-                if (t + 1 < nt) stage(t + 1);
+                if (t + 1 < t_hi) stage(t + 1);
                 PP_BAR()
             }
         }
@@ -690,9 +719,61 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_pp_kernel(const AttnArgs p) {
 #undef PP_BAR
 #undef PP_FENCE
 
-    const float l_tot = sum_with_partner_half(l_run);
-    const float inv = 1.0f / l_tot;
+    float l_tot = sum_with_partner_half(l_run);
     const int q = q0 + l31;
+    if constexpr (SPLIT) {
+        if (part >= 0) {
+            // Key-range partial: under the shift-free softmax the unnormalised O^T and l of the ranges simply ADD.  Every part writes
+            // its slab with write-through (sc1) stores, drains them, and takes a ticket; the workgroup that draws the last ticket sums
+            // the ks slabs in PART ORDER (its own included, read back like the others: the result does not depend on who arrives
+            // last) and runs the ordinary epilogue.  Hand-off = cdna_hip_programming.md Guideline 16 (R1, counter form): sc1 payload,
+            // vmcnt(0) in every storing wave, barrier, ONE relaxed agent-scope ticket; the reducer reads with sc1 loads (L2, never a
+            // stale L1 line) - no fence, placement-independent; the counters are zeroed by a memset node ahead of every launch.
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.ws_o, 0, 0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(p.ws_l, 0, 0x7fffffff, 0x00020000);
+            const int slab0 = rest * p.ks;                                    // slabs of this item: slab0 .. slab0 + ks - 1
+            const int row_b = (wave * 32 + l31) * 256 + hi * 16;              // byte offset of this lane's first d quad inside a slab
+            if (act) {
+                const int so = (slab0 + part) * (256 * 64 * 4) + row_b;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        u32x4_t v;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = __float_as_uint(oT[db][qd * 4 + j]);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, ro, so + db * 128 + qd * 32, 0, 16);
+                    }
+                if (hi == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(l_tot), rl, ((slab0 + part) * 256 + wave * 32 + l31) * 4, 0, 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            unsigned* const flag = (unsigned*)smem;                           // the K / V tiles are dead
+            if (tid == 0) *flag = __hip_atomic_fetch_add(p.ws_cnt + rest, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (*flag != (unsigned)(p.ks - 1)) return;
+            if (!act) return;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oT[i][e] = 0.f;
+            l_tot = 0.f;
+            for (int pp = 0; pp < p.ks; ++pp) {
+                const int so = (slab0 + pp) * (256 * 64 * 4) + row_b;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(ro, so + db * 128 + qd * 32, 0, 16);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) oT[db][qd * 4 + j] += __uint_as_float(v[j]);
+                    }
+                l_tot += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rl, ((slab0 + pp) * 256 + wave * 32 + l31) * 4, 0, 16));
+            }
+        }
+    }
+    const float inv = 1.0f / l_tot;
     SEG_DUMP
 #ifdef ORV_PP_TRACE
     // timeline build only (never the product library): (start, end, HW_ID | XCC_ID << 32, item) per workgroup through the lse pointer
@@ -1080,7 +1161,7 @@ extern "C" int orv_attention_fwd(const void* qkv, int ld_qkv, const void* vT, vo
     AttnArgs a;
     a.qkv = (const bf16_t*)qkv; a.ld = ld_qkv; a.vT = (const bf16_t*)vT; a.out = (bf16_t*)out; a.ld_out = ld_out;
     a.lse = lse; a.B = B; a.S = S; a.H = H; a.s_pad = s_pad;
-    a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f; a.shift = 0.f;
+    a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f; a.shift = 0.f; a.guard_dev = nullptr; a.guard_limit = 0.f; a.ws_o = a.ws_l = nullptr; a.ws_cnt = nullptr; a.n_full = a.ks = 0;
     dim3 grid(((S + 255) / 256) * H * B);
     // q pre-multiplied by scale*log2(e) in orv_qkv_prep (q_premul) arrives here as scale == 1/log2(e): fused fast path
     const bool fused = fabsf(a.scale_log2 - 1.0f) < 1e-6f;
@@ -1099,16 +1180,26 @@ extern "C" int orv_attention_fwd(const void* qkv, int ld_qkv, const void* vT, vo
 
 // The same attention when the caller can BOUND the scores: |q . k| * scale * log2(e) <= score_bound for every (query, key) of the
 // call (ORV: from the qk-LayerNorm affine parameters, orv_amd/cogvideox_control.py `score_bound`).  With the fused scale
-// (q pre-multiplied, scale == 1 / log2 e) and score_bound <= 40 the softmax runs with that bound as its fixed shift
-// (attn_fwd_v2_kernel<.., STATIC>); otherwise this is orv_attention_fwd.  A bound that does not hold gives P > 1 and, far enough
+// (q pre-multiplied, scale == 1 / log2 e) the softmax then needs no running max:
+//   * attn_fwd_pp_kernel<STATIC> (16-byte aligned output) computes P = exp2(s) with NO shift at all, so P lies in
+//     [2^-bound, 2^bound]: l <= S 2^bound and O <= l max|v| stay finite and every P stays a normal number for bound <= 90
+//     (2^90 x 2^14 keys x 2^10 = 2^114 < 2^127; 2^-90 > 2^-126) - ORV_STATIC_LIMIT_PP.  At gamma = 1, beta = 0 the bound is
+//     11.8, so the limit admits max|gamma_q| max|gamma_k| up to ~7.6 (40 was exceeded from ~3.4).
+//   * attn_fwd_v2_kernel<.., STATIC> (unaligned outputs) shifts by the bound, P in [2^(-2 bound), 1]: valid to bound <= 60.
+// Above the limit this is orv_attention_fwd (online softmax).  A bound that does not hold gives wrong results and, far enough
 // off, inf: the caller owns the guarantee (tests/test_gpu_kernels.py exercises a violated bound to show it is a contract).
+constexpr float ORV_STATIC_LIMIT_PP = 90.f, ORV_STATIC_LIMIT_V2 = 60.f;
 extern "C" int orv_attention_fwd_bounded(const void* qkv, int ld_qkv, void* out, int ld_out, float* lse, int B, int S, int H,
                                          float scale, float score_bound, void* stream) {
     const float scale_log2 = scale * 1.4426950408889634f;
     const bool fused = fabsf(scale_log2 - 1.0f) < 1e-6f;
     static int use_static = -1;      // ORV_ATTN_STATIC=0: A/B switch
     if (use_static < 0) { const char* e = getenv("ORV_ATTN_STATIC"); use_static = (e && atoi(e) == 0) ? 0 : 1; }
-    if (!use_static || !fused || !(score_bound > 0.f) || score_bound > 40.f)
+    static int use_pp_ = -1;
+    if (use_pp_ < 0) { const char* e = getenv("ORV_ATTN_PP"); use_pp_ = (e && atoi(e) == 0) ? 0 : 1; }
+    const bool aligned_out = ld_out % 8 == 0 && ((uintptr_t)out & 15) == 0;
+    const float limit = (use_pp_ && aligned_out) ? ORV_STATIC_LIMIT_PP : ORV_STATIC_LIMIT_V2;
+    if (!use_static || !fused || !(score_bound > 0.f) || score_bound > limit)
         return orv_attention_fwd(qkv, ld_qkv, nullptr, out, ld_out, lse, B, S, H, 0, scale, stream);
     ORV_REQUIRE(qkv && out, "orv_attention_fwd_bounded: null operand");
     ORV_REQUIRE(B > 0 && S > 0 && H > 0, "orv_attention_fwd_bounded: empty problem");
@@ -1116,7 +1207,7 @@ extern "C" int orv_attention_fwd_bounded(const void* qkv, int ld_qkv, void* out,
     AttnArgs a;
     a.qkv = (const bf16_t*)qkv; a.ld = ld_qkv; a.vT = nullptr; a.out = (bf16_t*)out; a.ld_out = ld_out;
     a.lse = lse; a.B = B; a.S = S; a.H = H; a.s_pad = 0;
-    a.scale = scale; a.scale_log2 = scale_log2; a.shift = score_bound;
+    a.scale = scale; a.scale_log2 = scale_log2; a.shift = score_bound; a.guard_dev = nullptr; a.guard_limit = 0.f; a.ws_o = a.ws_l = nullptr; a.ws_cnt = nullptr; a.n_full = a.ks = 0;
     dim3 grid(((S + 255) / 256) * H * B);
     static int use_pp = -1;
     if (use_pp < 0) { const char* e = getenv("ORV_ATTN_PP"); use_pp = (e && atoi(e) == 0) ? 0 : 1; }
@@ -1129,4 +1220,98 @@ extern "C" int orv_attention_fwd_bounded(const void* qkv, int ld_qkv, void* out,
     else
         hipLaunchKernelGGL((attn_fwd_v2_kernel<true, true, true>), grid, dim3(512), 0, (hipStream_t)stream, a);
     return orv_check_launch("orv_attention_fwd_bounded");
+}
+
+// Key-split tail (orv_attention_fwd_bounded_ws).  The grid of the ping-pong kernel is ceil(S / 256) H B workgroups on 2 x CUs slots: at
+// the headline shape 1560 on 512 = 3.05 rounds, and the dispatcher's fourth "round" of 24 full-length workgroups costs ~10 % of the
+// launch (profiles/r3_attention_pingpong.txt: span 3.79 workgroup lifetimes against 3.43 for an exact 3-round shape).  Plan: the
+// items beyond the last full round - when they are few - are cut into ks key ranges each and dispatched last.
+struct AttnSplit { int n_full, rest, ks; };
+static AttnSplit attn_split_plan(int B, int S, int H) {
+    AttnSplit sp{0, 0, 0};
+    static int enabled = -1;         // ORV_ATTN_SPLIT=0: A/B switch
+    if (enabled < 0) { const char* e = getenv("ORV_ATTN_SPLIT"); enabled = (e && atoi(e) == 0) ? 0 : 1; }
+    if (!enabled) return sp;
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    static int slots_env = -1;       // ORV_ATTN_SLOTS: pretend the chip has this many workgroup slots (tests of the split path at small shapes)
+    if (slots_env < 0) { const char* e = getenv("ORV_ATTN_SLOTS"); slots_env = e ? atoi(e) : 0; }
+    const int slots = slots_env > 0 ? slots_env : 2 * cus, items = ((S + 255) / 256) * H * B, nt = (S + KV - 1) / KV;
+    const int full = items / slots * slots, rest = items - full;
+    if (full == 0 || rest == 0 || rest * 4 > slots) return sp;          // nothing to cut, or the last round is not small
+    int ks = slots / (2 * rest);
+    if (ks > 8) ks = 8;
+    while (ks > 1 && nt < 4 * ks) --ks;                                  // every part keeps at least 4 key tiles
+    if (ks < 2) return sp;
+    sp.n_full = full; sp.rest = rest; sp.ks = ks;
+    return sp;
+}
+// bytes of workspace orv_attention_fwd_bounded_ws wants for this shape (0: the shape is not split)
+extern "C" size_t orv_attention_ws_bytes(int B, int S, int H) {
+    const AttnSplit sp = attn_split_plan(B, S, H);
+    if (!sp.ks) return 0;
+    return 1024 + (size_t)sp.rest * sp.ks * (256 * 64 + 256) * sizeof(float);
+}
+
+// largest score bound (log2 units) the fixed-shift softmax of orv_attention_fwd_bounded(_dev) accepts: 16-byte aligned output
+// (ping-pong kernel) / any output (v2 kernel)
+extern "C" float orv_attention_static_limit(int aligned_out) { return aligned_out ? ORV_STATIC_LIMIT_PP : ORV_STATIC_LIMIT_V2; }
+
+// orv_attention_fwd_bounded with a caller-provided workspace (>= orv_attention_ws_bytes(B, S, H), 256-byte aligned; reusable across
+// calls on one stream): when the fixed-shift ping-pong kernel applies and the shape has a small last round, that round is key-split
+// (above).  Without workspace, or where the plan does not apply, this IS orv_attention_fwd_bounded.  Results are deterministic
+// (fixed part order) but differ in fp32 summation order from the unsplit kernel for the split items.
+extern "C" int orv_attention_fwd_bounded_ws(const void* qkv, int ld_qkv, void* out, int ld_out, float* lse, int B, int S, int H,
+                                            float scale, float score_bound, void* ws, size_t ws_bytes, void* stream) {
+    const float scale_log2 = scale * 1.4426950408889634f;
+    const bool fused = fabsf(scale_log2 - 1.0f) < 1e-6f;
+    static int use_static = -1, use_pp = -1, use_m16 = -1;
+    if (use_static < 0) { const char* e = getenv("ORV_ATTN_STATIC"); use_static = (e && atoi(e) == 0) ? 0 : 1; }
+    if (use_pp < 0) { const char* e = getenv("ORV_ATTN_PP"); use_pp = (e && atoi(e) == 0) ? 0 : 1; }
+    if (use_m16 < 0) { const char* e = getenv("ORV_ATTN_M16"); use_m16 = (e && atoi(e) != 0) ? 1 : 0; }
+    const AttnSplit sp = (ws && B > 0 && S > 0 && H > 0) ? attn_split_plan(B, S, H) : AttnSplit{0, 0, 0};
+    if (!sp.ks || !use_static || !use_pp || use_m16 || !fused || !(score_bound > 0.f) || score_bound > ORV_STATIC_LIMIT_PP ||
+        ld_out % 8 != 0 || ((uintptr_t)out & 15) != 0 || ((uintptr_t)ws & 255) != 0 || ws_bytes < orv_attention_ws_bytes(B, S, H))
+        return orv_attention_fwd_bounded(qkv, ld_qkv, out, ld_out, lse, B, S, H, scale, score_bound, stream);
+    ORV_REQUIRE(qkv && out, "orv_attention_fwd_bounded_ws: null operand");
+    ORV_REQUIRE(ld_qkv % 8 == 0, "orv_attention_fwd_bounded_ws: misaligned leading dimension");
+    AttnArgs a;
+    a.qkv = (const bf16_t*)qkv; a.ld = ld_qkv; a.vT = nullptr; a.out = (bf16_t*)out; a.ld_out = ld_out;
+    a.lse = lse; a.B = B; a.S = S; a.H = H; a.s_pad = 0;
+    a.scale = scale; a.scale_log2 = scale_log2; a.shift = 0.f; a.guard_dev = nullptr; a.guard_limit = 0.f;
+    a.ws_cnt = (unsigned*)ws;
+    a.ws_o = (float*)((char*)ws + 1024);
+    a.ws_l = a.ws_o + (size_t)sp.rest * sp.ks * 256 * 64;
+    a.n_full = sp.n_full; a.ks = sp.ks;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, 1024, st) != hipSuccess) { orv_set_error("orv_attention_fwd_bounded_ws: hipMemsetAsync failed"); return ORV_EDEVICE; }
+    hipLaunchKernelGGL((attn_fwd_pp_kernel<true, true>), dim3(sp.n_full + sp.rest * sp.ks), dim3(512), 0, st, a);
+    return orv_check_launch("orv_attention_fwd_bounded_ws");
+}
+
+// orv_attention_fwd_bounded with the bound in DEVICE memory (one fp32, e.g. element l of the per-layer bound vector the training
+// step recomputes on the device after every optimizer update): no device -> host read.  The fixed-shift and the online form of
+// the ping-pong kernel are both launched and every workgroup of the form the scalar does not select returns at once (~2 us of an
+// empty grid per call).  Needs the fused scale and a 16-byte aligned output (else: orv_attention_fwd, online softmax).
+extern "C" int orv_attention_fwd_bounded_dev(const void* qkv, int ld_qkv, void* out, int ld_out, float* lse, int B, int S, int H,
+                                             float scale, const float* score_bound_dev, void* stream) {
+    ORV_REQUIRE(qkv && out && score_bound_dev, "orv_attention_fwd_bounded_dev: null operand");
+    ORV_REQUIRE(B > 0 && S > 0 && H > 0, "orv_attention_fwd_bounded_dev: empty problem");
+    ORV_REQUIRE(ld_qkv % 8 == 0 && ld_out % 4 == 0, "orv_attention_fwd_bounded_dev: misaligned leading dimension");
+    const float scale_log2 = scale * 1.4426950408889634f;
+    const bool fused = fabsf(scale_log2 - 1.0f) < 1e-6f;
+    static int use_static = -1, use_pp = -1;
+    if (use_static < 0) { const char* e = getenv("ORV_ATTN_STATIC"); use_static = (e && atoi(e) == 0) ? 0 : 1; }
+    if (use_pp < 0) { const char* e = getenv("ORV_ATTN_PP"); use_pp = (e && atoi(e) == 0) ? 0 : 1; }
+    if (!use_static || !use_pp || !fused || ld_out % 8 != 0 || ((uintptr_t)out & 15) != 0)
+        return orv_attention_fwd(qkv, ld_qkv, nullptr, out, ld_out, lse, B, S, H, 0, scale, stream);
+    AttnArgs a;
+    a.qkv = (const bf16_t*)qkv; a.ld = ld_qkv; a.vT = nullptr; a.out = (bf16_t*)out; a.ld_out = ld_out;
+    a.lse = lse; a.B = B; a.S = S; a.H = H; a.s_pad = 0;
+    a.scale = scale; a.scale_log2 = scale_log2; a.shift = 0.f; a.guard_dev = score_bound_dev; a.guard_limit = ORV_STATIC_LIMIT_PP; a.ws_o = a.ws_l = nullptr; a.ws_cnt = nullptr; a.n_full = a.ks = 0;
+    dim3 grid(((S + 255) / 256) * H * B);
+    hipLaunchKernelGGL((attn_fwd_pp_kernel<true>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((attn_fwd_pp_kernel<false>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    return orv_check_launch("orv_attention_fwd_bounded_dev");
 }

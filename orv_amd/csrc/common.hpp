@@ -42,11 +42,12 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 }
 
 __device__ __forceinline__ float gelu_tanh(float x) {
-    // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))),  tanh(u) = 1 - 2 / (1 + exp(2u))
-    // 0.5 x (1 + tanh(u)) = x - x / (1 + exp(2u));  exp(2u) = exp2(u * 2 log2 e), reciprocal via v_rcp_f32
-    const float u2 = (2.0f * 0.7978845608028654f * 1.4426950408889634f) * (x + 0.044715f * x * x * x);
-    const float e = __builtin_amdgcn_exp2f(u2);
-    return x - x * __builtin_amdgcn_rcpf(1.0f + e);
+    // 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3), is x sigmoid(2u) = x / (1 + exp(-2u)); with -2u log2(e) = x (c0 + c1 x^2):
+    // five plain VALU instructions + v_exp_f32 + v_rcp_f32 per element (round 3's form x - x / (1 + exp(2u)) took eight + two; the GELU
+    // epilogue is bound by exactly these).  Large |x|: exp2 -> inf gives x * 0 = -0, exp2 -> 0 gives x: no NaN.
+    constexpr float c0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, c1 = c0 * 0.044715f;
+    const float z = x * __builtin_fmaf(x * x, c1, c0);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
 }
 // d/dx of gelu_tanh
 __device__ __forceinline__ float gelu_tanh_grad(float x) {

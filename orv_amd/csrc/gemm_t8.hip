@@ -256,11 +256,185 @@ __device__ __forceinline__ void t8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][4
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 4: epilogue through a per-wave LDS transpose (the shipped one; -DORV_T8_EPI_DIRECT keeps the register-layout epilogue above).
+// Why: in the accumulator layout lane (r = lane & 15, g = lane >> 4) owns 16-byte pieces of row r, so ONE store / residual-load
+// instruction touches 16 different rows and the four lanes that share a row's 64-byte segment are 16 lanes apart - the address
+// coalescer sees 64 separate 16-byte requests.  Measured (profiles/r4_gemm_epilogue_ablation.txt): the stores alone cost 10-12 % of
+// every K = 1920 GEMM (~6 us per 128-KB tile and CU = 11 B/clk/CU, the same with half the CUs active: a per-CU request rate, not a
+// memory burst), the residual loads of the gated epilogue about as much again.  Here every 16-row block of the wave goes through a
+// 4-KiB fp32 scratch image [16 rows][64 columns] in LDS (wave-private: no barrier) and comes back with lane l = (row l >> 3,
+// 8-column chunk l & 7): 8 adjacent lanes hold one row's 128 contiguous bytes (BN = 256; 96 of them at BN = 192, lanes with chunk >= 6
+// idle), a store / load instruction is 8 rows x one full line.  Image: 16-byte chunk L of row r sits at chunk L ^ (r & 7)
+// (conflict-free for the 8-lane ds_write_b128 groups and the 16-lane ds_read_b128 groups).
+// The arithmetic is the register epilogue's, element for element (same fp32 expressions), so results are bit-identical to it.
+__device__ __forceinline__ float sum8(float v) {             // sum over the 8 lanes lane & ~7 .. lane | 7
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x141, 0xF, 0xF, true));    // row_half_mirror
+    return v;
+}
+
+template <int BN, int EPI>
+__device__ __forceinline__ void t8_epilogue_lds(const GemmArgs& p, f32x4 (&acc)[2][4][BN / 64], const int mbase, const int nbase, const int lane,
+                                                char* const scr) {
+    constexpr int NBW = BN / 64;                     // 16-column accumulator blocks per wave
+    constexpr int NC = BN / 32;                      // 8-column chunks per row of the wave (8 or 6)
+    static_assert(BN == 256 || EPI != 4, "epilogue 4 needs whole heads per wave");
+    const int g = lane >> 4, r16 = lane & 15;        // accumulator side
+    const int c = lane & 7, rr8 = lane >> 3;         // transposed side: row 8 j + rr8 of the block, columns 8 c .. 8 c + 7 of the wave
+    const bool lane_on = c < NC;
+    const int col8 = nbase + 8 * min(c, NC - 1);
+#ifdef ORV_T8_ABL_NOSTORE
+    const bool st_ok = p.M < 0;
+#else
+    constexpr bool st_ok = true;
+#endif
+    // scratch offsets
+    int woff[NBW];
+#pragma unroll
+    for (int blk = 0; blk < NBW; ++blk) {
+        const int L = BN == 256 ? 8 * (blk >> 1) + 2 * g + (blk & 1) : (blk < 2 ? 2 * g + blk : 8 + g);
+        woff[blk] = r16 * 256 + ((L ^ (r16 & 7)) << 4);
+    }
+    const int roff0 = rr8 * 256 + (((2 * c) ^ rr8) << 4), roff1 = rr8 * 256 + (((2 * c + 1) ^ rr8) << 4);      // + j * 2048
+
+    float b8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b8[e] = 0.f;
+    if (p.bias) unpack8(*(const uint4*)(p.bias + col8), b8);
+
+    // epilogue 4: qk LayerNorm parameters of this lane's 8 channels of the head
+    float ga[8], be[8];
+    int region = 2;
+    float post = 1.f;
+    if constexpr (EPI == 4) {
+        region = __builtin_amdgcn_readfirstlane(nbase / (p.qn_heads * 64));     // 0 = q, 1 = k, 2 = v
+        const bf16_t* gam = region == 0 ? p.qn_gq : p.qn_gk;
+        const bf16_t* bet = region == 0 ? p.qn_bq : p.qn_bk;
+        post = region == 0 ? p.qn_premul : 1.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ga[e] = 1.f; be[e] = 0.f; }
+        if (region < 2 && gam) unpack8(*(const uint4*)(gam + 8 * c), ga);
+        if (region < 2 && bet) unpack8(*(const uint4*)(bet + 8 * c), be);
+    }
+    // gate row cache (EPI 2): the fp32 gate values of this lane's 8 columns, reloaded only when the block's gate row changes
+    float g8[8];
+    const float* g_cached = nullptr;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g8[e] = 1.f;
+
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+        // row operands of this half's 8 row groups (4 blocks x 2 rounds of 8 rows) are requested together
+        long orow[4][2];
+        bool valid[4][2];
+        uint4 r8[4][2];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int m = mbase + mh * 64 + mb * 16 + 8 * j + rr8;
+                valid[mb][j] = m < p.M && lane_on;
+                const int mc = min(m, p.M - 1);
+                orow[mb][j] = mc;
+                if (p.c_rows > 0) orow[mb][j] = (long)(mc / p.c_rows) * p.c_bstride + p.c_off + mc % p.c_rows;
+                if (EPI == 2 || EPI == 3) {
+                    const long rr = p.r_mod > 0 ? mc % p.r_mod : orow[mb][j];
+                    r8[mb][j] = *(const uint4*)(p.R + rr * p.ldr + col8);
+                }
+            }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            // accumulators -> scratch (fp32, natural column order), back as rows
+#pragma unroll
+            for (int blk = 0; blk < NBW; ++blk) *(f32x4*)(scr + woff[blk]) = acc[mh][mb][blk];
+            float v[2][8];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4 lo = *(const f32x4*)(scr + j * 2048 + roff0), hi = *(const f32x4*)(scr + j * 2048 + roff1);
+                v[j][0] = lo[0]; v[j][1] = lo[1]; v[j][2] = lo[2]; v[j][3] = lo[3];
+                v[j][4] = hi[0]; v[j][5] = hi[1]; v[j][6] = hi[2]; v[j][7] = hi[3];
+            }
+            // gate row of this 16-row block (EPI 2): wave-uniform when the block lies inside one (batch element, token group)
+            bool g_lane = false;
+            if (EPI == 2 && p.gate) {
+                const int mf = __builtin_amdgcn_readfirstlane(mbase + mh * 64 + mb * 16), ml = min(mf + 15, p.M - 1);
+                long of = min(mf, p.M - 1), ol = ml;
+                if (p.c_rows > 0) {
+                    of = (long)(of / p.c_rows) * p.c_bstride + p.c_off + of % p.c_rows;
+                    ol = (long)(ml / p.c_rows) * p.c_bstride + p.c_off + ml % p.c_rows;
+                }
+                const int bf_ = (int)(of / p.seq), bl_ = (int)(ol / p.seq);
+                const int gf_ = orv_group_of((int)(of % p.seq), p.n_text, p.per_group);
+                const int gl_ = orv_group_of((int)(ol % p.seq), p.n_text, p.per_group);
+                if (bf_ == bl_ && gf_ == gl_) {
+                    const float* gr = p.gate + bf_ * p.gate_b + gf_ * p.gate_g;
+                    if (gr != g_cached) {
+                        g_cached = gr;
+                        const float4 a = *(const float4*)(gr + col8), b = *(const float4*)(gr + col8 + 4);
+                        g8[0] = a.x; g8[1] = a.y; g8[2] = a.z; g8[3] = a.w; g8[4] = b.x; g8[5] = b.y; g8[6] = b.z; g8[7] = b.w;
+                    }
+                } else g_lane = true;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float (&w)[8] = v[j];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[e] += b8[e];
+                bf16_t* crow = p.C + orow[mb][j] * p.ldc + col8;
+                if (p.Y && valid[mb][j] && st_ok) *(uint4*)(p.Y + orow[mb][j] * p.ldy + col8) = pack8(w);
+                if constexpr (EPI == 4) {
+                    if (region < 2) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) s += w[e];
+                        const float mean = sum8(s) * (1.f / 64.f);
+                        float sq = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { w[e] -= mean; sq += w[e] * w[e]; }
+                        const float rstd = rsqrtf(sum8(sq) * (1.f / 64.f) + p.qn_eps);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) w[e] = (w[e] * rstd * ga[e] + be[e]) * post;
+                    }
+                }
+                if (EPI == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w[e] = gelu_tanh(w[e]);
+                }
+                if (EPI == 2) {
+                    float rv[8], gg[8];
+                    unpack8(r8[mb][j], rv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gg[e] = g8[e];
+                    if (g_lane) {            // block straddles a frame / text boundary: this lane's row picks its own gate row
+                        const int bidx = (int)(orow[mb][j] / p.seq), sq_ = (int)(orow[mb][j] % p.seq);
+                        const float* grow = p.gate + bidx * p.gate_b + orv_group_of(sq_, p.n_text, p.per_group) * p.gate_g;
+                        const float4 a = *(const float4*)(grow + col8), b = *(const float4*)(grow + col8 + 4);
+                        gg[0] = a.x; gg[1] = a.y; gg[2] = a.z; gg[3] = a.w; gg[4] = b.x; gg[5] = b.y; gg[6] = b.z; gg[7] = b.w;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w[e] = rv[e] + gg[e] * w[e];
+                }
+                if (EPI == 3) {
+                    float rv[8];
+                    unpack8(r8[mb][j], rv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w[e] *= gelu_tanh_grad(rv[e]);
+                }
+                if (valid[mb][j] && st_ok) *(uint4*)crow = pack8(w);
+            }
+        }
+    }
+}
+
 template <int BN, int EPI>
 __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
     constexpr int NBW = BN / 64;                      // 16-column blocks per wave
     constexpr int HALF = 16384;                       // A0 | A1 | B region 0 | B region 1
     constexpr int BUF = BN == 256 ? 65536 : 57344;    // BN = 192: the second B region (block 2 of every wave) is 64 rows = 8 KiB
+    constexpr int SCR = 2 * BUF;                      // epilogue transpose scratch: 8 waves x 4 KiB behind the two K-tile buffers
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -428,15 +602,71 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
         T8_BAR() T8_PRIO1() T8_MFMA(1, 0, 2) T8_PRIO0() T8_BAR()                                                     \
     }
 
+    // ---- experiment (-DORV_T8_SCHED2, tools/t8_sched_ab.sh): TWO phases of 32 (24) MFMAs per K-tile instead of four (three) of 16: half as
+    // many barriers per MFMA, load segments of 20 + 4 (14 + 8) fragment reads that are closer to the MFMA segments in length.  The
+    // fragment reads are retired BEFORE a phase's first barrier (the DMA that restages a region is issued one phase after its last
+    // reader passed that barrier), one counted vmcnt per phase.
+    //   BN = 256: P1 reads A0 A1 B01, issues B1 (region 1) of K-tile + 1, MFMA (m0 m1) x n01 | P2 reads B23, issues A0 A1 B0 of K-tile + 2,
+    //             MFMA (m0 m1) x n23; vmcnt(8) in both.
+    //   BN = 192: P1 reads A0 B012, issues A1 of K-tile + 1, MFMA m0 x n012 | P2 reads A1, issues A0 B0 B1 of K-tile + 2, MFMA m1 x n012;
+    //             vmcnt(7) in both.
+#define T8_LGKM0_PRE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#define T8_KTILE2_256(S)                                                                                             \
+    {                                                                                                                \
+        T8_READ_B01(S)                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        T8_READ_A(0, S)                                                                                              \
+        T8_READ_A(1, S)                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        T8_ISSUE_B1((S) ^ 1)                                                                                         \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                             \
+        T8_LGKM0_PRE()                                                                                               \
+        T8_BAR() T8_PRIO1() T8_MFMA(0, 0, 2) T8_MFMA(1, 0, 2) T8_PRIO0() T8_BAR()                                    \
+        T8_READ_B23(S)                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        T8_ISSUE_A0(S)                                                                                               \
+        T8_ISSUE_A1(S)                                                                                               \
+        T8_ISSUE_B0(S)                                                                                               \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                             \
+        T8_LGKM0_PRE()                                                                                               \
+        T8_BAR() T8_PRIO1() T8_MFMA(0, 2, 2) T8_MFMA(1, 2, 2) T8_PRIO0() T8_BAR()                                    \
+    }
+#define T8_KTILE2_192(S)                                                                                             \
+    {                                                                                                                \
+        T8_READ_B01(S)                                                                                               \
+        T8_READ_B23(S)                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        T8_READ_A(0, S)                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        T8_ISSUE_A1((S) ^ 1)                                                                                         \
+        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                                                             \
+        T8_LGKM0_PRE()                                                                                               \
+        T8_BAR() T8_PRIO1() T8_MFMA(0, 0, 3) T8_PRIO0() T8_BAR()                                                     \
+        T8_READ_A(1, S)                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        T8_ISSUE_A0(S)                                                                                               \
+        T8_ISSUE_B0(S)                                                                                               \
+        T8_ISSUE_B1(S)                                                                                               \
+        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                                                             \
+        T8_LGKM0_PRE()                                                                                               \
+        T8_BAR() T8_PRIO1() T8_MFMA(1, 0, 3) T8_PRIO0() T8_BAR()                                                     \
+    }
+
     // prologue: K-tile 0 complete into buffer 0, then the pieces of K-tile 1 the steady state would have issued by now
     if constexpr (BN == 256) {
         T8_ISSUE_A0(0) T8_ISSUE_B0(0) T8_ISSUE_A1(0) T8_ISSUE_B1(0)
         T8_ISSUE_B0(1) T8_ISSUE_A0(1) T8_ISSUE_A1(1)
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
+#ifdef ORV_T8_SCHED2
+        T8_ISSUE_A0(0) T8_ISSUE_B0(0) T8_ISSUE_A1(0) T8_ISSUE_B1(0)
+        T8_ISSUE_A0(1) T8_ISSUE_B0(1) T8_ISSUE_B1(1)
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+#else
         T8_ISSUE_A0(0) T8_ISSUE_B0(0) T8_ISSUE_A1(0) T8_ISSUE_B1(0)
         T8_ISSUE_B0(1) T8_ISSUE_A0(1)
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#endif
     }
     if (p.stagger_groups > 1) {
         // the prologue's DMA is in flight; this workgroup's group waits its share of the stagger before the first K-tile
@@ -446,19 +676,62 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
     }
     T8_BAR()
 
+#ifdef ORV_T8_TRACE   // tools/trace_t8.cpp (EPI 0 / 1 builds only: R doubles as the trace buffer): wall-clock stamps (10 ns) of waves 0 and 4 of
+    // workgroups 0, 8 and 100: [loop start, after K-tiles 0-1, after K-tiles 2-3, loop end, epilogue start, epilogue end (stores issued),
+    // (ORV_T8_TRACE == 2: + after s_waitcnt vmcnt(0), i.e. the stores have drained)] for their first 8 tiles
+    int trace_i = 0;
+    const int trace_w = blockIdx.x == 0 ? 0 : (blockIdx.x == 8 ? 1 : (blockIdx.x == 100 ? 2 : -1));
+#define T8_STAMP(SLOT)                                                                                               \
+    if (trace_w >= 0 && (wave & 3) == 0 && lane == 0 && trace_i < 8)                                                 \
+        ((unsigned long long*)p.R)[((trace_w * 2 + wr) * 8 + trace_i) * 8 + (SLOT)] = wall_clock64();
+#else
+#define T8_STAMP(SLOT)
+#endif
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         if (wr == 1) { T8_BAR() }             // the second half of the workgroup runs one barrier behind ...
+        T8_STAMP(0)
         for (int kt = 0; kt < nk; kt += 2) {
+#ifdef ORV_T8_SCHED2
+            if constexpr (BN == 256) { T8_KTILE2_256(0) T8_KTILE2_256(1) }
+            else { T8_KTILE2_192(0) T8_KTILE2_192(1) }
+#else
             if constexpr (BN == 256) { T8_KTILE_256(0) T8_KTILE_256(1) }
             else { T8_KTILE_192(0) T8_KTILE_192(1) }
+#endif
+#ifdef ORV_T8_TRACE
+            if (kt == 0) { T8_STAMP(1) }
+            if (kt == 2) { T8_STAMP(2) }
+#endif
         }
+        T8_STAMP(3)
         if (wr == 0) { T8_BAR() }             // ... and both halves run their epilogues side by side
+        T8_STAMP(4)
         int tm, tn;
         tile_of_index(p, tile, ntiles, tm, tn);
 #ifdef ORV_T8_ABL_NOEPI      // ablation build: no epilogue at all (the accumulators stay live through the never-taken call)
         if (p.M < 0)
 #endif
-        t8_epilogue<BN, EPI>(p, acc, tm * 256 + wr * 128, tn * BN + wc * (BN / 4), lane);
+        // which epilogue: the LDS-transposed one wins where row operands are LOADED (gated residual: FFN2 -4.5 %, out-projection
+        // -2...4 %) and is level for the plain / qk-LayerNorm epilogues; the GELU epilogue is bound by its two transcendentals per
+        // element and pays the LDS round trip on top (+1...2 %): it keeps the register-layout form
+        // (profiles/r4_gemm_epilogue_ablation.txt).  -DORV_T8_EPI_DIRECT / -DORV_T8_EPI_LDS force one form (A/B builds).
+#if defined(ORV_T8_EPI_DIRECT)
+        constexpr bool lds_epi = false;
+#elif defined(ORV_T8_EPI_LDS)
+        constexpr bool lds_epi = true;
+#else
+        constexpr bool lds_epi = EPI != 1;
+#endif
+        if constexpr (lds_epi) t8_epilogue_lds<BN, EPI>(p, acc, tm * 256 + wr * 128, tn * BN + wc * (BN / 4), lane, smem + SCR + wave * 4096);
+        else t8_epilogue<BN, EPI>(p, acc, tm * 256 + wr * 128, tn * BN + wc * (BN / 4), lane);
+        T8_STAMP(5)
+#ifdef ORV_T8_TRACE
+#if ORV_T8_TRACE == 2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        T8_STAMP(6)
+#endif
+        ++trace_i;
+#endif
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -471,7 +744,7 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
 
 template <int BN, int EPI>
 int launch_one(const GemmArgs& a, hipStream_t st) {
-    constexpr int smem = 2 * (BN == 256 ? 65536 : 57344);
+    constexpr int smem = 2 * (BN == 256 ? 65536 : 57344) + 8 * 4096;      // two K-tile buffers + the epilogue scratch (160 KiB at BN = 256)
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)gemm_t8_kernel<BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);

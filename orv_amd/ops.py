@@ -205,10 +205,33 @@ def linear(x2d, W, bias=None, epilogue=0):
     return gemm(x2d, W, bias, C, M, N, K, epilogue)
 
 
-def attention_fwd(qkv, vT, out, B, S, H, s_pad, scale, lse=None, ld_qkv=None, ld_out=None, score_bound=None):
+def attention_ws_bytes(B, S, H):
+    """Workspace bytes ``attention_fwd(..., ws=)`` wants for this shape (0: the shape's grid is not key-split)."""
+    return int(lib().orv_attention_ws_bytes(int(B), int(S), int(H)))
+
+
+def attention_fwd(qkv, vT, out, B, S, H, s_pad, scale, lse=None, ld_qkv=None, ld_out=None, score_bound=None, score_bound_dev=None, ws=None):
     """``score_bound`` (V in place only): a guaranteed upper bound of |q . k| * scale * log2(e) over the whole call - the kernel
-    then runs its fixed-shift softmax when the bound is small enough (``orv_attention_fwd_bounded``)."""
+    then runs its fixed-shift softmax when the bound is small enough (``orv_attention_fwd_bounded``).  ``score_bound_dev``: the
+    same bound as a one-element fp32 DEVICE tensor (``orv_attention_fwd_bounded_dev``: no host read; training)."""
     _need(qkv, BF16, "qkv"), _need(out, BF16, "out")
+    if score_bound_dev is not None and vT is None:
+        _need(score_bound_dev, torch.float32, "score_bound_dev")
+        if score_bound_dev.numel() != 1:
+            raise ValueError("attention_fwd: score_bound_dev must hold exactly one fp32 value")
+        with _timed(("attention", B, S, H)):
+            check(lib().orv_attention_fwd_bounded_dev(_p(qkv), ld_qkv or 3 * H * 64, _p(out), ld_out or H * 64, _p(lse), B, S, H,
+                                                      float(scale), _p(score_bound_dev), _stream()), "orv_attention_fwd_bounded_dev")
+        return out
+    if score_bound is not None and vT is None and ws is not None:
+        # key-split last round (orv_attention_fwd_bounded_ws): ws from attention_ws_bytes(B, S, H), reusable on one stream
+        if ws.dtype != torch.uint8 or not ws.is_cuda:
+            raise ValueError("attention_fwd: ws must be a uint8 CUDA tensor")
+        with _timed(("attention", B, S, H)):
+            check(lib().orv_attention_fwd_bounded_ws(_p(qkv), ld_qkv or 3 * H * 64, _p(out), ld_out or H * 64, _p(lse), B, S, H,
+                                                     float(scale), float(score_bound), _p(ws), ws.numel(), _stream()),
+                  "orv_attention_fwd_bounded_ws")
+        return out
     if score_bound is not None and vT is None:
         with _timed(("attention", B, S, H)):
             check(lib().orv_attention_fwd_bounded(_p(qkv), ld_qkv or 3 * H * 64, _p(out), ld_out or H * 64, _p(lse), B, S, H,

@@ -116,7 +116,7 @@ def _attn_forward(at, xn, ly, bufs, B_, S_, n_text, heads, rope, scale):
     _M._qkv_projection(at, xn, ly.qkvn, rope, B_, S_, heads, n_text, bufs.s_pad, scale, raw=ly.qkv_raw)   # 148 MB/layer)
     ly.att = torch.empty(M_, D, dtype=BF16, device=dev)
     ly.lse = torch.empty(B_, heads, S_, dtype=torch.float32, device=dev)
-    ops.attention_fwd(ly.qkvn, None, ly.att, B_, S_, heads, bufs.s_pad, 1.0 / LOG2E, lse=ly.lse, score_bound=at.score_bound(scale))
+    ops.attention_fwd(ly.qkvn, None, ly.att, B_, S_, heads, bufs.s_pad, 1.0 / LOG2E, lse=ly.lse, score_bound_dev=at.score_bound_dev(scale))
 
 
 def _attn_backward(at, ly, xn, datt, bufs, B_, S_, n_text, heads, rope, scale, grads, f32_to_param_grad, z32):
@@ -330,7 +330,8 @@ def forward_train(model, hidden_states, encoder_hidden_states, controls, timeste
     mb, mg = G * 3 * D, 3 * D
     scale = 1.0 / math.sqrt(c.attention_head_dim)
     from .cogvideox_control import prime_score_bounds
-    prime_score_bounds([b.attn1 for b in model.transformer_blocks] + ([b.attn1 for b in model.mv_blocks] if c.multiview else []), scale)
+    prime_score_bounds([b.attn1 for b in model.transformer_blocks] + ([b.attn1 for b in model.mv_blocks] if c.multiview else []), scale,
+                       on_device=True)      # no device -> host read in the training step
     bufs = _AttnBufs(B, S, heads, dev)
     sv.mv = None
     if c.multiview:                                                                  # :273-348

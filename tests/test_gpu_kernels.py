@@ -604,7 +604,7 @@ def test_attention_fixed_shift_softmax_with_a_score_bound(B, S, H, nt, use_rope)
 
 
 def test_attention_bound_too_large_takes_the_online_kernel():
-    """Adversarially large qk-LayerNorm gains: the bound exceeds what the fixed shift may absorb (40 log2 units), and the bounded
+    """Adversarially large qk-LayerNorm gains: the bound exceeds what the fixed shift may absorb (90 log2 units), and the bounded
     entry point must run the online kernel - bit-identical to orv_attention_fwd, correct against the reference."""
     from orv_amd import ops
     from orv_amd.cogvideox_control import Attention
@@ -617,7 +617,8 @@ def test_attention_bound_too_large_takes_the_online_kernel():
     with torch.no_grad():
         at.norm_q.weight.copy_(gq); at.norm_q.bias.copy_(bq); at.norm_k.weight.copy_(gk); at.norm_k.bias.copy_(bk)
     bound = at.score_bound(0.125)
-    assert bound > 40.0
+    from orv_amd._lib import lib
+    assert bound > lib().orv_attention_static_limit(1) == 90.0
     dq = qkv.to(dev, BF).clone()
     ops.qkv_prep(dq, None, gq.to(dev, BF), bq.to(dev, BF), gk.to(dev, BF), bk.to(dev, BF), None, B, S, H, 0, 320, 1e-6,
                  q_premul=0.125 * LOG2E)
@@ -630,6 +631,148 @@ def test_attention_bound_too_large_takes_the_online_kernel():
     t = dq.float().cpu().view(B, S, 3, H, 64).permute(2, 0, 3, 1, 4)
     pr = torch.softmax(torch.einsum("bhqd,bhkd->bhqk", t[0], t[1]) * math.log(2.0), dim=-1)
     close(out, torch.einsum("bhqk,bhkd->bhqd", pr, t[2]).transpose(1, 2).reshape(B * S, H * 64))
+
+
+def _gamma_case(gq_val, gk_val, seed=5, B=2, S=520, H=3):
+    from orv_amd import ops
+    from orv_amd.cogvideox_control import Attention
+    dev = _dev()
+    g = torch.Generator().manual_seed(seed)
+    qkv = q(torch.randn(B * S, 3 * H * 64, generator=g))
+    gq, bq = q(torch.full((64,), gq_val) * (1 + 0.05 * torch.randn(64, generator=g)).clamp(0.8, 1.0)), q(torch.randn(64, generator=g) * 0.2)
+    gk, bk = q(torch.full((64,), gk_val) * (1 + 0.05 * torch.randn(64, generator=g)).clamp(0.8, 1.0)), q(torch.randn(64, generator=g) * 0.2)
+    at = Attention(H * 64, H, 64, True, True)
+    with torch.no_grad():
+        at.norm_q.weight.copy_(gq); at.norm_q.bias.copy_(bq); at.norm_k.weight.copy_(gk); at.norm_k.bias.copy_(bk)
+    at = at.to(dev)                          # the device-side bound lives where the norm parameters live
+    s_pad = (S + 63) // 64 * 64
+    dq = qkv.to(dev, BF).clone()
+    ops.qkv_prep(dq, None, gq.to(dev, BF), bq.to(dev, BF), gk.to(dev, BF), bk.to(dev, BF), None, B, S, H, 0, s_pad, 1e-6,
+                 q_premul=0.125 * LOG2E)
+    # fp32 softmax over the SAME bf16 q', k', v the kernel reads (exp2: q' carries scale * log2 e)
+    t = dq.float().cpu().view(B, S, 3, H, 64).permute(2, 0, 3, 1, 4)
+    sc = torch.einsum("bhqd,bhkd->bhqk", t[0], t[1])
+    pr = torch.softmax(sc * math.log(2.0), dim=-1)
+    ref = torch.einsum("bhqk,bhkd->bhqd", pr, t[2]).transpose(1, 2).reshape(B * S, H * 64)
+    lse_ref = torch.logsumexp(sc * math.log(2.0), dim=-1)
+    return at, dq, ref, lse_ref, sc.abs().max().item(), (B, S, H, s_pad)
+
+
+def test_attention_fixed_shift_fast_path_at_gamma_product_5():
+    """a trained qk LayerNorm with max|gamma_q| max|gamma_k| = 5 (bound ~ 60 log2 units: ordinary for a trained
+    model, far above the 11.8 of random init and above round 3's limit of 40) still runs the shift-free softmax: P = exp2(s)
+    spans [2^-60, 2^60] and stays a normal fp32 / bf16 number.  Against the fp32 softmax over the same bf16 q', k', v, lse
+    included, and against the online kernel."""
+    from orv_amd import ops
+    from orv_amd._lib import lib
+    at, dq, ref, lse_ref, smax, (B, S, H, s_pad) = _gamma_case(2.5, 2.0)
+    bound = at.score_bound(0.125)
+    assert 40.0 < bound <= lib().orv_attention_static_limit(1), bound       # the dispatch takes the fixed-shift kernel
+    assert smax <= bound and smax > 12.0, smax                              # the bound holds, and the scores really are large
+    dev = dq.device
+    out = torch.full((B * S, H * 64), float("nan"), dtype=BF, device=dev)
+    lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+    ops.attention_fwd(dq, None, out, B, S, H, s_pad, 1.0 / LOG2E, lse=lse, score_bound=bound)
+    close(out, ref)
+    close(lse, lse_ref, rtol=2e-3, afrac=2e-3)
+    out_online, lse_online = torch.empty_like(out), torch.empty_like(lse)
+    ops.attention_fwd(dq, None, out_online, B, S, H, s_pad, 1.0 / LOG2E, lse=lse_online)
+    close(out, out_online.float().cpu(), rtol=1.6e-2, afrac=4e-3)
+    assert (lse - lse_online).abs().max().item() <= 2e-3 * max(1.0, lse_online.abs().max().item())
+
+
+@pytest.mark.parametrize("gq_val,gk_val", [(1.0, 1.0), (2.5, 2.0), (4.0, 3.5)])
+def test_attention_device_side_bound_selects_the_same_kernel(gq_val, gk_val):
+    """orv_attention_fwd_bounded_dev (training: the bound changes with every optimizer step and is never read back to the host):
+    both softmax forms are launched and the device scalar picks one - bit-identical to the host-side dispatch with the same bound,
+    below the limit (fixed-shift kernel) and above it (online kernel; 4 x 3.5 gives ~ 165 log2 units)."""
+    from orv_amd import ops
+    at, dq, ref, lse_ref, smax, (B, S, H, s_pad) = _gamma_case(gq_val, gk_val, seed=9)
+    dev = dq.device
+    bound = at.score_bound(0.125)
+    bdev = at.score_bound_dev(0.125)
+    assert bdev.is_cuda and bdev.numel() == 1 and abs(bdev.item() - bound) <= 1e-4 * bound
+    out_h, out_d = (torch.full((B * S, H * 64), float("nan"), dtype=BF, device=dev) for _ in range(2))
+    lse_h, lse_d = (torch.full((B, H, S), float("nan"), dtype=torch.float32, device=dev) for _ in range(2))
+    ops.attention_fwd(dq, None, out_h, B, S, H, s_pad, 1.0 / LOG2E, lse=lse_h, score_bound=bound)
+    ops.attention_fwd(dq, None, out_d, B, S, H, s_pad, 1.0 / LOG2E, lse=lse_d, score_bound_dev=bdev)
+    import os
+    if os.environ.get("ORV_ATTN_M16") == "1":      # the opt-in 16x16x32 kernel serves the host-side dispatch only: same values, other rounding
+        close(out_d, out_h.float().cpu(), rtol=1.6e-2, afrac=4e-3)
+    else:
+        assert torch.equal(out_h, out_d) and torch.equal(lse_h, lse_d)
+    close(out_d, ref)
+
+
+def _split_case(B, S, H, seed, expect_split=True):
+    """bounded attention with and without the key-split workspace on random q' | k' | v (post-LayerNorm scale)."""
+    from orv_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(seed)
+    D = H * 64
+    dq = (torch.randn(B * S, 3 * D, generator=g) * 0.9).to(dev, BF)
+    nb = ops.attention_ws_bytes(B, S, H)
+    assert (nb > 0) == expect_split, nb
+    ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+    outs = []
+    for use_ws in (None, ws, ws):
+        out = torch.full((B * S, D), float("nan"), dtype=BF, device=dev)
+        lse = torch.full((B, H, S), float("nan"), dtype=torch.float32, device=dev)
+        ops.attention_fwd(dq, None, out, B, S, H, 0, 1.0 / LOG2E, lse=lse, score_bound=30.0, ws=use_ws)
+        outs.append((out, lse))
+    (o0, l0), (o1, l1), (o2, l2) = outs
+    assert torch.isfinite(o1.float()).all() and torch.isfinite(l1).all()
+    assert torch.equal(o1, o2) and torch.equal(l1, l2)                 # fixed part order: deterministic
+    close(o1, o0.float().cpu(), rtol=1.6e-2, afrac=4e-3)               # split items differ in fp32 summation order only
+    assert (l1 - l0).abs().max().item() <= 2e-3
+    return dq, o1, l1, nb
+
+
+def test_attention_key_split_last_round_at_the_headline_shape():
+    """1560 workgroups on 512 slots - the 24 items beyond three full rounds are cut into 8 key ranges each whose
+    unnormalised partials add under the shift-free softmax (orv_attention_fwd_bounded_ws).  Same results as the unsplit kernel to
+    rounding, bit-reproducible, and the split heads (the last two of the last clip) against the fp32 softmax over the same bf16
+    operands."""
+    B, S, H = 4, 3226, 30
+    dq, out, lse, nb = _split_case(B, S, H, seed=11)
+    assert nb >= 24 * 8 * (256 * 64 + 256) * 4
+    t = dq.view(B, S, 3, H, 64)
+    for b, h in ((3, 29), (3, 28), (0, 0)):
+        qh, kh, vh = (t[b, :, i, h].float().cpu() for i in range(3))
+        sc = (qh @ kh.T) * math.log(2.0)
+        ref = torch.softmax(sc, dim=-1) @ vh
+        close(out.view(B, S, H, 64)[b, :, h], ref)
+        close(lse[b, h], torch.logsumexp(sc, dim=-1), rtol=2e-3, afrac=2e-3)
+
+
+def test_attention_key_split_small_shapes_in_a_subprocess():
+    """The split path at shapes a test can sweep: ORV_ATTN_SLOTS (read once per process) shrinks the slot count the plan assumes, so
+    ragged sequences, 2 ... 8 key ranges and partial last query tiles all take it."""
+    import os
+    import subprocess
+    import sys
+    shapes = {"16": [(1, 4200, 1), (1, 2200, 2), (1, 2400, 2), (2, 1111, 3)],      # 8 / 4 / 2 key ranges, not split
+              "8": [(1, 700, 3), (3, 700, 2)],                                     # 2 / 2
+              "40": [(2, 1600, 3)]}                                                # 6
+    slots = os.environ.get("ORV_ATTN_SLOTS")
+    if slots:
+        from orv_amd import ops
+        n_split = 0
+        for seed, (B, S, H) in enumerate(shapes[slots]):
+            split = ops.attention_ws_bytes(B, S, H) > 0
+            n_split += split
+            dq, out, lse, nb = _split_case(B, S, H, seed, expect_split=split)
+            t = dq.view(B, S, 3, H, 64)
+            qh, kh, vh = (t[B - 1, :, i, H - 1].float().cpu() for i in range(3))       # the last item is always a split one
+            sc = (qh @ kh.T) * math.log(2.0)
+            close(out.view(B, S, H, 64)[B - 1, :, H - 1], torch.softmax(sc, dim=-1) @ vh)
+        assert n_split >= len(shapes[slots]) - 1
+        return
+    for slots in shapes:
+        env = dict(os.environ, ORV_ATTN_SLOTS=slots)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "key_split_small", "-p", "no:cacheprovider"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (slots, r.stdout[-2000:] + r.stderr[-2000:])
 
 
 def test_attention_16x16x32_variant_matches_in_a_subprocess():
