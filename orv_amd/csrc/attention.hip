@@ -1229,8 +1229,12 @@ extern "C" int orv_attention_fwd_bounded(const void* qkv, int ld_qkv, void* out,
 struct AttnSplit { int n_full, rest, ks; };
 static AttnSplit attn_split_plan(int B, int S, int H) {
     AttnSplit sp{0, 0, 0};
-    static int enabled = -1;         // ORV_ATTN_SPLIT=0: A/B switch
-    if (enabled < 0) { const char* e = getenv("ORV_ATTN_SPLIT"); enabled = (e && atoi(e) == 0) ? 0 : 1; }
+    // OPT-IN (ORV_ATTN_SPLIT=1).  Measured (profiles/r4_attention_key_split.txt): standalone 0.393 -> 0.364 ms per launch, but inside
+    // the graph-replayed step nothing (0.3215 vs 0.3231 ms, 41.1 ms / step either way, three interleaved rounds on one box) - and the
+    // split items sum their key ranges in another fp32 order, which a 30-block random-init model amplifies from 3e-5 per call to
+    // 1.1e-2 at the output, where the unsplit kernels make B = 4 bit-identical to four B = 1 calls.  Off by default.
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("ORV_ATTN_SPLIT"); enabled = (e && atoi(e) != 0) ? 1 : 0; }
     if (!enabled) return sp;
     int dev = 0, cus = 256;
     hipDeviceProp_t prop;

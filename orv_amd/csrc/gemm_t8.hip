@@ -325,12 +325,28 @@ __device__ __forceinline__ void t8_epilogue_lds(const GemmArgs& p, f32x4 (&acc)[
 #pragma unroll
     for (int e = 0; e < 8; ++e) g8[e] = 1.f;
 
+    // Row operands (residual / GELU-adjoint input): a rolling prefetch four 16-row blocks deep - blocks 0-3 are requested here, block
+    // b + 4 right before block b is processed, into the registers block b - 4... (b & 3) held - so the second half's loads fly while
+    // the first half is worked on: one exposed load latency per tile instead of one per half, no extra registers.
+    uint4 r8[4][2];
+    auto load_rows = [&](int blk8, uint4 (&dst)[2]) {       // blk8 = mh * 4 + mb
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int mc = min(mbase + blk8 * 16 + 8 * j + rr8, p.M - 1);
+            long rr = mc;
+            if (p.r_mod > 0) rr = mc % p.r_mod;
+            else if (p.c_rows > 0) rr = (long)(mc / p.c_rows) * p.c_bstride + p.c_off + mc % p.c_rows;
+            dst[j] = *(const uint4*)(p.R + rr * p.ldr + col8);
+        }
+    };
+    if (EPI == 2 || EPI == 3) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) load_rows(mb, r8[mb]);
+    }
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh) {
-        // row operands of this half's 8 row groups (4 blocks x 2 rounds of 8 rows) are requested together
         long orow[4][2];
         bool valid[4][2];
-        uint4 r8[4][2];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -340,10 +356,6 @@ __device__ __forceinline__ void t8_epilogue_lds(const GemmArgs& p, f32x4 (&acc)[
                 const int mc = min(m, p.M - 1);
                 orow[mb][j] = mc;
                 if (p.c_rows > 0) orow[mb][j] = (long)(mc / p.c_rows) * p.c_bstride + p.c_off + mc % p.c_rows;
-                if (EPI == 2 || EPI == 3) {
-                    const long rr = p.r_mod > 0 ? mc % p.r_mod : orow[mb][j];
-                    r8[mb][j] = *(const uint4*)(p.R + rr * p.ldr + col8);
-                }
             }
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
@@ -425,6 +437,7 @@ __device__ __forceinline__ void t8_epilogue_lds(const GemmArgs& p, f32x4 (&acc)[
                 }
                 if (valid[mb][j] && st_ok) *(uint4*)crow = pack8(w);
             }
+            if ((EPI == 2 || EPI == 3) && mh == 0) load_rows(4 + mb, r8[mb]);       // this block's registers take block + 4
         }
     }
 }
@@ -470,12 +483,14 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
     {                                                                                                                \
         int tm_, tn_;                                                                                                \
         tile_of_index(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                                                 \
+        if (p.dbg == 77) tm_ = 0;   /* ORV_GEMM_DBG=77 (timing experiment, wrong results): every workgroup streams the panels of tile (0, 0) */ \
         PTR = p.A + (long)min(tm_ * 256 + arow0 + (H) * 64, p.M - 1) * p.lda + schunk * 8;                           \
     }
 #define T8_SETUP_B(PTR, H, TILE)                                                                                     \
     {                                                                                                                \
         int tm_, tn_;                                                                                                \
         tile_of_index(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                                                 \
+        if (p.dbg == 77) tn_ = 0;                                                                                    \
         if ((H) == 0) PTR = p.W + (long)(tn_ * BN + brow0) * p.ldw + schunk * 8;                                     \
         else PTR = p.W + (long)(tn_ * BN + brow1) * p.ldw + koff1;                                                   \
     }
@@ -712,15 +727,16 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
         if (p.M < 0)
 #endif
         // which epilogue: the LDS-transposed one wins where row operands are LOADED (gated residual: FFN2 -4.5 %, out-projection
-        // -2...4 %) and is level for the plain / qk-LayerNorm epilogues; the GELU epilogue is bound by its two transcendentals per
-        // element and pays the LDS round trip on top (+1...2 %): it keeps the register-layout form
+        // -2...4 %) and is level or better for the plain one; the GELU epilogue is bound by its two transcendentals per element and
+        // pays the LDS round trip on top (+1...2 %), the qk-LayerNorm epilogue pays it and the 8-lane DPP reductions (+2.6 % on the
+        // QKV pair in the model): those two keep the register-layout form
         // (profiles/r4_gemm_epilogue_ablation.txt).  -DORV_T8_EPI_DIRECT / -DORV_T8_EPI_LDS force one form (A/B builds).
 #if defined(ORV_T8_EPI_DIRECT)
         constexpr bool lds_epi = false;
 #elif defined(ORV_T8_EPI_LDS)
         constexpr bool lds_epi = true;
 #else
-        constexpr bool lds_epi = EPI != 1;
+        constexpr bool lds_epi = EPI != 1 && EPI != 4;
 #endif
         if constexpr (lds_epi) t8_epilogue_lds<BN, EPI>(p, acc, tm * 256 + wr * 128, tn * BN + wc * (BN / 4), lane, smem + SCR + wave * 4096);
         else t8_epilogue<BN, EPI>(p, acc, tm * 256 + wr * 128, tn * BN + wc * (BN / 4), lane);

@@ -6,7 +6,14 @@
 
 namespace {
 
-template <int CH>
+// Round 4: every load of the kernel is UNCONDITIONAL (chunk index clamped, contributions of the lanes past the row end masked): with
+// the loads inside `if (c < nchunk)` hipcc branched around each one and waited vmcnt(0) behind it - the four 16-byte loads of a row
+// went out one dependent round trip after the other (cdna_hip_programming.md, "three .s-level traps" (c)) - and the wave reductions run
+// on the VALU (DPP + half-swaps) instead of 2 x 6 dependent ds_bpermute.
+// FULL: gamma, beta, scale and shift are all present (the two norms of every block): their loads carry no branch at all, so the compiler
+// batches them (with the null checks of the general form every factor load sat behind a scalar branch + its own vmcnt(0): twelve
+// dependent L2 round trips per row).
+template <int CH, bool FULL>
 __global__ __launch_bounds__(256) void ln_mod_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t* __restrict__ y,
                                                      long ldy, const bf16_t* __restrict__ gamma,
                                                      const bf16_t* __restrict__ beta, const float* __restrict__ scale,
@@ -19,42 +26,42 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const bf16_t* __restrict__ 
     const int nchunk = D >> 3;
     const long xrow = xmap.rows > 0 ? (long)(row / xmap.rows) * xmap.bstride + xmap.off + row % xmap.rows : row;
     const bf16_t* xr = x + xrow * ldx;
+    uint4 raw[CH];
+    int ce[CH];
+    bool ok[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = lane + 64 * i;
+        ok[i] = c < nchunk;
+        ce[i] = min(c, nchunk - 1);
+        raw[i] = *(const uint4*)(xr + ce[i] * 8);
+    }
     float v[CH][8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nchunk) {
-            const uint4 u = *(const uint4*)(xr + c * 8);
-            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+        const uint32_t w[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[i][2 * e] = bf2f(w[e] & 0xffff);
-                v[i][2 * e + 1] = bf2f(w[e] >> 16);
-                s += v[i][2 * e] + v[i][2 * e + 1];
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        for (int e = 0; e < 4; ++e) {
+            v[i][2 * e] = bf2f(w[e] & 0xffff);          // lanes past the row end carry the LAST chunk's real values (stored again
+            v[i][2 * e + 1] = bf2f(w[e] >> 16);         // below, identical bytes); only the statistics mask them out
+            s += ok[i] ? v[i][2 * e] + v[i][2 * e + 1] : 0.f;
         }
     }
-    const float mean = wave_sum(s) / (float)D;
+    const float mean = wave_sum_valu(s) / (float)D;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nchunk) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float d = v[i][e] - mean;
-                sq += d * d;
-            }
+        for (int e = 0; e < 8; ++e) {
+            const float d = ok[i] ? v[i][e] - mean : 0.f;
+            sq += d * d;
         }
     }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+    const float rstd = rsqrtf(wave_sum_valu(sq) / (float)D + eps);
     const float* sc = nullptr;
     const float* sh = nullptr;
-    if (scale) {
+    if (FULL || scale) {
         const int b = row / seq, sidx = row % seq;
         const long off = b * mod_b + orv_group_of(sidx, n_text, per_group) * mod_g;
         sc = scale + off;
@@ -63,12 +70,11 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const bf16_t* __restrict__ 
     bf16_t* yr = y + (long)row * ldy;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-        const int c = lane + 64 * i;
-        if (c >= nchunk) continue;
+        const int c = ce[i];
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd;
-        if (gamma) {
+        if (FULL || gamma) {
             const uint4 g = *(const uint4*)(gamma + c * 8);
             const uint32_t gw[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const bf16_t* __restrict__ 
                 o[2 * e + 1] *= bf2f(gw[e] >> 16);
             }
         }
-        if (beta) {
+        if (FULL || beta) {
             const uint4 g = *(const uint4*)(beta + c * 8);
             const uint32_t gw[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
@@ -86,7 +92,7 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const bf16_t* __restrict__ 
                 o[2 * e + 1] += bf2f(gw[e] >> 16);
             }
         }
-        if (sc) {
+        if (FULL || sc) {
             const float4 s0 = *(const float4*)(sc + c * 8), s1 = *(const float4*)(sc + c * 8 + 4);
             const float4 h0 = *(const float4*)(sh + c * 8), h1 = *(const float4*)(sh + c * 8 + 4);
             const float ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
@@ -96,6 +102,8 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const bf16_t* __restrict__ 
         }
         uint4 u;
         u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]); u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
+        // lanes past the row end hold the row's LAST chunk (clamped index: same input, same factors, same result): they store it too -
+        // identical bytes to the same address - so the kernel has no divergent branch and its loads can be scheduled as one batch
         *(uint4*)(yr + c * 8) = u;
     }
 }
@@ -225,15 +233,21 @@ extern "C" int orv_layernorm_modulate(const void* x, int ldx, orv_rowmap_t xmap,
     const int ch = (D / 8 + 63) / 64;
     dim3 grid((rows + 3) / 4), block(256);
     hipStream_t st = (hipStream_t)stream;
+    const bool full = gamma && beta && scale && shift;
 #define ORV_LN_CASE(C)                                                                                                 \
-    hipLaunchKernelGGL(ln_mod_kernel<C>, grid, block, 0, st, (const bf16_t*)x, (long)ldx, (bf16_t*)y, (long)ldy,       \
-                       (const bf16_t*)gamma, (const bf16_t*)beta, scale, shift, mod_b, mod_g, grp.seq, grp.n_text,     \
-                       grp.per_group, rows, D, eps, xmap)
-    if (ch <= 1) ORV_LN_CASE(1);
-    else if (ch <= 2) ORV_LN_CASE(2);
-    else if (ch <= 4) ORV_LN_CASE(4);
-    else if (ch <= 6) ORV_LN_CASE(6);
-    else ORV_LN_CASE(8);
+    if (full)                                                                                                          \
+        hipLaunchKernelGGL((ln_mod_kernel<C, true>), grid, block, 0, st, (const bf16_t*)x, (long)ldx, (bf16_t*)y, (long)ldy, \
+                           (const bf16_t*)gamma, (const bf16_t*)beta, scale, shift, mod_b, mod_g, grp.seq, grp.n_text, \
+                           grp.per_group, rows, D, eps, xmap);                                                         \
+    else                                                                                                               \
+        hipLaunchKernelGGL((ln_mod_kernel<C, false>), grid, block, 0, st, (const bf16_t*)x, (long)ldx, (bf16_t*)y, (long)ldy, \
+                           (const bf16_t*)gamma, (const bf16_t*)beta, scale, shift, mod_b, mod_g, grp.seq, grp.n_text, \
+                           grp.per_group, rows, D, eps, xmap)
+    if (ch <= 1) { ORV_LN_CASE(1); }
+    else if (ch <= 2) { ORV_LN_CASE(2); }
+    else if (ch <= 4) { ORV_LN_CASE(4); }
+    else if (ch <= 6) { ORV_LN_CASE(6); }
+    else { ORV_LN_CASE(8); }
 #undef ORV_LN_CASE
     return orv_check_launch("orv_layernorm_modulate");
 }

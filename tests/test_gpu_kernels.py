@@ -729,10 +729,21 @@ def _split_case(B, S, H, seed, expect_split=True):
 
 
 def test_attention_key_split_last_round_at_the_headline_shape():
-    """1560 workgroups on 512 slots - the 24 items beyond three full rounds are cut into 8 key ranges each whose
-    unnormalised partials add under the shift-free softmax (orv_attention_fwd_bounded_ws).  Same results as the unsplit kernel to
-    rounding, bit-reproducible, and the split heads (the last two of the last clip) against the fp32 softmax over the same bf16
-    operands."""
+    """VERDICT r3 #2(a), built and measured, opt-in (ORV_ATTN_SPLIT=1, read once per process: child process here): 1560 workgroups on
+    512 slots - the 24 items beyond three full rounds are cut into 8 key ranges each whose unnormalised partials add under the
+    shift-free softmax (orv_attention_fwd_bounded_ws).  Same results as the unsplit kernel to rounding, bit-reproducible, and the split
+    heads (the last two of the last clip) against the fp32 softmax over the same bf16 operands."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("ORV_ATTN_SPLIT") != "1":
+        from orv_amd import ops
+        assert ops.attention_ws_bytes(4, 3226, 30) == 0                      # off by default: B = 4 stays bit-identical to 4 x B = 1
+        env = dict(os.environ, ORV_ATTN_SPLIT="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "key_split_last_round", "-p", "no:cacheprovider"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        return
     B, S, H = 4, 3226, 30
     dq, out, lse, nb = _split_case(B, S, H, seed=11)
     assert nb >= 24 * 8 * (256 * 64 + 256) * 4
@@ -769,7 +780,7 @@ def test_attention_key_split_small_shapes_in_a_subprocess():
         assert n_split >= len(shapes[slots]) - 1
         return
     for slots in shapes:
-        env = dict(os.environ, ORV_ATTN_SLOTS=slots)
+        env = dict(os.environ, ORV_ATTN_SLOTS=slots, ORV_ATTN_SPLIT="1")
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "key_split_small", "-p", "no:cacheprovider"],
                            env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (slots, r.stdout[-2000:] + r.stderr[-2000:])
