@@ -257,6 +257,16 @@ class AutoencoderKLCogVideoX(nn.Module):
             json.dump({**{k: (list(v) if isinstance(v, tuple) else v) for k, v in self.config.items()},
                        "_class_name": "AutoencoderKLCogVideoX", "_diffusers_version": "0.32.0.dev0"}, f, indent=2)
 
+    def _prepack(self, fn):
+        """Touch the packed-weight cache of every convolution ``fn`` (decode / encode of one frame batch) uses, on the current
+        stream: tiles that later run on side streams must find the packed tensors complete."""
+        net = self.decoder if fn == self._decode_batch else self.encoder
+        for m in net.modules():
+            if isinstance(m, (nn.Conv3d, nn.Conv2d)) and m.weight.ndim >= 4:
+                self._w(m)
+        if net is self.encoder:
+            self._w(self._padded_conv_in())
+
     # ---- weights in GEMM form (cached per weight version) ----
     def _w(self, conv: nn.Module):
         """[Npad, Kpad] bf16 with column = tap * Cin + ci (the patch matrix's column order) and the padded bias."""
@@ -466,10 +476,36 @@ class AutoencoderKLCogVideoX(nn.Module):
         H, W = x.shape[2], x.shape[3]
         step_h = int(tile_h * (1 - self.tile_overlap_factor_height))
         step_w = int(tile_w * (1 - self.tile_overlap_factor_width))
-        rows = []
-        for i in range(0, H, step_h):
-            rows.append([self._batched(fn, x[:, :, i:i + tile_h, j:j + tile_w].contiguous(), frame_batch).contiguous()
-                         for j in range(0, W, step_w)])
+        # The tiles are independent until the blend (own frame batching, own GroupNorm statistics, own conv caches) and small: at the
+        # reference geometry (40 x 60 latent: 30x45, 30x24, 15x45, 15x24) most of their launches fill a fraction of the 256 CUs.  Every
+        # tile therefore runs on its own HIP stream (forked behind the input, joined before the blends); same kernels on the same
+        # data, so the result is bit-identical to the serial loop (``ORV_VAE_TILE_STREAMS=0``).
+        coords = [(i, j) for i in range(0, H, step_h) for j in range(0, W, step_w)]
+        n_cols = len(range(0, W, step_w))
+        use_streams = x.is_cuda and len(coords) > 1 and os.environ.get("ORV_VAE_TILE_STREAMS", "1") != "0"
+        tiles = []
+        if use_streams:
+            self._prepack(fn)                    # weight repacking happens once, on THIS stream, before anybody forks
+            cur = torch.cuda.current_stream(x.device)
+            side = getattr(self, "_tile_streams", None)
+            if side is None or len(side) < len(coords) - 1 or side[0].device != x.device:
+                side = self._tile_streams = [torch.cuda.Stream(device=x.device) for _ in range(len(coords) - 1)]
+            fork = torch.cuda.Event()
+            fork.record(cur)
+            for k, (i, j) in enumerate(coords):
+                st = cur if k == 0 else side[k - 1]
+                if k:
+                    st.wait_event(fork)
+                with torch.cuda.stream(st):
+                    t = self._batched(fn, x[:, :, i:i + tile_h, j:j + tile_w].contiguous(), frame_batch).contiguous()
+                if k:
+                    t.record_stream(cur)         # produced on a side stream, consumed (blend / cat) and freed on this one
+                tiles.append(t)
+            for st in side[:len(coords) - 1]:
+                cur.wait_stream(st)
+        else:
+            tiles = [self._batched(fn, x[:, :, i:i + tile_h, j:j + tile_w].contiguous(), frame_batch).contiguous() for i, j in coords]
+        rows = [tiles[r * n_cols:(r + 1) * n_cols] for r in range(len(tiles) // n_cols)]
         result_rows = []
         for i, row in enumerate(rows):
             result_row = []
