@@ -606,8 +606,8 @@ def main():
                 _, M, N, K, epi = key
                 # kernel symbol as orv_gemm_bf16 dispatches it (cost-model tile choice), so it matches the rocprofv3 name
                 import ctypes
-                buf = ctypes.create_string_buffer(128)
-                check(lib().orv_gemm_kernel_name(M, N, K, epi, buf, 128), "orv_gemm_kernel_name")
+                buf = ctypes.create_string_buffer(64)
+                check(lib().orv_gemm_kernel_name(M, N, K, epi, buf, 64), "orv_gemm_kernel_name")
                 sym = buf.value.decode()
                 flop, name = 2.0 * M * N * K, f"{sym} M={M} N={N} K={K}"
             else:

@@ -157,15 +157,8 @@ typedef struct {
      * receives the raw projection.  Equivalent to epilogue 0 followed by orv_qkv_prep without RoPE, minus the V^T copy
      * (use orv_head_transpose for that). */
     const void *qn_gamma_q, *qn_beta_q, *qn_gamma_k, *qn_beta_k; float qn_eps, qn_premul; int qn_heads;
-    /* optional stream-K workspace (>= orv_gemm_ws_bytes(M, N, K, epilogue) bytes, 256-byte aligned, reusable across calls on one
-     * stream): shapes whose output tiles do not fill whole rounds of the CUs (one clip: M = 3226 is 13 row tiles, every per-block
-     * GEMM is 0.5 ... 1.5 rounds) then deal the tiles' K loops out evenly and sum the cut tiles in a fixed order (deterministic).
-     * NULL / too small: whole tiles per workgroup, as before. */
-    void* ws; size_t ws_bytes;
 } orv_gemm_t;
 int orv_gemm_bf16(const orv_gemm_t* g, void* stream);
-/* Workspace bytes orv_gemm_bf16 can use for this shape (0: the shape runs whole tiles and needs none). */
-size_t orv_gemm_ws_bytes(int M, int N, int K, int epilogue);
 /* Kernel symbol (as rocprofv3 prints it, e.g. "gemm_pp_kernel<192, 5, 1>") that orv_gemm_bf16 launches for this shape on this
  * device: the tile is chosen by a cost model over all candidates, so callers that label timings ask. */
 int orv_gemm_kernel_name(int M, int N, int K, int epilogue, char* buf, int len);

@@ -27,7 +27,7 @@ class Gemm(Structure):
                 ("R", c_void_p), ("ldr", c_int), ("r_mod", c_int), ("gate", c_void_p), ("gate_b", c_long),
                 ("gate_g", c_long), ("grp", Groups), ("cmap", RowMap), ("Y", c_void_p), ("ldy", c_int),
                 ("qn_gamma_q", c_void_p), ("qn_beta_q", c_void_p), ("qn_gamma_k", c_void_p), ("qn_beta_k", c_void_p),
-                ("qn_eps", c_float), ("qn_premul", c_float), ("qn_heads", c_int), ("ws", c_void_p), ("ws_bytes", ctypes.c_size_t)]
+                ("qn_eps", c_float), ("qn_premul", c_float), ("qn_heads", c_int)]
 
 
 class Conv(Structure):
@@ -61,7 +61,6 @@ SIGNATURES = {
     "orv_gemm_kernel_name": (c_int, [c_int, c_int, c_int, c_int, ctypes.c_char_p, c_int]),
     "orv_gemm_force_tile": (c_int, [c_int, c_int, c_int]),
     "orv_gemm_bf16": (c_int, [POINTER(Gemm), c_void_p]),
-    "orv_gemm_ws_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
     "orv_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                   c_float, c_void_p]),
     "orv_attention_fwd_bounded": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p]),

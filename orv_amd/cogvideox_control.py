@@ -525,14 +525,9 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             # attention workspace: partial results of the key-split last round (orv_attention_fwd_bounded_ws); None when the shape's
             # grid has no small last round (B = 1, B = 2, the 5B widths)
             nb = ops.attention_ws_bytes(B, S, H)
-            # stream-K workspace of the block GEMMs (one stream: one buffer serves them all); 0 when every shape fills whole rounds
-            F4 = self.transformer_blocks[0].ff.net[0].proj.weight.shape[0] if len(self.transformer_blocks) else 4 * D
-            ng = max(ops.gemm_ws_bytes(M, 3 * D, D, 4), ops.gemm_ws_bytes(M, D, D, 2), ops.gemm_ws_bytes(M, F4, D, 1),
-                     ops.gemm_ws_bytes(M, D, F4, 2))
             self._ws = {key: dict(x=e(M, D), xn=e(M, D), qkv=e(M, 3 * D), att=e(M, D), h=e(M, 4 * D), vis=e(B * Nv, D),
                                   vis2=e(B * Nv, D), s_pad=s_pad,
-                                  attn_ws=torch.empty(nb, dtype=torch.uint8, device=dev) if nb else None,
-                                  gemm_ws=torch.empty(ng, dtype=torch.uint8, device=dev) if ng else None)}
+                                  attn_ws=torch.empty(nb, dtype=torch.uint8, device=dev) if nb else None)}
         return self._ws[key]
 
     def _view_pos_table(self, pos, n_view, T, P, dev):
@@ -623,7 +618,7 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         return self._mv_ptr_tables[1:]
 
     @staticmethod
-    def _qkv_projection(at, xn, qkv, rope, B, S, heads, n_text, s_pad, scale, raw=None, gemm_ws=None):
+    def _qkv_projection(at, xn, qkv, rope, B, S, heads, n_text, s_pad, scale, raw=None):
         """to_q / to_k / to_v + norm_q / norm_k (+ RoPE) (:232-254): q', k', v into ``qkv``; the attention kernel reads all three
         in place (V through transposing LDS reads: no V^T copy).  Without RoPE the qk LayerNorm and the softmax pre-multiplier
         (scale * log2 e, one rounding) ride in the GEMM epilogue; with RoPE the projection is followed by ``orv_qkv_prep``.
@@ -634,7 +629,7 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         nq, nk = at.norm_q, at.norm_k
         if rope is None and _FUSE_QKNORM:
             ops.gemm(xn, wqkv, bqkv, qkv, M, 3 * D, D, epilogue=4, Y=raw,
-                     qknorm=(nq.weight, nq.bias, nk.weight, nk.bias, at.eps, scale * LOG2E, heads), ws=gemm_ws)
+                     qknorm=(nq.weight, nq.bias, nk.weight, nk.bias, at.eps, scale * LOG2E, heads))
         else:
             dst = qkv if raw is None else raw
             ops.gemm(xn, wqkv, bqkv, dst, M, 3 * D, D)
@@ -790,7 +785,6 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         mb, mg = G * 3 * D, 3 * D
         scale = 1.0 / math.sqrt(c.attention_head_dim)
         prime_score_bounds([b.attn1 for b in self.transformer_blocks] + ([b.attn1 for b in self.mv_blocks] if mv is not None else []), scale)
-        gws = ws["gemm_ws"]
         for i, blk in enumerate(self.transformer_blocks):
             if mv is not None:
                 self._mv_block(self.mv_blocks[i], mv, mv_mod[i], x, xn, grp0, B, S, Nt, num_views, T, rope_view)
@@ -798,16 +792,16 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             at = blk.attn1
             ops.layernorm_modulate(x, xn, blk.norm1.norm.weight, blk.norm1.norm.bias, m1[..., D:2 * D], m1[..., :D],
                                    mb, mg, grp, B, D, c.norm_eps)
-            self._qkv_projection(at, xn, qkv, rope, B, S, heads, Nt, s_pad, scale, gemm_ws=gws)
+            self._qkv_projection(at, xn, qkv, rope, B, S, heads, Nt, s_pad, scale)
             ops.attention_fwd(qkv, None, att, B, S, heads, s_pad, 1.0 / LOG2E, score_bound=at.score_bound(scale), ws=ws["attn_ws"])
             ops.gemm(att, at.to_out[0].weight, at.to_out[0].bias, x, M, D, D, epilogue=2, R=x, ldr=D,
-                     gate=m1[..., 2 * D:], gate_b=mb, gate_g=mg, grp=grp, ws=gws)
+                     gate=m1[..., 2 * D:], gate_b=mb, gate_g=mg, grp=grp)
             ops.layernorm_modulate(x, xn, blk.norm2.norm.weight, blk.norm2.norm.bias, m2[..., D:2 * D], m2[..., :D],
                                    mb, mg, grp, B, D, c.norm_eps)
             f0, f2 = blk.ff.net[0].proj, blk.ff.net[2]
-            ops.gemm(xn, f0.weight, f0.bias, hbuf, M, f0.weight.shape[0], D, epilogue=1, ws=gws)
+            ops.gemm(xn, f0.weight, f0.bias, hbuf, M, f0.weight.shape[0], D, epilogue=1)
             ops.gemm(hbuf, f2.weight, f2.bias, x, M, D, f0.weight.shape[0], epilogue=2, R=x, ldr=D,
-                     gate=m2[..., 2 * D:], gate_b=mb, gate_g=mg, grp=grp, ws=gws)
+                     gate=m2[..., 2 * D:], gate_b=mb, gate_g=mg, grp=grp)
 
         # 6. head: norm_final is row-wise, so the 2B (:916) and 5B (:911-913) branches are the same arithmetic on the
         #    video rows; read them in place from the joint buffer.

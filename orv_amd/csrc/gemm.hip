@@ -1275,8 +1275,7 @@ extern "C" int orv_gemm_force_tile(int ring, int bm, int bn) {
 // and the cheapest wins.  The rates are measured on MI355X at M = 12904 (tools/tile_sweep.sh rates); the rounds term is
 // what matters at small batch, where a "better" tile that needs one more, nearly empty, round loses to a smaller one that
 // fills the chip (B = 1: N = 1920 GEMMs take 195 tiles of 256x128 instead of 260 of 128x192).
-// `sk` (out, may be NULL): the winning candidate is priced in stream-K form (only offered when `allow_sk`: the caller has a workspace)
-static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int heads = 0, bool allow_sk = false, bool* sk = nullptr) {
+static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int heads = 0) {
     static const GemmCand cands[] = {
         // ring = 3: the 16x16x32 8-phase kernel of gemm_t8.hip (persistent, BK = 64; needs an even number of K-tiles)
         {3, 256, 256, 1.29f, 0}, {3, 256, 192, 1.21f, 0},
@@ -1303,17 +1302,9 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
     if (no_t8 < 0) { const char* e = getenv("ORV_GEMM_T8"); no_t8 = (e && atoi(e) == 0) ? 1 : 0; }
     static int no384 = -1;   // ORV_GEMM_BN384=0: A/B switch for the 384-wide variant
     if (no384 < 0) { const char* e = getenv("ORV_GEMM_BN384"); no384 = (e && atoi(e) == 0) ? 1 : 0; }
-    int ncu = orv_num_cus();
-    {   // ORV_T8_GRID (experiments, and the tests' way to reach the stream-K seams at small shapes): plan as if the chip had this many CUs
-        static int gcap = -1;
-        if (gcap < 0) { const char* e = getenv("ORV_T8_GRID"); gcap = e ? atoi(e) : 0; }
-        if (gcap > 0 && gcap < ncu) ncu = gcap;
-    }
+    const int ncu = orv_num_cus();
     const GemmCand* best = nullptr;
     double best_cost = 0;
-    bool best_sk = false;
-    static int sk_env = -1;      // ORV_GEMM_SK=0: A/B switch for the stream-K form
-    if (sk_env < 0) { const char* e = getenv("ORV_GEMM_SK"); sk_env = (e && atoi(e) == 0) ? 0 : 1; }
     for (const GemmCand& c : cands) {
         if (N % c.bn) continue;
         if (c.ring == 2 && (K % 128 != 0 || no_phased)) continue;
@@ -1332,19 +1323,10 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
         // (fewer active CUs clock higher): 0.62 (= 1.5 GHz / 2.4 GHz) + 0.38 x the fraction of CUs it occupies.
         // Rows of the last M tile that do not exist still cost their MFMAs (tiles are counted whole).
         const long full = tiles / ncu, rem = tiles % ncu;
-        double rounds = (double)full + (rem ? 0.62 + 0.38 * (double)rem / ncu : 0.0);
-        // stream-K form of the t8 kernel: every CU gets tiles / ncu tiles' worth of K-tile pairs; the cut tiles cost a slab round trip
-        // and a second epilogue, priced at 7 K-tiles.  Only where whole tiles waste >= 8 % of a round and a workgroup still gets >= 4 pairs.
-        bool use_sk = false;
-        if (c.ring == 3 && allow_sk && sk_env && orv_gemm::t8_has_sk(c.bn, epilogue) && rem != 0) {
-            const int nk = K / BK;
-            const double r_sk = (double)tiles / ncu + 7.0 / nk;
-            if (r_sk < 0.92 * rounds && tiles * (long)(nk / 2) >= 4L * ncu && tiles * (long)(nk / 2) < (1L << 30)) { rounds = r_sk; use_sk = true; }
-        }
+        const double rounds = (double)full + (rem ? 0.62 + 0.38 * (double)rem / ncu : 0.0);
         const double cost = rounds * c.bm * c.bn / c.rate;
-        if (!best || cost < best_cost) { best = &c; best_cost = cost; best_sk = use_sk; }
+        if (!best || cost < best_cost) { best = &c; best_cost = cost; }
     }
-    if (sk) *sk = best_sk;
     return best;
 }
 
@@ -1353,41 +1335,20 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
 // (N = 2 H 64 = 3840 = 15 x 256, epilogue 4) and v (N = H 64 = 1920, plain bias epilogue into the same packed buffer) whenever the
 // cost model puts the q | k part on the t8 kernel: 0.247 vs 0.286 ms per layer at B = 4 (profiles/r3_gemm_t8_ab.txt).  The A
 // operand is read by both launches (L2 / Infinity Cache).  ORV_GEMM_QKV_SPLIT=0: A/B switch.
-static bool plan_gemm(int M, int N, int K, int epilogue, int heads, const GemmCand*& first, const GemmCand*& second,
-                      bool allow_sk = false, bool* sk_first = nullptr, bool* sk_second = nullptr) {
+static bool plan_gemm(int M, int N, int K, int epilogue, int heads, const GemmCand*& first, const GemmCand*& second) {
     static int qkv_split = -1;
     if (qkv_split < 0) { const char* e = getenv("ORV_GEMM_QKV_SPLIT"); qkv_split = (e && atoi(e) == 0) ? 0 : 1; }
     second = nullptr;
-    bool s1 = false, s2 = false;
-    first = choose_tile(M, N, K, epilogue, heads, allow_sk, &s1);
+    first = choose_tile(M, N, K, epilogue, heads);
     if (epilogue == 4 && qkv_split && heads > 0 && N == 3 * heads * 64 && !(first && first->ring == 3)) {
-        bool sq = false, sv = false;
-        const GemmCand* qk = choose_tile(M, 2 * heads * 64, K, 4, heads, allow_sk, &sq);
-        const GemmCand* vv = choose_tile(M, heads * 64, K, 0, 0, allow_sk, &sv);
-        if (qk && qk->ring == 3 && vv) { first = qk; second = vv; s1 = sq; s2 = sv; }
+        const GemmCand* qk = choose_tile(M, 2 * heads * 64, K, 4, heads);
+        const GemmCand* vv = choose_tile(M, heads * 64, K, 0, 0);
+        if (qk && qk->ring == 3 && vv) { first = qk; second = vv; }
     }
-    if (sk_first) *sk_first = s1;
-    if (sk_second) *sk_second = s2;
     return first != nullptr;
 }
-// stream-K workspace of one candidate launch (0 when it is not a stream-K launch)
-static size_t cand_ws_bytes(const GemmCand* c, bool sk, int M, int N) {
-    if (!c || !sk) return 0;
-    return orv_gemm::t8_sk_ws_bytes(((M + c->bm - 1) / c->bm) * (N / c->bn), c->bn, orv_num_cus());      // (a capped grid needs less)
-}
-extern "C" size_t orv_gemm_ws_bytes(int M, int N, int K, int epilogue) {
-    if (M <= 0 || N <= 0 || K <= 0 || N % 64 || K % 64) return 0;
-    const GemmCand *c = nullptr, *c2 = nullptr;
-    bool s1 = false, s2 = false;
-    const int heads = epilogue == 4 ? N / 192 : 0;
-    if (!plan_gemm(M, N, K, epilogue, heads, c, c2, true, &s1, &s2)) return 0;
-    if (!c2) return cand_ws_bytes(c, s1, M, N);
-    // split q | k + v launch: the two launches run one after the other on the stream and share the workspace
-    const size_t a = cand_ws_bytes(c, s1, M, 2 * heads * 64), b = cand_ws_bytes(c2, s2, M, heads * 64);
-    return a > b ? a : b;
-}
-static void cand_name(const GemmCand* c, int epilogue, char* buf, int len, bool sk = false) {
-    if (c->ring == 3) snprintf(buf, len, sk ? "gemm_t8_kernel<%d, %d, true>" : "gemm_t8_kernel<%d, %d, false>", c->bn, epilogue);
+static void cand_name(const GemmCand* c, int epilogue, char* buf, int len) {
+    if (c->ring == 3) snprintf(buf, len, "gemm_t8_kernel<%d, %d>", c->bn, epilogue);
     else if (c->ring == 2) snprintf(buf, len, "gemm_ph_kernel<%d, %d>", c->bn, epilogue);
     else if (c->ring) snprintf(buf, len, "gemm_pp_kernel<%d, %d, %d>", c->bn, c->bn == 384 ? 4 : 5, epilogue);
     else if (c->bm == 192) snprintf(buf, len, "gemm_kernel<%d, %d, %d, 2, 2>", c->bm, c->bn, epilogue);
@@ -1398,26 +1359,19 @@ static void cand_name(const GemmCand* c, int epilogue, char* buf, int len, bool 
 extern "C" int orv_gemm_kernel_name(int M, int N, int K, int epilogue, char* buf, int len) {
     ORV_REQUIRE(buf && len > 0 && M > 0 && N > 0 && N % 64 == 0, "orv_gemm_kernel_name: bad arguments");
     const GemmCand *c = nullptr, *c2 = nullptr;
-    bool s1 = false, s2 = false;          // as the model calls it: with a stream-K workspace
-    ORV_REQUIRE(plan_gemm(M, N, K, epilogue, epilogue == 4 ? N / 192 : 0, c, c2, true, &s1, &s2), "orv_gemm_kernel_name: no tile configuration for N=%d", N);
-    cand_name(c, epilogue, buf, len, s1);
+    ORV_REQUIRE(plan_gemm(M, N, K, epilogue, epilogue == 4 ? N / 192 : 0, c, c2), "orv_gemm_kernel_name: no tile configuration for N=%d", N);
+    cand_name(c, epilogue, buf, len);
     if (c2) {                     // split q | k + v launch: both symbols
         const int n = (int)strlen(buf);
-        if (n + 4 < len) { snprintf(buf + n, len - n, " + "); cand_name(c2, 0, buf + n + 3, len - n - 3, s2); }
+        if (n + 4 < len) { snprintf(buf + n, len - n, " + "); cand_name(c2, 0, buf + n + 3, len - n - 3); }
     }
     return ORV_OK;
 }
 
 // launch the chosen candidate
-static int gemm_dispatch(GemmArgs a, const GemmCand* best, int epilogue, hipStream_t st, bool sk = false, void* ws = nullptr) {
+static int gemm_dispatch(GemmArgs a, const GemmCand* best, int epilogue, hipStream_t st) {
     a.tiles_n = a.N / best->bn;
     a.tiles_m = (a.M + best->bm - 1) / best->bm;
-    a.sk = 0; a.sk_cnt = nullptr; a.sk_slabs = nullptr;
-    if (sk && ws && best->ring == 3) {
-        a.sk = 1;
-        a.sk_cnt = (unsigned*)ws;
-        a.sk_slabs = (float*)((char*)ws + (size_t)((a.tiles_m * a.tiles_n * 4 + 255) / 256 * 256));
-    }
     {
         static int gm_env = -1;
         if (gm_env < 0) { const char* e = getenv("ORV_GEMM_GM"); gm_env = e ? atoi(e) : 0; }
@@ -1493,33 +1447,19 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
     }
     hipStream_t st = (hipStream_t)stream;
     const GemmCand *first = nullptr, *second = nullptr;
-    // stream-K needs the caller's workspace (and plain output rows: the row-remapped / table-residual forms keep whole tiles)
-    const bool allow_sk = g->ws && ((uintptr_t)g->ws & 255) == 0 && g->cmap.rows == 0 && g->r_mod == 0 && !g->Y;
-    bool sk1 = false, sk2 = false;
-    ORV_REQUIRE(plan_gemm(g->M, g->N, g->K, g->epilogue, g->qn_heads, first, second, allow_sk, &sk1, &sk2),
+    ORV_REQUIRE(plan_gemm(g->M, g->N, g->K, g->epilogue, g->qn_heads, first, second),
                 "orv_gemm_bf16: no tile configuration for N=%d (ORV_GEMM_TILE override?)", g->N);
-    if (!second) {
-        if (sk1 && g->ws_bytes < cand_ws_bytes(first, true, g->M, g->N)) sk1 = false;
-        if (sk1) return gemm_dispatch(a, first, g->epilogue, st, true, g->ws);
-        if (allow_sk) {        // the plan assumed stream-K but the workspace is too small: plan again without it
-            ORV_REQUIRE(plan_gemm(g->M, g->N, g->K, g->epilogue, g->qn_heads, first, second), "orv_gemm_bf16: no tile configuration for N=%d", g->N);
-            if (second) goto split_launch;
-        }
-        return gemm_dispatch(a, first, g->epilogue, st);
-    }
-split_launch:
+    if (!second) return gemm_dispatch(a, first, g->epilogue, st);
     const int nqk = 2 * g->qn_heads * 64;
     GemmArgs q = a;
     q.N = nqk;
-    if (sk1 && g->ws_bytes < cand_ws_bytes(first, true, g->M, nqk)) sk1 = false;
-    if (sk2 && g->ws_bytes < cand_ws_bytes(second, true, g->M, g->N - nqk)) sk2 = false;
-    const int rc = gemm_dispatch(q, first, 4, st, sk1, g->ws);
+    const int rc = gemm_dispatch(q, first, 4, st);
     if (rc != ORV_OK) return rc;
     GemmArgs v = a;
     v.N = g->N - nqk; v.W = a.W + (long)nqk * a.ldw; v.C = a.C + nqk;
     if (a.bias) v.bias = a.bias + nqk;
     if (a.Y) v.Y = a.Y + nqk;
-    return gemm_dispatch(v, second, 0, st, sk2, g->ws);
+    return gemm_dispatch(v, second, 0, st);
 }
 
 // Implicit-GEMM convolution entry point: g->A is ignored (the A operand is gathered from c->src), g->M = B*T*H*W, g->K = taps * C.

@@ -41,10 +41,6 @@ struct GemmArgs {
     // tile g * stagger_ticks (10 ns each) late, so the epilogue store bursts of the groups do not coincide.  0 / 1 groups: off.
     int stagger_groups, stagger_ticks;
     int grid_cap;   // > 0: at most this many persistent workgroups (experiment knob, ORV_T8_GRID)
-    // stream-K mode of gemm_t8_kernel (sk != 0): the (tile, K-tile pair) units are dealt out evenly, tiles cut between workgroups meet in
-    // the workspace: sk_cnt[tile] arrival tickets (zeroed by the launch function), sk_slabs two fp32 accumulator slabs per workgroup
-    int sk;
-    unsigned* sk_cnt; float* sk_slabs;
     int gm;   // super-tile height in tiles (0: GM).  8 for the long-K, narrow GEMM (FFN2: 10 column tiles, 120 K-tiles): in the model
               // 0.3252 -> 0.3178 ms; every other per-block shape is best at or indifferent to 4 (sweep 1 / 2 / 3 / 4 / 6 / 8 / 13 in
               // profiles/r3_gemm_walk_back.txt).  ORV_GEMM_GM overrides.
@@ -68,23 +64,9 @@ __device__ __forceinline__ void tile_of_index(const GemmArgs& p, int b, int nb, 
     tn = rem / gsize;
 }
 __device__ __forceinline__ void tile_of_block(const GemmArgs& p, int& tm, int& tn) { tile_of_index(p, blockIdx.x, gridDim.x, tm, tn); }
-// the same list addressed by its LINEAR position (stream-K: a workgroup owns a contiguous range of it)
-__device__ __forceinline__ void tile_of_linear(const GemmArgs& p, int L, int nb, int& tm, int& tn) {
-    if (p.walk_back) L = nb - 1 - L;
-    const int gm = p.gm > 0 ? p.gm : GM;
-    const int per = gm * p.tiles_n;
-    const int gid = L / per, rem = L % per;
-    const int first_m = gid * gm;
-    const int gsize = min(p.tiles_m - first_m, gm);
-    tm = first_m + rem % gsize;
-    tn = rem / gsize;
-}
 
 
 // gemm_t8.hip: launches gemm_t8_kernel<BN, EPI> (BN = 256 or 192); a.tiles_m / a.tiles_n must be set for BM = 256, BN
 int launch_t8(const GemmArgs& a, int bn, int epi, hipStream_t st);
-bool t8_has_sk(int bn, int epi);          // is there a stream-K instantiation for this tile width / epilogue
-// stream-K workspace of a t8 launch with `tiles` output tiles of 256 x bn on `grid` workgroups: tickets + 2 slabs per workgroup
-inline size_t t8_sk_ws_bytes(int tiles, int bn, int grid) { return (size_t)((tiles * 4 + 255) / 256 * 256) + (size_t)grid * 2 * 256 * bn * 4; }
 
 }  // namespace orv_gemm

@@ -442,13 +442,7 @@ __device__ __forceinline__ void t8_epilogue_lds(const GemmArgs& p, f32x4 (&acc)[
     }
 }
 
-// SK (stream-K, round 4: the single-clip shapes, where M = 3226 is 13 row tiles and every per-block GEMM is 0.5 ... 1.5 rounds of
-// tiles): the output tiles' K loops are laid end to end - unit = one pair of K-tiles - and every workgroup takes an equal contiguous
-// share of the units, so a workgroup's range starts and ends in the middle of tiles.  A tile cut between workgroups meets in the
-// workspace: every contributor writes its fp32 accumulators (write-through stores) and draws a ticket; whoever draws the last one sums
-// the slabs in PART ORDER (its own included: the result does not depend on who arrives last) and runs the epilogue.  Hand-off as in
-// attention.hip's key split (cdna_hip_programming.md Guideline 16, R1 counter form; tickets zeroed by a memset node per launch).
-template <int BN, int EPI, bool SK = false>
+template <int BN, int EPI>
 __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
     constexpr int NBW = BN / 64;                      // 16-column blocks per wave
     constexpr int HALF = 16384;                       // A0 | A1 | B region 0 | B region 1
@@ -482,34 +476,20 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
     char* const dst2 = smem + wave * 2048;            // two-instruction streams: + S * BUF + region * HALF (+ 1024 for k half 1)
     char* const dst1 = smem + 3 * HALF + wave * 1024; // BN = 192 region 1: + S * BUF
 
-    // stream-K: this workgroup's unit range [u0, u1) in the XCD-contiguous workgroup order (neighbouring ranges share an L2)
-    const int nkp = nk >> 1;                          // units (K-tile pairs) per tile
-    int u0 = 0, u1 = 0;                               // (host: ntiles * nkp < 2^31)
-    if constexpr (SK) {
-        const long U = (long)ntiles * nkp;
-        const int w_ = orv_xcd_item(blockIdx.x, gridDim.x);
-        u0 = (int)(w_ * U / gridDim.x); u1 = (int)((w_ + 1) * U / gridDim.x);
-    }
-    const int tile_step = SK ? 1 : (int)gridDim.x;
-    const int tile_first = SK ? (int)(u0 / nkp) : (int)blockIdx.x;
-    const int k_first = SK ? 2 * (int)(u0 % nkp) : 0;             // first K-tile of the first tile
-
     const bf16_t *pA0, *pA1, *pB0, *pB1;
-    int kA0 = k_first, kA1 = k_first, kB0 = k_first, kB1 = k_first;
-    int tA0 = tile_first, tA1 = tile_first, tB0 = tile_first, tB1 = tile_first;
+    int kA0 = 0, kA1 = 0, kB0 = 0, kB1 = 0;
+    int tA0 = blockIdx.x, tA1 = blockIdx.x, tB0 = blockIdx.x, tB1 = blockIdx.x;
 #define T8_SETUP_A(PTR, H, TILE)                                                                                     \
     {                                                                                                                \
         int tm_, tn_;                                                                                                \
-        if constexpr (SK) tile_of_linear(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                              \
-        else tile_of_index(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                                            \
+        tile_of_index(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                                                 \
         if (p.dbg == 77) tm_ = 0;   /* ORV_GEMM_DBG=77 (timing experiment, wrong results): every workgroup streams the panels of tile (0, 0) */ \
         PTR = p.A + (long)min(tm_ * 256 + arow0 + (H) * 64, p.M - 1) * p.lda + schunk * 8;                           \
     }
 #define T8_SETUP_B(PTR, H, TILE)                                                                                     \
     {                                                                                                                \
         int tm_, tn_;                                                                                                \
-        if constexpr (SK) tile_of_linear(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                              \
-        else tile_of_index(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                                            \
+        tile_of_index(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                                                 \
         if (p.dbg == 77) tn_ = 0;                                                                                    \
         if ((H) == 0) PTR = p.W + (long)(tn_ * BN + brow0) * p.ldw + schunk * 8;                                     \
         else PTR = p.W + (long)(tn_ * BN + brow1) * p.ldw + koff1;                                                   \
@@ -518,10 +498,10 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
     // final tile again - uniform instruction counts, data never read)
 #define T8_NEXT_A(PTR, KC, TC, H)                                                                                    \
     PTR += BK;                                                                                                       \
-    if (__builtin_expect(++KC == nk, 0)) { KC = 0; TC += tile_step; T8_SETUP_A(PTR, H, TC) }
+    if (__builtin_expect(++KC == nk, 0)) { KC = 0; TC += gridDim.x; T8_SETUP_A(PTR, H, TC) }
 #define T8_NEXT_B(PTR, KC, TC, H)                                                                                    \
     PTR += BK;                                                                                                       \
-    if (__builtin_expect(++KC == nk, 0)) { KC = 0; TC += tile_step; T8_SETUP_B(PTR, H, TC) }
+    if (__builtin_expect(++KC == nk, 0)) { KC = 0; TC += gridDim.x; T8_SETUP_B(PTR, H, TC) }
 #define T8_ISSUE_A0(S) { glds16(pA0, dst2 + (S) * BUF); glds16(pA0 + 32, dst2 + (S) * BUF + 1024); T8_NEXT_A(pA0, kA0, tA0, 0) }
 #define T8_ISSUE_A1(S) { glds16(pA1, dst2 + (S) * BUF + HALF); glds16(pA1 + 32, dst2 + (S) * BUF + HALF + 1024); T8_NEXT_A(pA1, kA1, tA1, 1) }
 #define T8_ISSUE_B0(S) { glds16(pB0, dst2 + (S) * BUF + 2 * HALF); glds16(pB0 + 32, dst2 + (S) * BUF + 2 * HALF + 1024); T8_NEXT_B(pB0, kB0, tB0, 0) }
@@ -535,7 +515,6 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
     T8_SETUP_A(pA1, 1, tA1)
     T8_SETUP_B(pB0, 0, tB0)
     T8_SETUP_B(pB1, 1, tB1)
-    if constexpr (SK) { pA0 += k_first * BK; pA1 += k_first * BK; pB0 += k_first * BK; pB1 += k_first * BK; }
 
     // ---- fragment reads: logical byte (l & 15) * 64 + (l >> 4) * 16 of a subtile, bit 5 flipped for rows 8-15
     const int fro = ((lane & 15) * 64 + (lane >> 4) * 16) ^ (((lane >> 3) & 1) << 5);
@@ -723,14 +702,10 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
 #else
 #define T8_STAMP(SLOT)
 #endif
-    // SK: segments (tile, pairs [pa, pb)) of this workgroup's unit range; otherwise whole tiles blockIdx, blockIdx + grid, ...
-    int u_ = u0;
-    for (int tile = tile_first; SK ? u_ < u1 : tile < ntiles; tile += tile_step) {
-        const int pa = SK ? u_ % nkp : 0;
-        const int pb = SK ? min(nkp, pa + (u1 - u_)) : nkp;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         if (wr == 1) { T8_BAR() }             // the second half of the workgroup runs one barrier behind ...
         T8_STAMP(0)
-        for (int kt = 2 * pa; kt < 2 * pb; kt += 2) {
+        for (int kt = 0; kt < nk; kt += 2) {
 #ifdef ORV_T8_SCHED2
             if constexpr (BN == 256) { T8_KTILE2_256(0) T8_KTILE2_256(1) }
             else { T8_KTILE2_192(0) T8_KTILE2_192(1) }
@@ -747,74 +722,10 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
         if (wr == 0) { T8_BAR() }             // ... and both halves run their epilogues side by side
         T8_STAMP(4)
         int tm, tn;
-        if constexpr (SK) tile_of_linear(p, tile, ntiles, tm, tn);
-        else tile_of_index(p, tile, ntiles, tm, tn);
-        bool run_epilogue = true;
-        if constexpr (SK) {
-            u_ += pb - pa;
-            if (pa != 0 || pb != nkp) {
-                // a part of a tile: slab (workgroup, s), s = 0 for a part that does not start the tile, 1 for one that does
-                typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-                constexpr int SLAB = 256 * BN * 4, WSLAB = SLAB / 8;                       // bytes per slab / per wave
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.sk_slabs, 0, 0x7fffffff, 0x00020000);
-                const int G_ = gridDim.x, w_ = orv_xcd_item(blockIdx.x, G_);
-                const long U = (long)ntiles * nkp, t_lo = (long)tile * nkp, t_hi = t_lo + nkp;
-                const int lane_b = wave * WSLAB + lane * 16;
-                {
-                    const int base = (2 * w_ + (pa == 0 ? 1 : 0)) * SLAB + lane_b;
-#pragma unroll
-                    for (int a = 0; a < 2; ++a)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b)
-#pragma unroll
-                            for (int c = 0; c < NBW; ++c) {
-                                u32x4_t v;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(acc[a][b][c][e]);
-                                __builtin_amdgcn_raw_buffer_store_b128(v, rs, base + ((a * 4 + b) * NBW + c) * 1024, 0, 16);
-                            }
-                }
-                // contributors of this tile: the workgroups whose ranges meet [t_lo, t_hi); first = the one holding unit t_lo
-                int wf = (int)(t_lo * G_ / U);
-                while (wf > 0 && (long)wf * U / G_ > t_lo) --wf;
-                while ((long)(wf + 1) * U / G_ <= t_lo) ++wf;
-                int wl = wf;
-                while ((long)(wl + 1) * U / G_ < t_hi) ++wl;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                unsigned* const flag = (unsigned*)(smem + SCR);                             // epilogue scratch: free here
-                if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(p.sk_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __syncthreads();
-                run_epilogue = *flag == (unsigned)(wl - wf);
-                __syncthreads();                                                            // the scratch is reused by the epilogue
-                if (run_epilogue) {
-#pragma unroll
-                    for (int a = 0; a < 2; ++a)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b)
-#pragma unroll
-                            for (int c = 0; c < NBW; ++c) acc[a][b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    for (int wq = wf; wq <= wl; ++wq) {                                     // fixed order: ascending position in the K loop
-                        const long q0 = (long)wq * U / G_;
-                        const int base = (2 * wq + (q0 <= t_lo ? 1 : 0)) * SLAB + lane_b;   // starts the tile <=> its range begins at or before t_lo
-#pragma unroll
-                        for (int a = 0; a < 2; ++a)
-#pragma unroll
-                            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                                for (int c = 0; c < NBW; ++c) {
-                                    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, base + ((a * 4 + b) * NBW + c) * 1024, 0, 16);
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) acc[a][b][c][e] += __uint_as_float(v[e]);
-                                }
-                    }
-                }
-            }
-        }
+        tile_of_index(p, tile, ntiles, tm, tn);
 #ifdef ORV_T8_ABL_NOEPI      // ablation build: no epilogue at all (the accumulators stay live through the never-taken call)
-        run_epilogue = run_epilogue && p.M < 0;
+        if (p.M < 0)
 #endif
-        if (run_epilogue) {
         // which epilogue: the LDS-transposed one wins where row operands are LOADED (gated residual: FFN2 -4.5 %, out-projection
         // -2...4 %) and is level or better for the plain one; the GELU epilogue is bound by its two transcendentals per element and
         // pays the LDS round trip on top (+1...2 %), the qk-LayerNorm epilogue pays it and the 8-lane DPP reductions (+2.6 % on the
@@ -829,7 +740,6 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
 #endif
         if constexpr (lds_epi) t8_epilogue_lds<BN, EPI>(p, acc, tm * 256 + wr * 128, tn * BN + wc * (BN / 4), lane, smem + SCR + wave * 4096);
         else t8_epilogue<BN, EPI>(p, acc, tm * 256 + wr * 128, tn * BN + wc * (BN / 4), lane);
-        }
         T8_STAMP(5)
 #ifdef ORV_T8_TRACE
 #if ORV_T8_TRACE == 2
@@ -848,28 +758,17 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int BN, int EPI, bool SK = false>
+template <int BN, int EPI>
 int launch_one(const GemmArgs& a, hipStream_t st) {
     constexpr int smem = 2 * (BN == 256 ? 65536 : 57344) + 8 * 4096;      // two K-tile buffers + the epilogue scratch (160 KiB at BN = 256)
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_t8_kernel<BN, EPI, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)gemm_t8_kernel<BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
     int grid = min(a.tiles_m * a.tiles_n, orv_num_cus());
     if (a.grid_cap > 0) grid = min(grid, a.grid_cap);
-    if constexpr (SK) {
-        // every workgroup gets units: the grid is the whole chip (never more units than workgroups would leave one idle: K >= 128)
-        grid = orv_num_cus();
-        if (a.grid_cap > 0) grid = min(grid, a.grid_cap);
-        const long units = (long)a.tiles_m * a.tiles_n * (a.K / BK / 2);
-        if (units < grid) grid = (int)units;
-        if (hipMemsetAsync(a.sk_cnt, 0, (size_t)a.tiles_m * a.tiles_n * 4, st) != hipSuccess) {
-            orv_set_error("orv_gemm_bf16: hipMemsetAsync of the stream-K tickets failed");
-            return ORV_EDEVICE;
-        }
-    }
-    hipLaunchKernelGGL((gemm_t8_kernel<BN, EPI, SK>), dim3(grid), dim3(512), smem, st, a);
+    hipLaunchKernelGGL((gemm_t8_kernel<BN, EPI>), dim3(grid), dim3(512), smem, st, a);
     return orv_check_launch("orv_gemm_bf16");
 }
 
@@ -877,22 +776,6 @@ int launch_one(const GemmArgs& a, hipStream_t st) {
 
 namespace orv_gemm {
 int launch_t8(const GemmArgs& a, int bn, int epi, hipStream_t st) {
-    if (a.sk) {       // stream-K: the epilogues the single-clip forward uses
-        if (bn == 256) {
-            switch (epi) {
-                case 0: return launch_one<256, 0, true>(a, st);
-                case 1: return launch_one<256, 1, true>(a, st);
-                case 4: return launch_one<256, 4, true>(a, st);
-            }
-        } else if (bn == 192) {
-            switch (epi) {
-                case 0: return launch_one<192, 0, true>(a, st);
-                case 2: return launch_one<192, 2, true>(a, st);
-            }
-        }
-        orv_set_error("orv_gemm_bf16: no stream-K t8 kernel for BN=%d epilogue %d", bn, epi);
-        return ORV_EINVAL;
-    }
     if (bn == 256) {
         switch (epi) {
             case 0: return launch_one<256, 0>(a, st);
@@ -912,5 +795,4 @@ int launch_t8(const GemmArgs& a, int bn, int epi, hipStream_t st) {
     orv_set_error("orv_gemm_bf16: no t8 kernel for BN=%d epilogue %d", bn, epi);
     return ORV_EINVAL;
 }
-bool t8_has_sk(int bn, int epi) { return (bn == 256 && (epi == 0 || epi == 1 || epi == 4)) || (bn == 192 && (epi == 0 || epi == 2)); }
 }  // namespace orv_gemm

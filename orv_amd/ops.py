@@ -169,22 +169,12 @@ def qkv_prep(qkv, vT, gq, bq, gk, bk, rope: Optional[Tuple[torch.Tensor, torch.T
                                   _p(sin), B, S, H, n_text, s_pad, float(eps), float(q_premul), _stream()), "orv_qkv_prep")
 
 
-def gemm_ws_bytes(M, N, K, epilogue=0):
-    """Stream-K workspace bytes ``gemm(..., ws=)`` can use for this shape (0: the shape runs whole tiles per workgroup)."""
-    return int(lib().orv_gemm_ws_bytes(int(M), int(N), int(K), int(epilogue)))
-
-
 def gemm(A, W, bias, C, M, N, K, epilogue=0, R=None, r_mod=0, gate=None, gate_b=0, gate_g=0, grp: Optional[Groups] = None,
-         cmap: Optional[RowMap] = None, lda=None, ldw=None, ldc=None, ldr=None, Y=None, ldy=None, qknorm=None, ws=None):
+         cmap: Optional[RowMap] = None, lda=None, ldw=None, ldc=None, ldr=None, Y=None, ldy=None, qknorm=None):
     """``qknorm`` = (gamma_q, beta_q, gamma_k, beta_k, eps, q_premul, heads) with ``epilogue=4``: the QKV projection with the
-    per-head qk LayerNorm fused (no RoPE).  ``ws``: uint8 workspace (``gemm_ws_bytes``) for the stream-K form of shapes that do not
-    fill whole rounds of the CUs; one workspace may serve every GEMM of ONE stream."""
+    per-head qk LayerNorm fused (no RoPE)."""
     _need(A, BF16, "A"), _need(W, BF16, "W"), _need(C, BF16, "C")
     g = Gemm()
-    if ws is not None:
-        if ws.dtype != torch.uint8 or not ws.is_cuda:
-            raise ValueError("gemm: ws must be a uint8 CUDA tensor")
-        g.ws, g.ws_bytes = _p(ws), ws.numel()
     if qknorm is not None:
         gq, bq, gk, bk, eps, premul, heads = qknorm
         g.qn_gamma_q, g.qn_beta_q, g.qn_gamma_k, g.qn_beta_k = _p(gq), _p(bq), _p(gk), _p(bk)

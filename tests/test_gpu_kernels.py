@@ -633,75 +633,6 @@ def test_attention_bound_too_large_takes_the_online_kernel():
     close(out, torch.einsum("bhqk,bhkd->bhqd", pr, t[2]).transpose(1, 2).reshape(B * S, H * 64))
 
 
-def _streamk_case(M, N, K, epi, seed):
-    """orv_gemm_bf16 with and without the stream-K workspace on one shape: both against the fp64 reference, and against each other."""
-    from orv_amd import ops
-    dev = _dev()
-    g = torch.Generator().manual_seed(seed)
-    A, W = q(torch.randn(M, K, generator=g)), q(torch.randn(N, K, generator=g) * 0.05)
-    bias, R = q(torch.randn(N, generator=g) * 0.5), q(torch.randn(M, N, generator=g))
-    acc = A.double() @ W.double().T + bias.double()
-    kw = {}
-    if epi == 1:
-        ref = torch.nn.functional.gelu(acc.float(), approximate="tanh")
-    elif epi == 2:
-        seq, nt, pg = M, min(226, M // 4), max(1, (M - min(226, M // 4)) // 5)
-        G = 1 + (seq - nt + pg - 1) // pg
-        gate = torch.randn(1, G, N, generator=g)
-        grp = torch.where(torch.arange(M) < nt, 0, 1 + (torch.arange(M) - nt) // pg)
-        ref = R.double() + gate[0, grp].double() * acc
-        kw = dict(R=R.to(dev, BF), gate=gate.to(dev), gate_b=G * N, gate_g=N, grp=ops.groups(seq, nt, pg))
-    else:
-        ref = acc
-    nb = ops.gemm_ws_bytes(M, N, K, epi)
-    outs = []
-    for ws in (None, torch.empty(max(nb, 256), dtype=torch.uint8, device=dev) if nb else None):
-        C = torch.full((M, N), float("nan"), dtype=BF, device=dev)
-        ops.gemm(A.to(dev, BF), W.to(dev, BF), bias.to(dev, BF), C, M, N, K, epilogue=epi, ws=ws, **kw)
-        if ws is not None:
-            C2 = torch.full((M, N), float("nan"), dtype=BF, device=dev)
-            ops.gemm(A.to(dev, BF), W.to(dev, BF), bias.to(dev, BF), C2, M, N, K, epilogue=epi, ws=ws, **kw)
-            assert torch.equal(C, C2)                        # fixed summation order: bit-reproducible
-        close(C, ref)
-        outs.append(C)
-    return nb, outs
-
-
-def test_gemm_stream_k_single_clip_shapes():
-    """Round 4: one clip (M = 3226: 13 row tiles) leaves every per-block GEMM at 0.5 ... 1.5 rounds of tiles; with a
-    workspace the t8 kernel deals the tiles' K loops out evenly (stream-K) and sums cut tiles in part order.  The four block shapes
-    of CogVideoX-2B at B = 1: the plan takes the stream-K form, results match the fp64 reference and the whole-tile kernels to
-    rounding, and are bit-reproducible."""
-    for (M, N, K, epi), seed in (((3226, 1920, 7680, 2), 1), ((3226, 7680, 1920, 1), 2), ((3226, 1920, 1920, 2), 3), ((3226, 1920, 1920, 0), 4)):
-        nb, (c_tiles, c_sk) = _streamk_case(M, N, K, epi, seed)
-        assert nb > 0, (M, N, K, epi)
-        d = (c_sk.float() - c_tiles.float()).abs()
-        assert (d <= 1.6e-2 * c_tiles.float().abs() + 1e-2).all()
-    from orv_amd import ops
-    assert ops.gemm_ws_bytes(12904, 7680, 1920, 1) == 0 and ops.gemm_ws_bytes(12904, 1920, 7680, 2) == 0     # B = 4 fills whole rounds
-
-
-def test_gemm_stream_k_seams_at_small_shapes_in_a_subprocess():
-    """The seams of the stream-K walk (a workgroup's range inside one tile, parts of three workgroups in one tile, ragged last row
-    tile) at shapes a test can sweep: ORV_T8_GRID (read once per process) makes the plan and the launch use 6 / 10 workgroups."""
-    import os
-    import subprocess
-    import sys
-    if os.environ.get("ORV_T8_GRID"):
-        n_sk = 0
-        for (M, N, K, epi), seed in (((700, 768, 1024, 0), 1), ((1000, 1920, 2048, 2), 2), ((300, 512, 4096, 1), 3), ((520, 768, 768, 2), 4),
-                                     ((2100, 384, 1280, 0), 5)):
-            nb, _ = _streamk_case(M, N, K, epi, seed)
-            n_sk += nb > 0
-        assert n_sk >= 3, n_sk
-        return
-    for grid in ("6", "10"):
-        env = dict(os.environ, ORV_T8_GRID=grid)
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "stream_k_seams", "-p", "no:cacheprovider"],
-                           env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, (grid, r.stdout[-2500:] + r.stderr[-1500:])
-
-
 def _gamma_case(gq_val, gk_val, seed=5, B=2, S=520, H=3):
     from orv_amd import ops
     from orv_amd.cogvideox_control import Attention
