@@ -23,6 +23,11 @@
 
 namespace {
 using namespace orv_gemm;
+#ifdef ORV_T8_SCHED3
+constexpr bool T8_SCHED3_ON = true;
+#else
+constexpr bool T8_SCHED3_ON = false;
+#endif
 
 __device__ __forceinline__ float sum_xor16(float v) {      // v(lane) + v(lane ^ 16)
     const unsigned u = __float_as_uint(v);
@@ -502,13 +507,18 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
 #define T8_NEXT_B(PTR, KC, TC, H)                                                                                    \
     PTR += BK;                                                                                                       \
     if (__builtin_expect(++KC == nk, 0)) { KC = 0; TC += gridDim.x; T8_SETUP_B(PTR, H, TC) }
-#define T8_ISSUE_A0(S) { glds16(pA0, dst2 + (S) * BUF); glds16(pA0 + 32, dst2 + (S) * BUF + 1024); T8_NEXT_A(pA0, kA0, tA0, 0) }
-#define T8_ISSUE_A1(S) { glds16(pA1, dst2 + (S) * BUF + HALF); glds16(pA1 + 32, dst2 + (S) * BUF + HALF + 1024); T8_NEXT_A(pA1, kA1, tA1, 1) }
-#define T8_ISSUE_B0(S) { glds16(pB0, dst2 + (S) * BUF + 2 * HALF); glds16(pB0 + 32, dst2 + (S) * BUF + 2 * HALF + 1024); T8_NEXT_B(pB0, kB0, tB0, 0) }
+#ifdef ORV_T8_ABL_NODMA      // ablation builds (tools/t8_loop_abl.sh, wrong results): what does the K loop cost without its LDS-DMA / without its fragment reads?
+#define T8_GLDS(SRC, DST) asm volatile("" :: "v"(SRC), "s"(DST))
+#else
+#define T8_GLDS(SRC, DST) glds16(SRC, DST)
+#endif
+#define T8_ISSUE_A0(S) { T8_GLDS(pA0, dst2 + (S) * BUF); T8_GLDS(pA0 + 32, dst2 + (S) * BUF + 1024); T8_NEXT_A(pA0, kA0, tA0, 0) }
+#define T8_ISSUE_A1(S) { T8_GLDS(pA1, dst2 + (S) * BUF + HALF); T8_GLDS(pA1 + 32, dst2 + (S) * BUF + HALF + 1024); T8_NEXT_A(pA1, kA1, tA1, 1) }
+#define T8_ISSUE_B0(S) { T8_GLDS(pB0, dst2 + (S) * BUF + 2 * HALF); T8_GLDS(pB0 + 32, dst2 + (S) * BUF + 2 * HALF + 1024); T8_NEXT_B(pB0, kB0, tB0, 0) }
 #define T8_ISSUE_B1(S)                                                                                               \
     {                                                                                                                \
-        if constexpr (BN == 256) { glds16(pB1, dst2 + (S) * BUF + 3 * HALF); glds16(pB1 + 32, dst2 + (S) * BUF + 3 * HALF + 1024); } \
-        else { glds16(pB1, dst1 + (S) * BUF); }                                                                      \
+        if constexpr (BN == 256) { T8_GLDS(pB1, dst2 + (S) * BUF + 3 * HALF); T8_GLDS(pB1 + 32, dst2 + (S) * BUF + 3 * HALF + 1024); } \
+        else { T8_GLDS(pB1, dst1 + (S) * BUF); }                                                                     \
         T8_NEXT_B(pB1, kB1, tB1, 1)                                                                                  \
     }
     T8_SETUP_A(pA0, 0, tA0)
@@ -531,7 +541,11 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
             for (int c = 0; c < NBW; ++c) acc[a][b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 fa[2][4][2], fb[NBW][2];
 
-#ifdef ORV_T8_ABL_NOA1
+#ifdef ORV_T8_ABL_NOREAD
+#define T8_READ_A(MH, S)                                                                                             \
+    _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                                 \
+        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) asm volatile("" : "+v"(fa[MH][mb][kh]));
+#elif defined(ORV_T8_ABL_NOA1)
 #define T8_READ_A(MH, S)                                                                                             \
     _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                                 \
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
@@ -542,11 +556,21 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
             fa[MH][mb][kh] = *(const bf16x8*)(rdA + (S) * BUF + (MH) * HALF + mb * 2048 + kh * 1024);
 #endif
+#ifdef ORV_T8_ABL_NOREAD
+#define T8_READ_B01(S)                                                                                               \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                    \
+        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) asm volatile("" : "+v"(fb[t][kh]));
+#else
 #define T8_READ_B01(S)                                                                                               \
     _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                    \
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
             fb[t][kh] = *(const bf16x8*)(rdB + (S) * BUF + t * 2048 + kh * 1024);
-#ifdef ORV_T8_ABL_NOB23      // ablation builds (tools/t8_lds_abl.sh, wrong results): how much do the fragment reads cost?
+#endif
+#if defined(ORV_T8_ABL_NOREAD)
+#define T8_READ_B23(S)                                                                                               \
+    _Pragma("unroll") for (int t = 0; t < NBW - 2; ++t)                                                              \
+        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) asm volatile("" : "+v"(fb[2 + t][kh]));
+#elif defined(ORV_T8_ABL_NOB23)      // ablation builds (tools/t8_lds_abl.sh, wrong results): how much do the fragment reads cost?
 #define T8_READ_B23(S)                                                                                               \
     _Pragma("unroll") for (int t = 0; t < NBW - 2; ++t)                                                              \
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
@@ -558,11 +582,18 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
             fb[2 + t][kh] = *(const bf16x8*)(rdB1 + (S) * BUF + t * 2048 + kh * 1024);
 #endif
     // (m half MH) x (blocks B0 .. B0 + NBK - 1), both k halves
+#ifdef ORV_T8_ABL_NOMFMA
+#define T8_MFMA(MH, B0, NBK)                                                                                         \
+    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                                 \
+        _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                             \
+            _Pragma("unroll") for (int t = 0; t < (NBK); ++t) asm volatile("" : "+v"(acc[MH][mb][(B0) + t]) : "v"(fb[(B0) + t][kh]), "v"(fa[MH][mb][kh]));
+#else
 #define T8_MFMA(MH, B0, NBK)                                                                                         \
     _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                                 \
         _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                             \
             _Pragma("unroll") for (int t = 0; t < (NBK); ++t)                                                        \
                 acc[MH][mb][(B0) + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[(B0) + t][kh], fa[MH][mb][kh], acc[MH][mb][(B0) + t], 0, 0, 0);
+#endif
 #define T8_BAR()                                                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
     __builtin_amdgcn_s_barrier();                                                                                    \
@@ -667,11 +698,77 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
         T8_BAR() T8_PRIO1() T8_MFMA(1, 0, 3) T8_PRIO0() T8_BAR()                                                     \
     }
 
+    // ---- SCHED3 (-DORV_T8_SCHED3, BN = 256; tools/t8_sched3_ab.sh): the four phases with BALANCED load segments.  Ablation of the shipped loop
+    // (profiles/r4_gemm_loop_ablation.txt): MFMAs + barriers alone 0.518 ms, LDS-DMA + fragment reads + barriers alone 0.544 ms, together 0.777 ms
+    // (8192^3) - the two sides are equal and overlap badly, because the fragment reads are 12 / 8 / 4 / 0 per phase: P1's load segment (12 reads + 2
+    // DMA instructions = 320 LDS cycles) outlasts its partner's 256 MFMA cycles while P4's (128) idles.  Here B01 (dead after P2) and the first block
+    // of A1 (dead after P3) of the NEXT K-tile are read in P4: reads 8 / 6 / 4 / 6, DMA 2 / 2 / 2 / 2 (B0, A0, A1, B1 of K-tile + 2: every stream two
+    // K-tiles ahead), all four load segments <= 256 LDS cycles.  Fragment reads are retired BEFORE a phase's first barrier, so a region is restaged
+    // one interval after its last reader; one vmcnt(6) per K-tile in P3 (retires K-tile + 1 completely: P4 reads it).  The tile's first K-tile
+    // reads B01 / A1 head itself in P1 (T8C_KTILE_FIRST) and issues its P1 DMA in P2 (the second half reads B01 one interval later).
+#define T8_READ_A1_HEAD(S)                                                                                           \
+    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                                 \
+        fa[1][0][kh] = *(const bf16x8*)(rdA + (S) * BUF + HALF + kh * 1024);
+#define T8_READ_A1_REST(S)                                                                                           \
+    _Pragma("unroll") for (int mb = 1; mb < 4; ++mb)                                                                 \
+        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
+            fa[1][mb][kh] = *(const bf16x8*)(rdA + (S) * BUF + HALF + mb * 2048 + kh * 1024);
+#define T8C_PRE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#define T8C_TAIL(S)                                                                                                  \
+        T8_READ_B23(S)                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        T8_ISSUE_A1(S)                                                                                               \
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                             \
+        T8C_PRE()                                                                                                    \
+        T8_BAR() T8_PRIO1() T8_MFMA(1, 2, 2) T8_PRIO0() T8_BAR()                                                     \
+        T8_READ_B01((S) ^ 1)                                                                                         \
+        T8_READ_A1_HEAD((S) ^ 1)                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        T8_ISSUE_B1(S)                                                                                               \
+        T8C_PRE()                                                                                                    \
+        T8_BAR() T8_PRIO1() T8_MFMA(0, 2, 2) T8_PRIO0() T8_BAR()
+#define T8C_KTILE(S)                                                                                                 \
+    {                                                                                                                \
+        T8_READ_A(0, S)                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        T8_ISSUE_B0(S)                                                                                               \
+        T8C_PRE()                                                                                                    \
+        T8_BAR() T8_PRIO1() T8_MFMA(0, 0, 2) T8_PRIO0() T8_BAR()                                                     \
+        T8_READ_A1_REST(S)                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        T8_ISSUE_A0(S)                                                                                               \
+        T8C_PRE()                                                                                                    \
+        T8_BAR() T8_PRIO1() T8_MFMA(1, 0, 2) T8_PRIO0() T8_BAR()                                                     \
+        T8C_TAIL(S)                                                                                                  \
+    }
+#define T8C_KTILE_FIRST(S)                                                                                           \
+    {                                                                                                                \
+        T8_READ_B01(S)                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        T8_READ_A(0, S)                                                                                              \
+        T8_READ_A1_HEAD(S)                                                                                           \
+        T8C_PRE()                                                                                                    \
+        T8_BAR() T8_PRIO1() T8_MFMA(0, 0, 2) T8_PRIO0() T8_BAR()                                                     \
+        T8_READ_A1_REST(S)                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        T8_ISSUE_B0(S)                                                                                               \
+        T8_ISSUE_A0(S)                                                                                               \
+        T8C_PRE()                                                                                                    \
+        T8_BAR() T8_PRIO1() T8_MFMA(1, 0, 2) T8_PRIO0() T8_BAR()                                                     \
+        T8C_TAIL(S)                                                                                                  \
+    }
+
     // prologue: K-tile 0 complete into buffer 0, then the pieces of K-tile 1 the steady state would have issued by now
     if constexpr (BN == 256) {
+#ifdef ORV_T8_SCHED3
+        T8_ISSUE_A0(0) T8_ISSUE_B0(0) T8_ISSUE_A1(0) T8_ISSUE_B1(0)
+        T8_ISSUE_B0(1) T8_ISSUE_A0(1) T8_ISSUE_A1(1) T8_ISSUE_B1(1)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#else
         T8_ISSUE_A0(0) T8_ISSUE_B0(0) T8_ISSUE_A1(0) T8_ISSUE_B1(0)
         T8_ISSUE_B0(1) T8_ISSUE_A0(1) T8_ISSUE_A1(1)
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#endif
     } else {
 #ifdef ORV_T8_SCHED2
         T8_ISSUE_A0(0) T8_ISSUE_B0(0) T8_ISSUE_A1(0) T8_ISSUE_B1(0)
@@ -705,8 +802,14 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         if (wr == 1) { T8_BAR() }             // the second half of the workgroup runs one barrier behind ...
         T8_STAMP(0)
-        for (int kt = 0; kt < nk; kt += 2) {
-#ifdef ORV_T8_SCHED2
+#ifdef ORV_T8_SCHED3
+        if constexpr (BN == 256) { T8C_KTILE_FIRST(0) T8C_KTILE(1) }
+#endif
+        for (int kt = (BN == 256 && T8_SCHED3_ON) ? 2 : 0; kt < nk; kt += 2) {
+#ifdef ORV_T8_SCHED3
+            if constexpr (BN == 256) { T8C_KTILE(0) T8C_KTILE(1) }
+            else { T8_KTILE_192(0) T8_KTILE_192(1) }
+#elif defined(ORV_T8_SCHED2)
             if constexpr (BN == 256) { T8_KTILE2_256(0) T8_KTILE2_256(1) }
             else { T8_KTILE2_192(0) T8_KTILE2_192(1) }
 #else
