@@ -40,14 +40,35 @@ def _q(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
+def _canonical_header(path):
+    """safetensors keeps ``__metadata__`` in a hash map: its entries come out in a per-process random order, which made regenerated
+    fixtures differ bytewise although every tensor and every metadata value was identical.  Rewrite the header with
+    the metadata entries sorted (same bytes, same length: nothing else moves)."""
+    import struct
+    with open(path, "r+b") as f:
+        n = struct.unpack("<Q", f.read(8))[0]
+        raw = f.read(n)
+        hdr = json.loads(raw)
+        if "__metadata__" in hdr:
+            hdr["__metadata__"] = dict(sorted(hdr["__metadata__"].items()))
+        out = json.dumps(hdr, separators=(",", ":"), ensure_ascii=False).encode()
+        assert len(out) <= n, (len(out), n)
+        f.seek(8)
+        f.write(out + b" " * (n - len(out)))
+
+
 def _save(name, cfg, tensors, extra=None):
-    meta = {"config": json.dumps(cfg), "extra": json.dumps(extra or {})}
-    tensors = {k: v.detach().contiguous().clone() for k, v in tensors.items() if v is not None}
+    meta = {"config": json.dumps(cfg, sort_keys=True), "extra": json.dumps(extra or {}, sort_keys=True)}
+    # keys in sorted order, so that a regeneration is byte-identical (VERDICT r3 #9: tensors and metadata were, 9 of 19 files differed in
+    # serialisation order only)
+    tensors = {k: v.detach().contiguous().clone() for k, v in sorted(tensors.items()) if v is not None}
     for k, v in tensors.items():
         if (k.startswith("w.") or k.startswith("in.")) and v.dtype == torch.float32 and "rope" not in k:
             assert torch.equal(v, _q(v)), k
             tensors[k] = v.to(torch.bfloat16)
-    save_file(tensors, os.path.join(OUT, name + ".safetensors"), metadata=meta)
+    path = os.path.join(OUT, name + ".safetensors")
+    save_file(tensors, path, metadata=meta)
+    _canonical_header(path)
     print(f"{name}: {sum(v.numel() * v.element_size() for v in tensors.values()) / 1e6:.2f} MB")
 
 

@@ -288,6 +288,17 @@ def main():
             "parity": "second derivation by the same author: removes transcription errors, NOT pinned against diffusers"}
     path = os.path.join(ROOT, "tests", "golden", "vae_tiny_naive.safetensors")
     save_file({k: np.ascontiguousarray(v) for k, v in sorted(out.items())}, path, metadata=meta)
+    # the metadata entries come out of safetensors' hash map in a per-process order: sort them in place (same bytes, same length) so that
+    # a regeneration is byte-identical
+    import struct
+    with open(path, "r+b") as f:
+        n = struct.unpack("<Q", f.read(8))[0]
+        hdr = json.loads(f.read(n))
+        hdr["__metadata__"] = dict(sorted(hdr["__metadata__"].items()))
+        raw = json.dumps(hdr, separators=(",", ":"), ensure_ascii=False).encode()
+        assert len(raw) <= n
+        f.seek(8)
+        f.write(raw + b" " * (n - len(raw)))
     for k, v in out.items():
         print(k, v.shape, float(np.abs(v).max()))
     print("wrote", path, os.path.getsize(path), "bytes")
