@@ -13,8 +13,11 @@ namespace {
 // FULL: gamma, beta, scale and shift are all present (the two norms of every block): their loads carry no branch at all, so the compiler
 // batches them (with the null checks of the general form every factor load sat behind a scalar branch + its own vmcnt(0): twelve
 // dependent L2 round trips per row).
+#ifndef ORV_LN_WAVES          // minimum waves per SIMD the register allocation must leave room for (A/B builds: tools/variants.sh)
+#define ORV_LN_WAVES 1
+#endif
 template <int CH, bool FULL>
-__global__ __launch_bounds__(256) void ln_mod_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t* __restrict__ y,
+__global__ __launch_bounds__(256, ORV_LN_WAVES) void ln_mod_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t* __restrict__ y,
                                                      long ldy, const bf16_t* __restrict__ gamma,
                                                      const bf16_t* __restrict__ beta, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, long mod_b, long mod_g, int seq,

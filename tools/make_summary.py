@@ -2,7 +2,7 @@
 (HIP events / rocprofv3 stats), achieved TFLOP/s where the bench knows the FLOPs, and the PMC figures of the same command
 (effective clock, MFMA-busy fraction, fabric bytes per launch and TB/s).  usage: python tools/make_summary.py [round, default 3] > profiles/r3_summary.txt"""
 import json, os, re, sys
-RN = sys.argv[1] if len(sys.argv) > 1 else "3"
+RN = sys.argv[1] if len(sys.argv) > 1 else "4"
 R = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 def last_json(path):
     for line in reversed(open(path).read().strip().splitlines()):
