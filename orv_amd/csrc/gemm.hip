@@ -1275,7 +1275,8 @@ extern "C" int orv_gemm_force_tile(int ring, int bm, int bn) {
 // and the cheapest wins.  The rates are measured on MI355X at M = 12904 (tools/tile_sweep.sh rates); the rounds term is
 // what matters at small batch, where a "better" tile that needs one more, nearly empty, round loses to a smaller one that
 // fills the chip (B = 1: N = 1920 GEMMs take 195 tiles of 256x128 instead of 260 of 128x192).
-static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int heads = 0) {
+// wide: an operand spans 4 GiB or more - the t8 kernel addresses A and W with 32-bit byte offsets and is skipped
+static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int heads = 0, bool wide = false) {
     static const GemmCand cands[] = {
         // ring = 3: the 16x16x32 8-phase kernel of gemm_t8.hip (persistent, BK = 64; needs an even number of K-tiles)
         {3, 256, 256, 1.29f, 0}, {3, 256, 192, 1.21f, 0},
@@ -1308,7 +1309,7 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
     for (const GemmCand& c : cands) {
         if (N % c.bn) continue;
         if (c.ring == 2 && (K % 128 != 0 || no_phased)) continue;
-        if (c.ring == 3 && (K % 128 != 0 || no_t8 || (epilogue == 4 && c.bn != 256))) continue;
+        if (c.ring == 3 && (K % 128 != 0 || no_t8 || wide || (epilogue == 4 && c.bn != 256))) continue;
         // epilogue 4 normalises whole 64-wide heads inside a wave (BN / 2 columns) that must not straddle q | k | v
         if (epilogue == 4 && (c.bm == 192 || (c.bn / 2) % 64 != 0 || (heads * 64) % (c.bn / 2) != 0)) continue;
         if (force_bm && (c.ring != force_ring || c.bm != force_bm || c.bn != force_bn)) continue;
@@ -1335,14 +1336,14 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
 // (N = 2 H 64 = 3840 = 15 x 256, epilogue 4) and v (N = H 64 = 1920, plain bias epilogue into the same packed buffer) whenever the
 // cost model puts the q | k part on the t8 kernel: 0.247 vs 0.286 ms per layer at B = 4 (profiles/r3_gemm_t8_ab.txt).  The A
 // operand is read by both launches (L2 / Infinity Cache).  ORV_GEMM_QKV_SPLIT=0: A/B switch.
-static bool plan_gemm(int M, int N, int K, int epilogue, int heads, const GemmCand*& first, const GemmCand*& second) {
+static bool plan_gemm(int M, int N, int K, int epilogue, int heads, const GemmCand*& first, const GemmCand*& second, bool wide = false) {
     static int qkv_split = -1;
     if (qkv_split < 0) { const char* e = getenv("ORV_GEMM_QKV_SPLIT"); qkv_split = (e && atoi(e) == 0) ? 0 : 1; }
     second = nullptr;
-    first = choose_tile(M, N, K, epilogue, heads);
+    first = choose_tile(M, N, K, epilogue, heads, wide);
     if (epilogue == 4 && qkv_split && heads > 0 && N == 3 * heads * 64 && !(first && first->ring == 3)) {
-        const GemmCand* qk = choose_tile(M, 2 * heads * 64, K, 4, heads);
-        const GemmCand* vv = choose_tile(M, heads * 64, K, 0, 0);
+        const GemmCand* qk = choose_tile(M, 2 * heads * 64, K, 4, heads, wide);
+        const GemmCand* vv = choose_tile(M, heads * 64, K, 0, 0, wide);
         if (qk && qk->ring == 3 && vv) { first = qk; second = vv; }
     }
     return first != nullptr;
@@ -1447,7 +1448,8 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
     }
     hipStream_t st = (hipStream_t)stream;
     const GemmCand *first = nullptr, *second = nullptr;
-    ORV_REQUIRE(plan_gemm(g->M, g->N, g->K, g->epilogue, g->qn_heads, first, second),
+    const bool wide = (long)g->M * g->lda * 2 >= (1L << 32) || (long)g->N * g->ldw * 2 >= (1L << 32);
+    ORV_REQUIRE(plan_gemm(g->M, g->N, g->K, g->epilogue, g->qn_heads, first, second, wide),
                 "orv_gemm_bf16: no tile configuration for N=%d (ORV_GEMM_TILE override?)", g->N);
     if (!second) return gemm_dispatch(a, first, g->epilogue, st);
     const int nqk = 2 * g->qn_heads * 64;

@@ -460,77 +460,110 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
     const int ntiles = p.tiles_m * p.tiles_n;
     const int nk = p.K / BK;                          // even (chooser-checked)
 
-    // ---- DMA side.  One wave instruction fills one 1-KiB subtile; lane l writes physical bytes [16 l, 16 l + 16), which hold logical
-    // byte 16 (l ^ ((l >> 5) << 1)) of the subtile: row (of 16) = that >> 2, 16-byte k-chunk (of 4) = that & 3.
-    const int lsw = lane ^ ((lane >> 5) << 1);
-    const int srow = lsw >> 2, schunk = lsw & 3;
-    const int q = wave * 16 + srow;                   // row of a 128-row half-tile this lane feeds (k halves 0 / 1: two instructions)
+    // ---- DMA side.  One wave instruction fills one 1-KiB piece of LDS; the image is lane-linear (lane l writes physical bytes [16 l, 16 l + 16)),
+    // so WHICH 16 global bytes a lane fetches decides the layout.  Two layouts, chosen per instantiation (FL):
+    //   st_16x32 (the template's): a piece = 16 rows x 32 k; lane l holds logical byte 16 (l ^ ((l >> 5) << 1)): row = that >> 2, 16-byte k-chunk
+    //     = that & 3; the two k halves of a 16-row block are two instructions 64 B apart in memory.
+    //   full-line (round 4): a piece = 8 rows x 64 k = 8 whole 128-byte lines (lanes 8 r .. 8 r + 7 fetch row r), so the texture path handles 8
+    //     full lines per instruction instead of 16 half lines: the LDS-DMA stream ALONE is 13-18 % faster (profiles/r4_gemm_t8_load_side.txt).
+    //     Lane l holds physical chunk l & 7 of row r = l >> 3 and fetches logical chunk (l & 7) ^ (r & 6); with that XOR the 16 lanes of every
+    //     ds_read_b128 group (row i of a 16-row block = piece i >> 3, row i & 7; k chunk (4 kh + g) ^ (i & 6)) cover the 16 bank slots once.  A
+    //     block's two pieces are two instructions 8 rows apart.  In the model (same box, interleaved): FFN1 0.3008 -> 0.2958 ms, FFN2 0.3030 ->
+    //     0.2970, out-projection level, q | k | v 0.2326 -> 0.2350 - hence per epilogue: GELU and gated-residual instantiations only.
+    // Both: every instruction has its own 32-bit per-lane byte offset (row clamp to M - 1 included, recomputed per output tile) against a
+    // wave-uniform base that carries the K position (global_load_lds saddr form: no vector address arithmetic in the K loop).  Needs
+    // M * lda * 2 and N * ldw * 2 < 4 GiB (the chooser checks).
+#if defined(ORV_T8_FULLLINE_ALL)
+    constexpr bool FL = true;
+#elif defined(ORV_T8_FULLLINE_NONE)
+    constexpr bool FL = false;
+#else
+    constexpr bool FL = EPI == 1 || EPI == 2;
+#endif
+    const int lsw = FL ? lane : lane ^ ((lane >> 5) << 1);
+    const int srow = FL ? lane >> 3 : lsw >> 2;
+    const int schunk = FL ? (lane & 7) ^ (srow & 6) : lsw & 3;
+    const int q = wave * 16 + srow;                   // row of a 128-row half-tile this lane feeds with its first instruction (FL: second = + 8)
     const int arow0 = (q >> 6) * 128 + (q & 63);      // + h * 64: tile row held by row q of A half h
     int brow0, brow1;                                 // tile column held by row q of B region 0 / by this lane's row of region 1
     {
         const int wc_ = q >> 5, nb_ = (q >> 4) & 1, r = q & 15;
         if (BN == 256) {
-            brow0 = wc_ * 64 + 8 * (r >> 2) + 4 * nb_ + (r & 3);      // + h * 32
+            brow0 = wc_ * 64 + 8 * (r >> 2) + 4 * nb_ + (r & 3);      // FL second instruction (r + 8): + 16
             brow1 = brow0 + 32;
         } else {
             brow0 = wc_ * 48 + 8 * (r >> 2) + 4 * nb_ + (r & 3);
-            brow1 = (wave >> 1) * 48 + 32 + srow;                     // region 1: 64 rows, wave w fills subtile (row block w >> 1, k half w & 1)
+            // region 1: 64 rows.  st_16x32: wave w fills (row block w >> 1, k half w & 1); FL: rows 8 (w & 1) .. + 7 of block w >> 1
+            brow1 = (wave >> 1) * 48 + 32 + (FL ? (wave & 1) * 8 : 0) + srow;
         }
     }
-    const int koff1 = BN == 256 ? schunk * 8 : (wave & 1) * 32 + schunk * 8;
-    char* const dst2 = smem + wave * 2048;            // two-instruction streams: + S * BUF + region * HALF (+ 1024 for k half 1)
+    const int koff1 = (BN == 256 || FL) ? schunk * 8 : (wave & 1) * 32 + schunk * 8;
+    char* const dst2 = smem + wave * 2048;            // two-instruction streams: + S * BUF + region * HALF (+ 1024: second instruction)
     char* const dst1 = smem + 3 * HALF + wave * 1024; // BN = 192 region 1: + S * BUF
-
-    const bf16_t *pA0, *pA1, *pB0, *pB1;
+    unsigned oA0[2], oA1[2], oB0[2], oB1[2];          // byte offsets from p.A / p.W of the two instructions of a stream
     int kA0 = 0, kA1 = 0, kB0 = 0, kB1 = 0;
     int tA0 = blockIdx.x, tA1 = blockIdx.x, tB0 = blockIdx.x, tB1 = blockIdx.x;
-#define T8_SETUP_A(PTR, H, TILE)                                                                                     \
+#define T8_SETUP_A(OFF, H, TILE)                                                                                     \
     {                                                                                                                \
         int tm_, tn_;                                                                                                \
         tile_of_index(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                                                 \
         if (p.dbg == 77) tm_ = 0;   /* ORV_GEMM_DBG=77 (timing experiment, wrong results): every workgroup streams the panels of tile (0, 0) */ \
-        PTR = p.A + (long)min(tm_ * 256 + arow0 + (H) * 64, p.M - 1) * p.lda + schunk * 8;                           \
+        const int row_ = tm_ * 256 + arow0 + (H) * 64;                                                               \
+        OFF[0] = (unsigned)(((long)min(row_, p.M - 1) * p.lda + schunk * 8) * 2);                                    \
+        OFF[1] = FL ? (unsigned)(((long)min(row_ + 8, p.M - 1) * p.lda + schunk * 8) * 2) : OFF[0] + 64;             \
     }
-#define T8_SETUP_B(PTR, H, TILE)                                                                                     \
+#define T8_SETUP_B(OFF, H, TILE)                                                                                     \
     {                                                                                                                \
         int tm_, tn_;                                                                                                \
         tile_of_index(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                                                 \
         if (p.dbg == 77) tn_ = 0;                                                                                    \
-        if ((H) == 0) PTR = p.W + (long)(tn_ * BN + brow0) * p.ldw + schunk * 8;                                     \
-        else PTR = p.W + (long)(tn_ * BN + brow1) * p.ldw + koff1;                                                   \
+        const int row_ = tn_ * BN + ((H) == 0 ? brow0 : brow1);                                                      \
+        OFF[0] = (unsigned)(((long)row_ * p.ldw + ((H) == 0 ? schunk * 8 : koff1)) * 2);                             \
+        OFF[1] = FL ? (unsigned)(((long)(row_ + 16) * p.ldw + schunk * 8) * 2) : OFF[0] + 64;                        \
     }
     // advance a stream by one K-tile; past its tile's last K-tile it moves to the workgroup's next tile (past the last tile: the
     // final tile again - uniform instruction counts, data never read)
-#define T8_NEXT_A(PTR, KC, TC, H)                                                                                    \
-    PTR += BK;                                                                                                       \
-    if (__builtin_expect(++KC == nk, 0)) { KC = 0; TC += gridDim.x; T8_SETUP_A(PTR, H, TC) }
-#define T8_NEXT_B(PTR, KC, TC, H)                                                                                    \
-    PTR += BK;                                                                                                       \
-    if (__builtin_expect(++KC == nk, 0)) { KC = 0; TC += gridDim.x; T8_SETUP_B(PTR, H, TC) }
+#define T8_NEXT_A(OFF, KC, TC, H)                                                                                    \
+    if (__builtin_expect(++KC == nk, 0)) { KC = 0; TC += gridDim.x; T8_SETUP_A(OFF, H, TC) }
+#define T8_NEXT_B(OFF, KC, TC, H)                                                                                    \
+    if (__builtin_expect(++KC == nk, 0)) { KC = 0; TC += gridDim.x; T8_SETUP_B(OFF, H, TC) }
 #ifdef ORV_T8_ABL_NODMA      // ablation builds (tools/t8_loop_abl.sh, wrong results): what does the K loop cost without its LDS-DMA / without its fragment reads?
-#define T8_GLDS(SRC, DST) asm volatile("" :: "v"(SRC), "s"(DST))
+#define T8_GLDS(BASE, KC, OFF, DST) asm volatile("" :: "v"(OFF), "s"(DST))
 #else
-#define T8_GLDS(SRC, DST) glds16(SRC, DST)
+#define T8_GLDS(BASE, KC, OFF, DST) glds16((const char*)(BASE) + (long)(KC) * (BK * 2) + (OFF), DST)
 #endif
-#define T8_ISSUE_A0(S) { T8_GLDS(pA0, dst2 + (S) * BUF); T8_GLDS(pA0 + 32, dst2 + (S) * BUF + 1024); T8_NEXT_A(pA0, kA0, tA0, 0) }
-#define T8_ISSUE_A1(S) { T8_GLDS(pA1, dst2 + (S) * BUF + HALF); T8_GLDS(pA1 + 32, dst2 + (S) * BUF + HALF + 1024); T8_NEXT_A(pA1, kA1, tA1, 1) }
-#define T8_ISSUE_B0(S) { T8_GLDS(pB0, dst2 + (S) * BUF + 2 * HALF); T8_GLDS(pB0 + 32, dst2 + (S) * BUF + 2 * HALF + 1024); T8_NEXT_B(pB0, kB0, tB0, 0) }
+#define T8_ISSUE_A0(S) { T8_GLDS(p.A, kA0, oA0[0], dst2 + (S) * BUF); T8_GLDS(p.A, kA0, oA0[1], dst2 + (S) * BUF + 1024); T8_NEXT_A(oA0, kA0, tA0, 0) }
+#define T8_ISSUE_A1(S) { T8_GLDS(p.A, kA1, oA1[0], dst2 + (S) * BUF + HALF); T8_GLDS(p.A, kA1, oA1[1], dst2 + (S) * BUF + HALF + 1024); T8_NEXT_A(oA1, kA1, tA1, 1) }
+#define T8_ISSUE_B0(S) { T8_GLDS(p.W, kB0, oB0[0], dst2 + (S) * BUF + 2 * HALF); T8_GLDS(p.W, kB0, oB0[1], dst2 + (S) * BUF + 2 * HALF + 1024); T8_NEXT_B(oB0, kB0, tB0, 0) }
 #define T8_ISSUE_B1(S)                                                                                               \
     {                                                                                                                \
-        if constexpr (BN == 256) { T8_GLDS(pB1, dst2 + (S) * BUF + 3 * HALF); T8_GLDS(pB1 + 32, dst2 + (S) * BUF + 3 * HALF + 1024); } \
-        else { T8_GLDS(pB1, dst1 + (S) * BUF); }                                                                     \
-        T8_NEXT_B(pB1, kB1, tB1, 1)                                                                                  \
+        if constexpr (BN == 256) { T8_GLDS(p.W, kB1, oB1[0], dst2 + (S) * BUF + 3 * HALF); T8_GLDS(p.W, kB1, oB1[1], dst2 + (S) * BUF + 3 * HALF + 1024); } \
+        else { T8_GLDS(p.W, kB1, oB1[0], dst1 + (S) * BUF); }                                                        \
+        T8_NEXT_B(oB1, kB1, tB1, 1)                                                                                  \
     }
+#define pA0 oA0
+#define pA1 oA1
+#define pB0 oB0
+#define pB1 oB1
     T8_SETUP_A(pA0, 0, tA0)
     T8_SETUP_A(pA1, 1, tA1)
     T8_SETUP_B(pB0, 0, tB0)
     T8_SETUP_B(pB1, 1, tB1)
 
     // ---- fragment reads: logical byte (l & 15) * 64 + (l >> 4) * 16 of a subtile, bit 5 flipped for rows 8-15
-    const int fro = ((lane & 15) * 64 + (lane >> 4) * 16) ^ (((lane >> 3) & 1) << 5);
-    const char* const rdA = smem + (wr * 4) * 2048 + fro;             // + S * BUF + mh * HALF + mb * 2048 + kh * 1024
-    const char* const rdB = smem + 2 * HALF + (wc * 2) * 2048 + fro;  // region 0 (two blocks per wave): + S * BUF + t * 2048 + kh * 1024
+    // ---- fragment reads.  st_16x32: logical byte (l & 15) * 64 + (l >> 4) * 16 of a piece, bit 5 flipped for rows 8-15, k half 1 = + 1024 (an
+    // immediate).  FL: row i = l & 15 of a block = piece i >> 3, row i & 7, k chunk (4 kh + g) ^ (i & 6): k half 1 = the same address with
+    // bit 6 flipped (a second base register).
+    const int fro = FL ? ((lane & 15) >> 3) * 1024 + (lane & 7) * 128 + (((lane >> 4) ^ (lane & 6)) << 4)
+                       : ((lane & 15) * 64 + (lane >> 4) * 16) ^ (((lane >> 3) & 1) << 5);
+    const int fro1 = FL ? fro ^ 64 : fro + 1024;
+    const char* const rdA = smem + (wr * 4) * 2048 + fro;             // + S * BUF + mh * HALF + mb * 2048
+    const char* const rdA_1 = smem + (wr * 4) * 2048 + fro1;
+    const char* const rdB = smem + 2 * HALF + (wc * 2) * 2048 + fro;  // region 0 (two blocks per wave): + S * BUF + t * 2048
+    const char* const rdB_1 = smem + 2 * HALF + (wc * 2) * 2048 + fro1;
     const char* const rdB1 = BN == 256 ? rdB + HALF : smem + 3 * HALF + wc * 2048 + fro;
+    const char* const rdB1_1 = BN == 256 ? rdB_1 + HALF : smem + 3 * HALF + wc * 2048 + fro1;
+#define T8_KH(P, KH) (FL ? ((KH) ? P##_1 : P) : P + (KH) * 1024)
 
     f32x4 acc[2][4][NBW];
 #pragma unroll
@@ -549,12 +582,12 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
 #define T8_READ_A(MH, S)                                                                                             \
     _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                                 \
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
-            fa[MH][mb][kh] = (MH) ? fa[0][mb][kh] : *(const bf16x8*)(rdA + (S) * BUF + (MH) * HALF + mb * 2048 + kh * 1024);
+            fa[MH][mb][kh] = (MH) ? fa[0][mb][kh] : *(const bf16x8*)(T8_KH(rdA, kh) + (S) * BUF + (MH) * HALF + mb * 2048);
 #else
 #define T8_READ_A(MH, S)                                                                                             \
     _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                                 \
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
-            fa[MH][mb][kh] = *(const bf16x8*)(rdA + (S) * BUF + (MH) * HALF + mb * 2048 + kh * 1024);
+            fa[MH][mb][kh] = *(const bf16x8*)(T8_KH(rdA, kh) + (S) * BUF + (MH) * HALF + mb * 2048);
 #endif
 #ifdef ORV_T8_ABL_NOREAD
 #define T8_READ_B01(S)                                                                                               \
@@ -564,7 +597,7 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
 #define T8_READ_B01(S)                                                                                               \
     _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                    \
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
-            fb[t][kh] = *(const bf16x8*)(rdB + (S) * BUF + t * 2048 + kh * 1024);
+            fb[t][kh] = *(const bf16x8*)(T8_KH(rdB, kh) + (S) * BUF + t * 2048);
 #endif
 #if defined(ORV_T8_ABL_NOREAD)
 #define T8_READ_B23(S)                                                                                               \
@@ -579,7 +612,7 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
 #define T8_READ_B23(S)                                                                                               \
     _Pragma("unroll") for (int t = 0; t < NBW - 2; ++t)                                                              \
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
-            fb[2 + t][kh] = *(const bf16x8*)(rdB1 + (S) * BUF + t * 2048 + kh * 1024);
+            fb[2 + t][kh] = *(const bf16x8*)(T8_KH(rdB1, kh) + (S) * BUF + t * 2048);
 #endif
     // (m half MH) x (blocks B0 .. B0 + NBK - 1), both k halves
 #ifdef ORV_T8_ABL_NOMFMA
@@ -708,11 +741,11 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
     // reads B01 / A1 head itself in P1 (T8C_KTILE_FIRST) and issues its P1 DMA in P2 (the second half reads B01 one interval later).
 #define T8_READ_A1_HEAD(S)                                                                                           \
     _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                                 \
-        fa[1][0][kh] = *(const bf16x8*)(rdA + (S) * BUF + HALF + kh * 1024);
+        fa[1][0][kh] = *(const bf16x8*)(T8_KH(rdA, kh) + (S) * BUF + HALF);
 #define T8_READ_A1_REST(S)                                                                                           \
     _Pragma("unroll") for (int mb = 1; mb < 4; ++mb)                                                                 \
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
-            fa[1][mb][kh] = *(const bf16x8*)(rdA + (S) * BUF + HALF + mb * 2048 + kh * 1024);
+            fa[1][mb][kh] = *(const bf16x8*)(T8_KH(rdA, kh) + (S) * BUF + HALF + mb * 2048);
 #define T8C_PRE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #define T8C_TAIL(S)                                                                                                  \
         T8_READ_B23(S)                                                                                               \
@@ -879,6 +912,10 @@ int launch_one(const GemmArgs& a, hipStream_t st) {
 
 namespace orv_gemm {
 int launch_t8(const GemmArgs& a, int bn, int epi, hipStream_t st) {
+    if ((long)a.M * a.lda * 2 >= (1L << 32) || (long)a.N * a.ldw * 2 >= (1L << 32)) {
+        orv_set_error("orv_gemm_bf16: the t8 kernel addresses A / W with 32-bit byte offsets (M=%d lda=%ld N=%d ldw=%ld)", a.M, a.lda, a.N, a.ldw);
+        return ORV_EINVAL;
+    }
     if (bn == 256) {
         switch (epi) {
             case 0: return launch_one<256, 0>(a, st);
