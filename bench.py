@@ -249,7 +249,7 @@ def vae_decode_leg(latents, dev, loop_wall, steps, world, B, barrier):
     step_s = loop_wall / steps
     return {"ms_per_clip": round(1e3 * dt / B, 2), "ms_per_clip_untiled": round(1e3 * dt_plain / B, 2),
             "tiling": "enable_tiling() as the reference: 4 tiles 30x45 / 30x24 / 15x45 / 15x24 latent, blend 40 / 72 px",
-            "parity": "unpinned (oracle/vae.py restates diffusers incl. tiled_decode; no reference fixture)",
+            "parity": "no reference fixture can exist (diffusers absent); oracle/vae.py and the HIP decode are pinned by an independent naive derivation (tools/make_vae_naive.py, tests/test_vae_naive_golden.py)",
             "frames_per_sec_50_steps_incl_decode": round(17.0 * world * B / (50 * step_s + dt), 3),
             "frames_per_sec_50_steps_excl_decode": round(17.0 * world * B / (50 * step_s), 3)}
 
