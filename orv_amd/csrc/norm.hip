@@ -222,6 +222,103 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(const bf16_t* src, bf16_t
     }
 }
 
+// Round 4, rows-per-wave form of the FULL case (xmap-free): the one-row kernel moves 4 KB of x and 4 KB of y per row through the CU's texture
+// path - and 24 KB of FACTOR loads (gamma, beta, scale, shift: L2 hits, but 24 of the wave's 32 vector-memory instructions).  Here a wave
+// owns R consecutive rows, keeps the four factor vectors of the current token group in registers (reloaded when the group changes: text
+// rows, then per_group rows per frame) FOLDED into two - y = xhat * [gamma (1 + scale)] + [beta (1 + scale) + shift], fp32: one rounding order
+// away from ln_mod_kernel's ((xhat gamma + beta)(1 + scale) + shift), far below the bf16 output step - and prefetches row r + 1 while row r is
+// normalised.
+template <int CH>
+#ifndef ORV_LNR_WAVES
+#define ORV_LNR_WAVES 3
+#endif
+__global__ __launch_bounds__(256, ORV_LNR_WAVES) void ln_mod_rows_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t* __restrict__ y, long ldy,
+                                                             const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift, long mod_b,
+                                                             long mod_g, int seq, int n_text, int per_group, int rows, int D, float eps, int R) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r0 = __builtin_amdgcn_readfirstlane(w * R);
+    if (r0 >= rows) return;
+    const int r1 = min(r0 + R, rows);
+    const int nchunk = D >> 3;
+    int ce[CH];
+    bool ok[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = lane + 64 * i;
+        ok[i] = c < nchunk;
+        ce[i] = min(c, nchunk - 1);
+    }
+    float gg[CH][8], hh[CH][8];      // y = xhat * gg + hh with gg = gamma (1 + scale), hh = beta (1 + scale) + shift of the current token group
+    long cur_off = -1;
+    uint4 raw[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) raw[i] = *(const uint4*)(x + (long)r0 * ldx + ce[i] * 8);
+    for (int row = r0; row < r1; ++row) {
+        const int b = row / seq, sidx = row % seq;
+        const long off = b * mod_b + orv_group_of(sidx, n_text, per_group) * mod_g;
+        if (off != cur_off) {        // wave-uniform
+            cur_off = off;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const uint4 gm = *(const uint4*)(gamma + ce[i] * 8), bt = *(const uint4*)(beta + ce[i] * 8);
+                const float4 s0 = *(const float4*)(scale + off + ce[i] * 8), s1 = *(const float4*)(scale + off + ce[i] * 8 + 4);
+                const float4 h0 = *(const float4*)(shift + off + ce[i] * 8), h1 = *(const float4*)(shift + off + ce[i] * 8 + 4);
+                const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                const uint32_t gw[4] = {gm.x, gm.y, gm.z, gm.w}, bw[4] = {bt.x, bt.y, bt.z, bt.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float g = bf2f((e & 1) ? gw[e >> 1] >> 16 : gw[e >> 1] & 0xffff);
+                    const float be = bf2f((e & 1) ? bw[e >> 1] >> 16 : bw[e >> 1] & 0xffff);
+                    gg[i][e] = g * (1.0f + sv[e]);
+                    hh[i][e] = fmaf(be, 1.0f + sv[e], hv[e]);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // one chunk's factor loads at a time (rare path: keeps the register peak down)
+            }
+        }
+        float v[CH][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const uint32_t wv[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[i][2 * e] = bf2f(wv[e] & 0xffff);
+                v[i][2 * e + 1] = bf2f(wv[e] >> 16);
+                s += ok[i] ? v[i][2 * e] + v[i][2 * e + 1] : 0.f;
+            }
+        }
+        {   // row r + 1 is fetched into the registers row r was just unpacked from
+            const int rn = min(row + 1, rows - 1);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) raw[i] = *(const uint4*)(x + (long)rn * ldx + ce[i] * 8);
+        }
+        const float mean = wave_sum_valu(s) / (float)D;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = ok[i] ? v[i][e] - mean : 0.f;
+                sq += d * d;
+            }
+        }
+        const float rstd = rsqrtf(wave_sum_valu(sq) / (float)D + eps);
+        bf16_t* yr = y + (long)row * ldy;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = fmaf((v[i][e] - mean) * rstd, gg[i][e], hh[i][e]);
+            uint4 u;
+            u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]); u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
+            *(uint4*)(yr + ce[i] * 8) = u;       // lanes past the row end re-store the last chunk's identical bytes
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int orv_layernorm_modulate(const void* x, int ldx, orv_rowmap_t xmap, void* y, int ldy, const void* gamma,
@@ -237,6 +334,24 @@ extern "C" int orv_layernorm_modulate(const void* x, int ldx, orv_rowmap_t xmap,
     dim3 grid((rows + 3) / 4), block(256);
     hipStream_t st = (hipStream_t)stream;
     const bool full = gamma && beta && scale && shift;
+    // rows-per-wave form: big FULL launches without a row map; R = rows per wave so that one round of resident waves (12 per CU) covers
+    // the problem.  ORV_LN_ROWS=0: the one-row kernel everywhere (A/B); ORV_LN_ROWS=n: fixed R.
+    static int rows_env = -2;
+    if (rows_env == -2) { const char* e = getenv("ORV_LN_ROWS"); rows_env = e ? atoi(e) : -1; }
+    if (full && xmap.rows == 0 && rows_env != 0 && rows >= 2048 && ch <= 4) {
+        const int slots = 256 * 4 * ORV_LNR_WAVES;
+        const int R = rows_env > 0 ? rows_env : max(2, (rows + slots - 1) / slots);
+        dim3 g2(((rows + R - 1) / R + 3) / 4);
+#define ORV_LNR_CASE(C)                                                                                                \
+        hipLaunchKernelGGL((ln_mod_rows_kernel<C>), g2, block, 0, st, (const bf16_t*)x, (long)ldx, (bf16_t*)y, (long)ldy, \
+                           (const bf16_t*)gamma, (const bf16_t*)beta, scale, shift, mod_b, mod_g, grp.seq, grp.n_text, \
+                           grp.per_group, rows, D, eps, R)
+        if (ch <= 1) { ORV_LNR_CASE(1); }
+        else if (ch <= 2) { ORV_LNR_CASE(2); }
+        else { ORV_LNR_CASE(4); }
+#undef ORV_LNR_CASE
+        return orv_check_launch("orv_layernorm_modulate");
+    }
 #define ORV_LN_CASE(C)                                                                                                 \
     if (full)                                                                                                          \
         hipLaunchKernelGGL((ln_mod_kernel<C, true>), grid, block, 0, st, (const bf16_t*)x, (long)ldx, (bf16_t*)y, (long)ldy, \
