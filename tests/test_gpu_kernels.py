@@ -110,6 +110,49 @@ def test_layernorm_modulate(D):
     close(y2, ln.view(B, S, D)[:, nt:].reshape(B * nv, D))
 
 
+@pytest.mark.parametrize("D,B,S,nt,P", [(1920, 3, 1033, 26, 201), (1920, 1, 3226, 226, 600), (128, 2, 1500, 7, 149), (512, 5, 421, 0, 0)])
+def test_layernorm_modulate_rows_per_wave_kernel(D, B, S, nt, P):
+    """Launches of >= 2048 rows without a row map take ln_mod_rows_kernel (a wave owns R consecutive rows, keeps the folded factor
+    vectors of the current token group in registers, prefetches the next row): group changes inside a wave's row range, a batch
+    boundary inside it, a ragged last wave and D < 512 (one chunk, masked lanes) against the fp32 reference."""
+    from orv_amd import ops
+    dev = _dev()
+    G = 1 + ((S - nt) // P if P else 1)
+    g = torch.Generator().manual_seed(D + S)
+    x = q(torch.randn(B * S, D, generator=g) * 2 + 0.5)
+    gamma, beta = q(torch.randn(D, generator=g)), q(torch.randn(D, generator=g))
+    mod = torch.randn(B, G + 1, 2 * D, generator=g)
+    rows = torch.arange(B * S)
+    s = rows % S
+    grp = torch.where(s < nt, torch.zeros_like(s), 1 + ((s - nt) // P if P else torch.zeros_like(s)))
+    ln = torch.nn.functional.layer_norm(x, (D,), gamma, beta, 1e-5)
+    ref = ln * (1 + mod[rows // S, grp, D:]) + mod[rows // S, grp, :D]
+    y = torch.full((B * S, D), float("nan"), dtype=BF, device=dev)
+    md = mod.to(dev)
+    ops.layernorm_modulate(x.to(dev, BF), y, gamma.to(dev, BF), beta.to(dev, BF), md[..., D:], md[..., :D], (G + 1) * 2 * D,
+                           2 * D, ops.groups(S, nt, P), B, D, 1e-5)
+    assert B * S >= 2048 or D == 512           # (the last case stays on the one-row kernel: same bound either way)
+    close(y, ref)
+
+
+def test_gemm_operand_of_4gib_and_more_leaves_the_t8_kernel():
+    """gemm_t8_kernel addresses A and W with 32-bit byte offsets; a call whose A spans >= 4 GiB (here: a wide leading dimension)
+    must be planned onto another kernel and still be right."""
+    from orv_amd import ops
+    dev = _dev()
+    M, N, K = 2304, 768, 256
+    lda = 1 << 20                                  # 2304 rows x 2 MiB = 4.5 GiB span
+    g = torch.Generator().manual_seed(11)
+    A, W = q(torch.randn(M, K, generator=g)), q(torch.randn(N, K, generator=g) * 0.1)
+    big = torch.zeros(M * lda, dtype=BF, device=dev)
+    Av = big.view(M, lda)
+    Av[:, :K] = A.to(dev, BF)
+    C = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+    ops.gemm(Av, W.to(dev, BF), None, C, M, N, K, lda=lda)
+    close(C, A @ W.t())
+    del big
+
+
 def _attention_reference(qkv, B, S, H, gq, bq, gk, bk, rope, nt):
     D = H * 64
     x = qkv.view(B, S, 3, H, 64).permute(2, 0, 3, 1, 4)      # [3,B,H,S,64]
