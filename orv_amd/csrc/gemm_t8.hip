@@ -447,6 +447,30 @@ __device__ __forceinline__ void t8_epilogue_lds(const GemmArgs& p, f32x4 (&acc)[
     }
 }
 
+#ifdef ORV_T8_TRPROBE
+// timing probe (WRONG results; tools/t8_tr_probe.sh, profiles/r4_gemm_tn_probe.txt): what would a TN main loop (wgrad without the operand
+// transposes) cost?  Every ds_read_b128 of a fragment becomes two ds_read_b64_tr_b16 at the conflict-free addresses a row-major [8 m][64 n]
+// piece image would use, and the LDS-DMA is issued from inline asm (hipcc puts s_waitcnt vmcnt(0) in front of a transposing read that
+// follows a DMA builtin).
+typedef short t8_v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char t8_lds_char;
+__device__ __forceinline__ void t8_glds_asm(const char* sbase, unsigned voff, const void* lds_dst) {
+    unsigned keep;
+    const unsigned long long u = (unsigned long long)(uintptr_t)sbase;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi_ = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    const unsigned long long su = ((unsigned long long)hi_ << 32) | lo;
+    const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(su), "s"(d) : "memory");
+}
+__device__ __forceinline__ bf16x8 t8_tr2(t8_lds_char* a) {
+    const t8_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) t8_v4s*)(a));
+    const t8_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) t8_v4s*)(a + 512));
+    union { bf16x8 v; t8_v4s h[2]; } u;
+    u.h[0] = lo; u.h[1] = hi;
+    return u.v;
+}
+#endif
 template <int BN, int EPI>
 __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
     constexpr int NBW = BN / 64;                      // 16-column blocks per wave
@@ -530,7 +554,11 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
 #ifdef ORV_T8_ABL_NODMA      // ablation builds (tools/t8_loop_abl.sh, wrong results): what does the K loop cost without its LDS-DMA / without its fragment reads?
 #define T8_GLDS(BASE, KC, OFF, DST) asm volatile("" :: "v"(OFF), "s"(DST))
 #else
+#ifdef ORV_T8_TRPROBE
+#define T8_GLDS(BASE, KC, OFF, DST) t8_glds_asm((const char*)(BASE) + (long)(KC) * (BK * 2), OFF, DST)
+#else
 #define T8_GLDS(BASE, KC, OFF, DST) glds16((const char*)(BASE) + (long)(KC) * (BK * 2) + (OFF), DST)
+#endif
 #endif
 #define T8_ISSUE_A0(S) { T8_GLDS(p.A, kA0, oA0[0], dst2 + (S) * BUF); T8_GLDS(p.A, kA0, oA0[1], dst2 + (S) * BUF + 1024); T8_NEXT_A(oA0, kA0, tA0, 0) }
 #define T8_ISSUE_A1(S) { T8_GLDS(p.A, kA1, oA1[0], dst2 + (S) * BUF + HALF); T8_GLDS(p.A, kA1, oA1[1], dst2 + (S) * BUF + HALF + 1024); T8_NEXT_A(oA1, kA1, tA1, 1) }
@@ -565,6 +593,17 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
     const char* const rdB1_1 = BN == 256 ? rdB_1 + HALF : smem + 3 * HALF + wc * 2048 + fro1;
 #define T8_KH(P, KH) (FL ? ((KH) ? P##_1 : P) : P + (KH) * 1024)
 
+#ifdef ORV_T8_TRPROBE
+    t8_lds_char* trb[4];
+    t8_lds_char* trb1[4];
+    {
+        t8_lds_char* const smem3 = (t8_lds_char*)smem;
+        const int i16 = lane & 15, g4 = lane >> 4, f = ((i16 >> 3) & 1) | ((g4 & 1) << 1);
+        const int lb = g4 * 2048 + (i16 >> 2) * 128 + (i16 & 3) * 8, lb1 = g4 * 1024 + (i16 >> 2) * 128 + (i16 & 3) * 8;
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) { trb[sg] = smem3 + (lb | ((sg ^ f) << 5)); trb1[sg] = smem3 + (lb1 | ((sg ^ f) << 5)); }
+    }
+#endif
     f32x4 acc[2][4][NBW];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -583,6 +622,11 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
     _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                                 \
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
             fa[MH][mb][kh] = (MH) ? fa[0][mb][kh] : *(const bf16x8*)(T8_KH(rdA, kh) + (S) * BUF + (MH) * HALF + mb * 2048);
+#elif defined(ORV_T8_TRPROBE)
+#define T8_READ_A(MH, S)                                                                                             \
+    _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                                 \
+        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
+            fa[MH][mb][kh] = t8_tr2(trb[mb] + (S) * BUF + (MH) * HALF + wr * 1024 + kh * 8192);
 #else
 #define T8_READ_A(MH, S)                                                                                             \
     _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                                 \
@@ -593,6 +637,11 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
 #define T8_READ_B01(S)                                                                                               \
     _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                    \
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) asm volatile("" : "+v"(fb[t][kh]));
+#elif defined(ORV_T8_TRPROBE)
+#define T8_READ_B01(S)                                                                                               \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                    \
+        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
+            fb[t][kh] = t8_tr2(trb[2 * (wc & 1) + t] + (S) * BUF + 2 * HALF + (wc >> 1) * 1024 + kh * 8192);
 #else
 #define T8_READ_B01(S)                                                                                               \
     _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                    \
@@ -608,6 +657,12 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
     _Pragma("unroll") for (int t = 0; t < NBW - 2; ++t)                                                              \
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
             fb[2 + t][kh] = fb[t][kh];
+#elif defined(ORV_T8_TRPROBE)
+#define T8_READ_B23(S)                                                                                               \
+    _Pragma("unroll") for (int t = 0; t < NBW - 2; ++t)                                                              \
+        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
+            fb[2 + t][kh] = BN == 256 ? t8_tr2(trb[2 * (wc & 1) + t] + (S) * BUF + 3 * HALF + (wc >> 1) * 1024 + kh * 8192)                  \
+                                      : t8_tr2(trb1[wc] + (S) * BUF + 3 * HALF + kh * 4096);
 #else
 #define T8_READ_B23(S)                                                                                               \
     _Pragma("unroll") for (int t = 0; t < NBW - 2; ++t)                                                              \
