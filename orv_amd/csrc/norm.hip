@@ -416,6 +416,38 @@ struct ModArgs {
     int vis_tiles;            // ceil(B*T / 32)
 };
 
+// conditioning fragments of a row: lane holds silu(temb[b] (+ act[b, t]))[ks * 16 + hi * 8 .. + 8].  Loads are UNCONDITIONAL (without an
+// action embedding the second stream re-reads temb and is ignored) and issued eight k-steps at a time: with `if (ap) load` per k-step hipcc
+// branched around every load and waited vmcnt(0) behind it - 32 dependent round trips (~40 us) at the head of every workgroup (round 4).
+template <int KS>
+__device__ __forceinline__ void mod_cond_frags(const ModArgs& p, int b, int t, bool is_text, bool rvalid, int hi, bf16x8 (&cf)[KS]) {
+    const bool has_act = !is_text && p.act != nullptr;
+    const bf16_t* tp = p.temb + (long)b * p.E + hi * 8;
+    const bf16_t* ap = has_act ? p.act + ((long)b * p.T + t) * p.E + hi * 8 : tp;
+    constexpr int BATCH = KS < 8 ? KS : 8;
+#pragma unroll
+    for (int k0 = 0; k0 < KS; k0 += BATCH) {
+        uint4 tu[BATCH], au[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) { tu[j] = *(const uint4*)(tp + (k0 + j) * 16); au[j] = *(const uint4*)(ap + (k0 + j) * 16); }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const uint32_t tw[4] = {tu[j].x, tu[j].y, tu[j].z, tu[j].w}, aw[4] = {au[j].x, au[j].y, au[j].z, au[j].w};
+            union { bf16x8 v; uint32_t u[4]; } c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float lo = bf2f(tw[e] & 0xffff), hi2 = bf2f(tw[e] >> 16);
+                // the reference adds in the model dtype (bf16) before SiLU
+                const float lo_a = bf2f(f2bf(lo + bf2f(aw[e] & 0xffff))), hi_a = bf2f(f2bf(hi2 + bf2f(aw[e] >> 16)));
+                lo = has_act ? lo_a : lo;
+                hi2 = has_act ? hi_a : hi2;
+                c.u[e] = rvalid ? pack2bf(silu(lo), silu(hi2)) : 0u;
+            }
+            cf[k0 + j] = c.v;
+        }
+    }
+}
+
 template <int KS>  // KS = E / 16 k-steps
 __global__ __launch_bounds__(256) void mod_tables_kernel(const ModArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -430,28 +462,7 @@ __global__ __launch_bounds__(256) void mod_tables_kernel(const ModArgs p) {
     const int t = rvalid && !is_text ? r % p.T : 0;
     // conditioning fragments: lane holds cond[r][ks*16 + hi*8 .. +8]
     bf16x8 cf[KS];
-    {
-        const bf16_t* tp = p.temb + (long)b * p.E + hi * 8;
-        const bf16_t* ap = (!is_text && p.act) ? p.act + ((long)b * p.T + t) * p.E + hi * 8 : nullptr;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const uint4 tu = *(const uint4*)(tp + ks * 16);
-            uint4 au = make_uint4(0, 0, 0, 0);
-            if (ap) au = *(const uint4*)(ap + ks * 16);
-            const uint32_t tw[4] = {tu.x, tu.y, tu.z, tu.w}, aw[4] = {au.x, au.y, au.z, au.w};
-            union { bf16x8 v; uint32_t u[4]; } c;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float lo = bf2f(tw[e] & 0xffff), hi2 = bf2f(tw[e] >> 16);
-                if (ap) {  // the reference adds in the model dtype (bf16) before SiLU
-                    lo = bf2f(f2bf(lo + bf2f(aw[e] & 0xffff)));
-                    hi2 = bf2f(f2bf(hi2 + bf2f(aw[e] >> 16)));
-                }
-                c.u[e] = rvalid ? pack2bf(silu(lo), silu(hi2)) : 0u;
-            }
-            cf[ks] = c.v;
-        }
-    }
+    mod_cond_frags<KS>(p, b, t, is_text, rvalid, hi, cf);
     const bf16_t* Wt = p.W[tab] + (is_text ? (long)p.width * p.E : 0);
     const bf16_t* bt = p.bias ? (p.bias[tab] ? p.bias[tab] + (is_text ? p.width : 0) : nullptr) : nullptr;
     const int G = 1 + p.T;
@@ -488,6 +499,112 @@ __global__ __launch_bounds__(256) void mod_tables_kernel(const ModArgs p) {
 
 }  // namespace
 
+namespace {
+// Round 4, E = 512: the weight blocks go through LDS.  mod_tables_kernel loads a weight fragment straight into the MFMA layout - lane =
+// (weight row, 16-byte k half): one wave instruction touches 32 rows x 32 B, i.e. 32 cache lines of which it uses a quarter, four
+// instructions per line - and ran at 2.5 TB/s.  Here a wave streams its 32-row weight block in eight 64-k slabs of 32 rows x 128 B with the
+// LDS-DMA (8 rows x one full 128-byte line per instruction; chunk ^ ((row >> 1) & 7) on the source: the image gemm_kernel reads conflict-free
+// with ds_read_b128), four slabs in flight in a wave-private 16-KiB ring (no barrier: a wave reads only what it staged), and keeps the
+// accumulators of its (up to four) blocks in registers until its stream has drained, so no store sits between the counted vmcnt waits.
+// LDS-DMA from inline asm (M0 written in the same statement): behind the builtin hipcc treats every DMA as a pending LDS write and puts
+// s_waitcnt vmcnt(0) in front of the next ds_read - the ring would drain at every slab.  The waits are the counted ones below.
+__device__ __forceinline__ void mt_glds16(const void* gsrc, const void* lds_dst) {
+    unsigned keep;
+    const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(d) : "memory");
+}
+constexpr int MT_SLABS = 4;          // slabs in flight per wave
+constexpr int MT_MAXBLK = 4;         // 32-column blocks per wave
+__global__ __launch_bounds__(256) void mod_tables_lds_kernel(const ModArgs p) {
+    constexpr int KS = 32, SPB = 8;                                   // E = 512: 32 k-steps of 16, 8 slabs of 64 k per block
+    __shared__ __attribute__((aligned(16))) char smem[4 * MT_SLABS * 4096];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, hi = lane >> 5, sw = (l31 >> 1) & 7;
+    const int tab = blockIdx.y;
+    const bool is_text = (int)blockIdx.z >= p.vis_tiles;
+    const int rtile = is_text ? blockIdx.z - p.vis_tiles : blockIdx.z;
+    const int nrows = is_text ? p.B : p.B * p.T;
+    const int r = rtile * 32 + l31;
+    const bool rvalid = r < nrows;
+    const int b = rvalid ? (is_text ? r : r / p.T) : 0;
+    const int t = rvalid && !is_text ? r % p.T : 0;
+    bf16x8 cf[KS];
+    mod_cond_frags<KS>(p, b, t, is_text, rvalid, hi, cf);
+    const bf16_t* Wt = p.W[tab] + (is_text ? (long)p.width * p.E : 0);
+    const bf16_t* bt = p.bias ? (p.bias[tab] ? p.bias[tab] + (is_text ? p.width : 0) : nullptr) : nullptr;
+    const int G = 1 + p.T;
+    float* orow = p.out + (((long)tab * p.B + b) * G + (is_text ? 0 : 1 + t)) * p.width;
+    const int nblocks = p.width / 32;
+    const int nb0 = blockIdx.x * 4 + wave, stride = gridDim.x * 4;
+    const int nblk = nb0 < nblocks ? (nblocks - nb0 + stride - 1) / stride : 0;      // <= MT_MAXBLK (host)
+    const int total = nblk * SPB;
+    char* const ring = smem + wave * (MT_SLABS * 4096);
+    // DMA source of this lane inside a slab: piece j = rows 8 j + (lane >> 3), 16-byte chunk (lane & 7) ^ ((row >> 1) & 7)
+    int soff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 8 * j + (lane >> 3);
+        soff[j] = row * p.E + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+    }
+    auto issue = [&](int sl) {
+        const int bi = sl / SPB, ks = sl % SPB;
+        const bf16_t* wp = Wt + (long)((nb0 + bi * stride) * 32) * p.E + ks * 64;
+        char* const d = ring + (sl % MT_SLABS) * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mt_glds16(wp + soff[j], d + j * 1024);
+    };
+    f32x16 acc[MT_MAXBLK];
+#pragma unroll
+    for (int i = 0; i < MT_MAXBLK; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < MT_SLABS - 1; ++sl)
+        if (sl < total) issue(sl);
+    const int rd_off = l31 * 128;
+#pragma unroll
+    for (int bi = 0; bi < MT_MAXBLK; ++bi) {
+        if (bi >= nblk) break;                    // wave-uniform
+#pragma unroll
+        for (int ks = 0; ks < SPB; ++ks) {
+            const int sl = bi * SPB + ks;
+            if (sl + MT_SLABS - 1 < total) {      // keep MT_SLABS - 1 slabs ahead; the slot being refilled was read an iteration ago
+                issue(sl + MT_SLABS - 1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (MT_SLABS - 1)) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            const char* sb = ring + (sl % MT_SLABS) * 4096 + rd_off;
+            bf16x8 wf[4];
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) wf[k4] = *(const bf16x8*)(sb + (((k4 * 2 + hi) ^ sw) << 4));
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) acc[bi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k4], cf[ks * 4 + k4], acc[bi], 0, 0, 0);
+            // the reads of this slab are complete (their values fed the MFMAs) before the NEXT iteration's DMA may overwrite slot (sl - 1) % 4
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    if (rvalid) {
+#pragma unroll
+        for (int bi = 0; bi < MT_MAXBLK; ++bi) {
+            if (bi >= nblk) break;
+            const int nb = nb0 + bi * stride;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = nb * 32 + q * 8 + hi * 4;
+                float4 o = make_float4(acc[bi][q * 4], acc[bi][q * 4 + 1], acc[bi][q * 4 + 2], acc[bi][q * 4 + 3]);
+                if (bt) {
+                    const uint2 bb = *(const uint2*)(bt + n);
+                    o.x += bf2f(bb.x & 0xffff); o.y += bf2f(bb.x >> 16); o.z += bf2f(bb.y & 0xffff); o.w += bf2f(bb.y >> 16);
+                }
+                *(float4*)(orow + n) = o;
+            }
+        }
+    }
+}
+}  // namespace
+
 extern "C" int orv_modulation_tables(const void* temb, const void* action_emb, const void* const* W,
                                      const void* const* bias, float* out, int n_tab, int B, int T, int E, int width,
                                      int text, void* stream) {
@@ -503,6 +620,13 @@ extern "C" int orv_modulation_tables(const void* temb, const void* action_emb, c
     const int nblocks = width / 32;
     dim3 grid(max(1, min((nblocks + 11) / 12, 64)), n_tab, a.vis_tiles + txt_tiles);
     hipStream_t st = (hipStream_t)stream;
+    static int lds_env = -1;     // ORV_MOD_TABLES_LDS=0: the direct-load kernel for E = 512 too (A/B)
+    if (lds_env < 0) { const char* e = getenv("ORV_MOD_TABLES_LDS"); lds_env = (e && atoi(e) == 0) ? 0 : 1; }
+    if (E == 512 && lds_env) {
+        dim3 g2((nblocks + 4 * MT_MAXBLK - 1) / (4 * MT_MAXBLK), n_tab, a.vis_tiles + txt_tiles);
+        hipLaunchKernelGGL(mod_tables_lds_kernel, g2, dim3(256), 0, st, a);
+        return orv_check_launch("orv_modulation_tables");
+    }
     switch (E) {
         case 64: hipLaunchKernelGGL(mod_tables_kernel<4>, grid, dim3(256), 0, st, a); break;
         case 128: hipLaunchKernelGGL(mod_tables_kernel<8>, grid, dim3(256), 0, st, a); break;
