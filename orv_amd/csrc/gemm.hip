@@ -1280,6 +1280,8 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
     static const GemmCand cands[] = {
         // ring = 3: the 16x16x32 8-phase kernel of gemm_t8.hip (persistent, BK = 64; needs an even number of K-tiles)
         {3, 256, 256, 1.29f, 0}, {3, 256, 192, 1.21f, 0},
+        // ring = 4: four-wave 256 x 256 experiment of gemm_t8.hip - forced only (rate 0.01 never wins)
+        {4, 256, 256, 0.01f, 0},
         // ring = 2: the phased (8-phase, BK = 64) persistent kernel; needs an even number of K-tiles
         // (256x384 does not fit: 192 accumulator + 64 fragment registers of the 256 a wave gets at two waves per SIMD)
         {2, 256, 256, 1.10f, 0}, {2, 256, 128, 0.80f, 0},
@@ -1310,6 +1312,7 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
         if (N % c.bn) continue;
         if (c.ring == 2 && (K % 128 != 0 || no_phased)) continue;
         if (c.ring == 3 && (K % 128 != 0 || no_t8 || wide || (epilogue == 4 && c.bn != 256))) continue;
+        if (c.ring == 4 && (K % 128 != 0 || wide || epilogue > 2 || force_ring != 4)) continue;
         // epilogue 4 normalises whole 64-wide heads inside a wave (BN / 2 columns) that must not straddle q | k | v
         if (epilogue == 4 && (c.bm == 192 || (c.bn / 2) % 64 != 0 || (heads * 64) % (c.bn / 2) != 0)) continue;
         if (force_bm && (c.ring != force_ring || c.bm != force_bm || c.bn != force_bn)) continue;
@@ -1379,6 +1382,7 @@ static int gemm_dispatch(GemmArgs a, const GemmCand* best, int epilogue, hipStre
         a.gm = gm_env > 0 ? gm_env : (a.K >= 4096 && a.tiles_n <= 16 ? 8 : 0);
     }
     if (best->ring == 3) return launch_t8(a, best->bn, epilogue, st);
+    if (best->ring == 4) return launch_t4(a, epilogue, st);
     if (best->ring == 2) {
         if (best->bn == 256) return launch_ph<256>(a, epilogue, st);
         return launch_ph<128>(a, epilogue, st);

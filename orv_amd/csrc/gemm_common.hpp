@@ -68,5 +68,7 @@ __device__ __forceinline__ void tile_of_block(const GemmArgs& p, int& tm, int& t
 
 // gemm_t8.hip: launches gemm_t8_kernel<BN, EPI> (BN = 256 or 192); a.tiles_m / a.tiles_n must be set for BM = 256, BN
 int launch_t8(const GemmArgs& a, int bn, int epi, hipStream_t st);
+// gemm_t8.hip: the four-wave 256 x 256 experiment (ORV_GEMM_TILE=4,256,256)
+int launch_t4(const GemmArgs& a, int epi, hipStream_t st);
 
 }  // namespace orv_gemm

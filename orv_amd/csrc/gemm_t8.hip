@@ -949,6 +949,209 @@ __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// EXPERIMENT (round 4, ORV_GEMM_TILE=4,256,256 only - never chosen by the cost model): the 256 x 256 tile on FOUR waves, one per SIMD,
+// 512 registers each: a wave owns 128 x 128 (64 accumulator quads = 256 registers), so a K step of 32 needs 16 fragment reads per
+// wave instead of the 24 of two 128 x 64 waves (a third less LDS traffic), and ONE barrier per K step replaces the eight per K-tile of the
+// 8-wave ping-pong.  Nothing overlaps across waves here: a wave's own stream interleaves the MFMAs of step s with the fragment reads of step
+// s + 1 (second register set) and the LDS-DMA of step s + 4 into the region step s just left (four 32-KiB step regions: three steps = 1.5 K-tiles
+// of prefetch distance).
+// The 128 columns of a wave are two of gemm_t8_kernel's 64-column wave tiles side by side (same W-row permutation per 64 columns), so the
+// epilogues are t8's, called once per half.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void t4_glds_asm(const char* sbase, unsigned voff, const void* lds_dst) {
+    unsigned keep;
+    const unsigned long long u = (unsigned long long)(uintptr_t)sbase;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi_ = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    const unsigned long long su = ((unsigned long long)hi_ << 32) | lo;
+    const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(su), "s"(d) : "memory");
+}
+// the accumulators are pinned to AGPRs, in place ("+a"): left to the register allocator the 64 quads were spread over both files with
+// v_accvgpr_write copies in front of most MFMAs and the DMA offsets spilled (382 TF)
+__device__ __forceinline__ void t4_mfma(f32x4& acc, const bf16x8& b, const bf16x8& a) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(b), "v"(a));
+}
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_t4_kernel(const GemmArgs p) {
+    constexpr int BN = 256, REG = 32768, NREG = 4, SCR = NREG * REG;      // step region: A 16 blocks | B 16 blocks of 1 KiB (st_16x32)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int ns = p.K / 32;                                              // K steps per tile (K % 128 == 0)
+
+    // ---- DMA: 32 pieces per step; waves 0, 1 move the A blocks 8 w .. 8 w + 7, waves 2, 3 the B blocks ----
+    const int lsw = lane ^ ((lane >> 5) << 1);
+    const int srow = lsw >> 2, schunk = lsw & 3;
+    const bool dmaA = wave < 2;                                           // wave-uniform
+    unsigned long long gb_;
+    {
+        const unsigned long long u = (unsigned long long)(uintptr_t)(dmaA ? (const void*)p.A : (const void*)p.W);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi_ = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        gb_ = ((unsigned long long)hi_ << 32) | lo;
+    }
+    const long ldg = dmaA ? p.lda : p.ldw;
+    unsigned off0, off1, off2, off3, off4, off5, off6, off7;              // per-lane byte offsets of this wave's eight pieces (named: an array went to scratch)
+    int s_dma = 0, t_dma = blockIdx.x;                                    // cursor of the DMA stream: (tile, step)
+#define T4_ROW(J, TM, TN)                                                                                             \
+    (dmaA ? min((TM) * 256 + (wave * 8 + (J)) * 16 + srow, p.M - 1)                                                   \
+          : (TN) * BN + (wave - 2) * 128 + (((J) >> 2) & 1) * 64 +                                                    \
+                (((J) >> 1) & 1) * 32 + 8 * (srow >> 2) + 4 * ((J) & 1) + (srow & 3))
+#define T4_OFF(J, TM, TN) (unsigned)(((long)T4_ROW(J, TM, TN) * ldg + schunk * 8) * 2)
+#define T4_SETUP(TILE)                                                                                                \
+    {                                                                                                                 \
+        int tm_, tn_;                                                                                                 \
+        tile_of_index(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                                                  \
+        off0 = T4_OFF(0, tm_, tn_); off1 = T4_OFF(1, tm_, tn_); off2 = T4_OFF(2, tm_, tn_); off3 = T4_OFF(3, tm_, tn_); \
+        off4 = T4_OFF(4, tm_, tn_); off5 = T4_OFF(5, tm_, tn_); off6 = T4_OFF(6, tm_, tn_); off7 = T4_OFF(7, tm_, tn_); \
+    }
+#define T4_ADVANCE() if (__builtin_expect(++s_dma == ns, 0)) { s_dma = 0; t_dma += gridDim.x; T4_SETUP(t_dma) }
+    T4_SETUP(t_dma)
+    const unsigned dst = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)smem + wave * 8192;     // LDS byte address; + region * REG + j * 1024
+#ifdef ORV_T4_NODMA     // ablation (wrong results)
+#define T4_DMA1(OFF, LDS) { asm volatile("" :: "v"(OFF), "s"(sb_), "s"(LDS)); }
+#else
+#define T4_DMA1(OFF, LDS)                                                                                             \
+    {                                                                                                                 \
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                                 \
+                     :: "v"(OFF), "s"(sb_), "s"(LDS) : "memory", "m0");                                                \
+    }
+#endif
+#define T4_ISSUE_ALL(REGION)                                                                                          \
+    {                                                                                                                 \
+        const unsigned long long sb_ = gb_ + (unsigned long long)s_dma * 64;                                          \
+        T4_DMA1(off0, dst + (REGION) * REG) T4_DMA1(off1, dst + (REGION) * REG + 1024) T4_DMA1(off2, dst + (REGION) * REG + 2048) \
+        T4_DMA1(off3, dst + (REGION) * REG + 3072) T4_DMA1(off4, dst + (REGION) * REG + 4096) T4_DMA1(off5, dst + (REGION) * REG + 5120) \
+        T4_DMA1(off6, dst + (REGION) * REG + 6144) T4_DMA1(off7, dst + (REGION) * REG + 7168)                          \
+        T4_ADVANCE()                                                                                                  \
+    }
+
+    // ---- fragments ----
+    const int fro = ((lane & 15) * 64 + (lane >> 4) * 16) ^ (((lane >> 3) & 1) << 5);
+    const char* const rdA = smem + (wr * 8) * 1024 + fro;                 // + region * REG + (mh * 4 + mb) * 1024
+    const char* const rdB = smem + 16384 + (wc * 8) * 1024 + fro;         // + region * REG + (nh * 4 + blk) * 1024
+    f32x4 acc[2][2][4][4];                                                // [nh][mh][mb][blk]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[2][8], fb[2][8];                                            // [set][block]
+    auto read_set = [&](int set, int region) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[set][i] = *(const bf16x8*)(rdA + region * REG + i * 1024);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fb[set][i] = *(const bf16x8*)(rdB + region * REG + i * 1024);
+    };
+#define T4_FENCE() __builtin_amdgcn_sched_barrier(0);
+    // one K step: [own DMA of step s + 1 landed (steps s + 2, s + 3 stay in flight) | barrier] then eight groups of { one DMA piece of
+    // step s + 4 -> REGION = s % 4 ; two fragment reads of step s + 1 ; eight MFMAs of step s }
+#ifdef ORV_T4_NOREAD
+#define T4_RD(DST, SRC) asm volatile("" : "+v"(DST));
+#else
+#define T4_RD(DST, SRC) DST = *(const bf16x8*)(SRC);
+#endif
+#define T4_MF(SET, G, I) t4_mfma(acc[(G) >> 2][(I) >> 2][(I) & 3][(G) & 3], fb[SET][G], fa[SET][I]);
+#ifdef ORV_T4_V1
+#define T4_GROUP(SET, REGION, G, OFF)                                                                                 \
+    {                                                                                                                 \
+        T4_DMA1(OFF, dst + (REGION) * REG + (G) * 1024)                                                               \
+        fa[(SET) ^ 1][G] = *(const bf16x8*)(rdA + (((REGION) + 1) & 3) * REG + (G) * 1024);                            \
+        fb[(SET) ^ 1][G] = *(const bf16x8*)(rdB + (((REGION) + 1) & 3) * REG + (G) * 1024);                            \
+        T4_MF(SET, G, 0) T4_MF(SET, G, 1) T4_MF(SET, G, 2) T4_MF(SET, G, 3) T4_MF(SET, G, 4) T4_MF(SET, G, 5) T4_MF(SET, G, 6) T4_MF(SET, G, 7) \
+        T4_FENCE()                                                                                                    \
+    }
+#else
+    // the memory instructions sit BETWEEN MFMAs (an MFMA occupies the pipe for 16 cycles: the issue slots behind it are free)
+#define T4_GROUP(SET, REGION, G, OFF)                                                                                 \
+    {                                                                                                                 \
+        T4_MF(SET, G, 0)                                                                                              \
+        T4_DMA1(OFF, dst + (REGION) * REG + (G) * 1024)                                                               \
+        T4_MF(SET, G, 1)                                                                                              \
+        T4_FENCE()                                                                                                    \
+        T4_RD(fa[(SET) ^ 1][G], rdA + (((REGION) + 1) & 3) * REG + (G) * 1024)                                        \
+        T4_FENCE()                                                                                                    \
+        T4_MF(SET, G, 2) T4_MF(SET, G, 3)                                                                             \
+        T4_FENCE()                                                                                                    \
+        T4_RD(fb[(SET) ^ 1][G], rdB + (((REGION) + 1) & 3) * REG + (G) * 1024)                                        \
+        T4_FENCE()                                                                                                    \
+        T4_MF(SET, G, 4) T4_MF(SET, G, 5) T4_MF(SET, G, 6) T4_MF(SET, G, 7)                                           \
+        T4_FENCE()                                                                                                    \
+    }
+#endif
+#define T4_STEP(SET, REGION)                                                                                          \
+    {                                                                                                                 \
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                                                             \
+        T4_FENCE() __builtin_amdgcn_s_barrier(); T4_FENCE()                                                           \
+        const unsigned long long sb_ = gb_ + (unsigned long long)s_dma * 64;                                          \
+        T4_GROUP(SET, REGION, 0, off0) T4_GROUP(SET, REGION, 1, off1) T4_GROUP(SET, REGION, 2, off2) T4_GROUP(SET, REGION, 3, off3) \
+        T4_GROUP(SET, REGION, 4, off4) T4_GROUP(SET, REGION, 5, off5) T4_GROUP(SET, REGION, 6, off6) T4_GROUP(SET, REGION, 7, off7) \
+        T4_ADVANCE()                                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
+        T4_FENCE()                                                                                                    \
+    }
+
+    // prologue: steps 0 .. 3 of the first tile in flight (all four regions), fragments of step 0 in set 0
+    T4_ISSUE_ALL(0) T4_ISSUE_ALL(1) T4_ISSUE_ALL(2) T4_ISSUE_ALL(3)
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    T4_FENCE() __builtin_amdgcn_s_barrier(); T4_FENCE()
+    read_set(0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    T4_FENCE()
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // step s: MFMAs on the fragments of region s % 4 (read during step s - 1, in set s & 1); that region is refilled with step s + 4
+        for (int s = 0; s < ns; s += 4) {
+            T4_STEP(0, 0) T4_STEP(1, 1) T4_STEP(0, 2) T4_STEP(1, 3)
+        }
+        int tm, tn;
+        tile_of_index(p, tile, ntiles, tm, tn);
+        constexpr bool lds_epi = EPI != 1 && EPI != 4;
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+            if constexpr (lds_epi) t8_epilogue_lds<BN, EPI>(p, acc[nh], tm * 256 + wr * 128, tn * BN + wc * 128 + nh * 64, lane, smem + SCR + wave * 4096);
+            else t8_epilogue<BN, EPI>(p, acc[nh], tm * 256 + wr * 128, tn * BN + wc * 128 + nh * 64, lane);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef T4_STEP
+#undef T4_GROUP
+#undef T4_MF
+#undef T4_FENCE
+#undef T4_ISSUE_ALL
+#undef T4_DMA1
+#undef T4_ADVANCE
+#undef T4_SETUP
+#undef T4_OFF
+#undef T4_ROW
+}
+
+template <int EPI>
+int launch_t4_one(const GemmArgs& a, hipStream_t st) {
+    constexpr int smem = 4 * 32768 + 4 * 4096;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_t4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    const int grid = min(a.tiles_m * a.tiles_n, orv_num_cus());
+    hipLaunchKernelGGL((gemm_t4_kernel<EPI>), dim3(grid), dim3(256), smem, st, a);
+    return orv_check_launch("orv_gemm_bf16");
+}
+
 template <int BN, int EPI>
 int launch_one(const GemmArgs& a, hipStream_t st) {
     constexpr int smem = 2 * (BN == 256 ? 65536 : 57344) + 8 * 4096;      // two K-tile buffers + the epilogue scratch (160 KiB at BN = 256)
@@ -966,6 +1169,15 @@ int launch_one(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 namespace orv_gemm {
+int launch_t4(const GemmArgs& a, int epi, hipStream_t st) {
+    switch (epi) {
+        case 0: return launch_t4_one<0>(a, st);
+        case 1: return launch_t4_one<1>(a, st);
+        case 2: return launch_t4_one<2>(a, st);
+    }
+    orv_set_error("orv_gemm_bf16: no t4 kernel for epilogue %d", epi);
+    return ORV_EINVAL;
+}
 int launch_t8(const GemmArgs& a, int bn, int epi, hipStream_t st) {
     if ((long)a.M * a.lda * 2 >= (1L << 32) || (long)a.N * a.ldw * 2 >= (1L << 32)) {
         orv_set_error("orv_gemm_bf16: the t8 kernel addresses A / W with 32-bit byte offsets (M=%d lda=%ld N=%d ldw=%ld)", a.M, a.lda, a.N, a.ldw);
