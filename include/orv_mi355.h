@@ -166,6 +166,11 @@ int orv_gemm_kernel_name(int M, int N, int K, int epilogue, char* buf, int len);
  * 1 ring, 2 phased, 3 t8; tile bm x bn) for all later orv_gemm_bf16 calls of this process; bm = 0 returns to the cost model.
  * Same effect as the environment variable ORV_GEMM_TILE="ring,bm,bn" read at the first call. */
 int orv_gemm_force_tile(int ring, int bm, int bn);
+/* C[M, N] (+)= A[K, M]^T . W[K, N] - both operands row-major over the CONTRACTION index (K rows): the weight gradient dW = dY^T X of a linear
+ * layer straight from the row-major dY [tokens, out] and X [tokens, in], without transposed copies (torch autograd of nn.Linear inside
+ * `accelerator.backward(loss)`, train_cogvideox_control_to_video_sft.py:1093; the linears of cogvideox_control.py:232-234, 263, 439-440).
+ * bf16 operands, fp32 accumulation, bf16 C; accumulate != 0 adds to C (gradient accumulation).  M % 8 == 0, N % 192 == 0 or N % 256 == 0. */
+int orv_gemm_tn_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, int accumulate, void* stream);
 
 /* -- backward (training) ------------------------------------------------------------------------------ */
 /* dst[c, r] = src[r, c] ([R, C] bf16 -> [C, ld_dst], columns [R, ld_dst) zero-filled).  Feeds the NT GEMM with the

@@ -60,6 +60,7 @@ SIGNATURES = {
                                   c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
     "orv_gemm_kernel_name": (c_int, [c_int, c_int, c_int, c_int, ctypes.c_char_p, c_int]),
     "orv_gemm_force_tile": (c_int, [c_int, c_int, c_int]),
+    "orv_gemm_tn_bf16": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p]),
     "orv_gemm_bf16": (c_int, [POINTER(Gemm), c_void_p]),
     "orv_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                   c_float, c_void_p]),

@@ -1261,6 +1261,35 @@ int launch(const GemmArgs& a, int epi, hipStream_t st) {
 }  // namespace
 
 struct GemmCand { int ring, bm, bn; float rate; int min_rounds; };
+// C[M, N] (+)= A[K, M]^T . W[K, N]: the TN form of gemm_t8.hip (weight gradients: A = dY [tokens, out], W = X [tokens, in]; reference:
+// torch autograd of nn.Linear inside accelerator.backward, train_cogvideox_control_to_video_sft.py:1093).  bf16 in, fp32 accumulate, bf16 out;
+// accumulate != 0: C += the product (gradient accumulation).  N % 192 == 0 or N % 256 == 0, M % 8 == 0; any K (rows past K are zeros).
+extern "C" int orv_gemm_tn_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, int accumulate,
+                                void* stream) {
+    ORV_REQUIRE(A && W && C, "orv_gemm_tn_bf16: null operand");
+    ORV_REQUIRE(M > 0 && N > 0 && K > 0, "orv_gemm_tn_bf16: empty problem M=%d N=%d K=%d", M, N, K);
+    ORV_REQUIRE(M % 8 == 0 && (N % 192 == 0 || N % 256 == 0), "orv_gemm_tn_bf16: M=%d must be a multiple of 8 and N=%d of 192 or 256", M, N);
+    ORV_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0 && lda >= M && ldw >= N && ldc >= N, "orv_gemm_tn_bf16: bad leading dimensions");
+    ORV_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 7) == 0, "orv_gemm_tn_bf16: misaligned operand");
+    ORV_REQUIRE(64L * lda * 2 + 2L * M < (1L << 32) && 64L * ldw * 2 + 2L * N < (1L << 32), "orv_gemm_tn_bf16: row stride too large");
+    GemmArgs a{};
+    a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)W; a.ldw = ldw; a.C = (bf16_t*)C; a.ldc = ldc;
+    a.M = M; a.N = N; a.K = K;
+    // tile width: the one whose tile count wastes less of its last round of CUs (ties: 256)
+    const int ncu = orv_num_cus();
+    auto waste = [&](int bn) {
+        if (N % bn) return 1e9;
+        const long tiles = (long)((M + 255) / 256) * (N / bn);
+        const long rounds = (tiles + ncu - 1) / ncu;
+        return (double)(rounds * ncu) * bn;            // CU-rounds x tile width ~ time
+    };
+    const int bn = waste(256) <= waste(192) ? 256 : 192;
+    a.tiles_n = N / bn;
+    a.tiles_m = (M + 255) / 256;
+    { static int wb = -1; if (wb < 0) { const char* e = getenv("ORV_GEMM_WALK_BACK"); wb = e ? atoi(e) : 2; } a.walk_back = wb == 2 ? 1 : 0; }
+    return launch_t8_tn(a, bn, accumulate ? 1 : 0, (hipStream_t)stream);
+}
+
 // ORV_GEMM_TILE="ring,bm,bn" / orv_gemm_force_tile() pin one candidate (sweeps, same-process A/B, the per-instantiation tests)
 static int g_force_ring = -1, g_force_bm = 0, g_force_bn = 0;
 extern "C" int orv_gemm_force_tile(int ring, int bm, int bn) {

@@ -68,6 +68,8 @@ __device__ __forceinline__ void tile_of_block(const GemmArgs& p, int& tm, int& t
 
 // gemm_t8.hip: launches gemm_t8_kernel<BN, EPI> (BN = 256 or 192); a.tiles_m / a.tiles_n must be set for BM = 256, BN
 int launch_t8(const GemmArgs& a, int bn, int epi, hipStream_t st);
+// gemm_t8.hip: TN form C[M, N] (+)= A[K, M]^T . W[K, N] (both operands row-major over the contraction index), BN = 256 or 192
+int launch_t8_tn(const GemmArgs& a, int bn, int accumulate, hipStream_t st);
 // gemm_t8.hip: the four-wave 256 x 256 experiment (ORV_GEMM_TILE=4,256,256)
 int launch_t4(const GemmArgs& a, int epi, hipStream_t st);
 

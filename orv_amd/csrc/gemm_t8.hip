@@ -1152,6 +1152,212 @@ int launch_t4_one(const GemmArgs& a, hipStream_t st) {
     return orv_check_launch("orv_gemm_bf16");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// TN form (round 4): C[M, N] (+)= A[K, M]^T . W[K, N] with BOTH operands row-major over the CONTRACTION index (the weight gradient
+// dW = dY^T X of training.py::_wgrad: A = dY [tokens, out], W = X [tokens, in]) - no orv_transpose_bf16 / transpose_colsum launches.
+// Same 8-phase schedule, tile sizes, LDS budget and instruction counts as gemm_t8_kernel (its K-tile macros are reused); what differs:
+//   * LDS image: a 1-KiB piece is 8 contraction rows x 64 columns (one 128-byte line per row and 8 lanes: full lines), region = 8 row groups
+//     x 2 column halves; 32-byte segment sg of row m sits at sg ^ f(m), f(m) = bit 1 of m | (bit 3 of m) << 1, so that the eight rows one
+//     half-wave of a transposing read touches fall into eight different 32-byte bank groups.
+//   * fragments: two ds_read_b64_tr_b16 per (block, k half) - lane i of a 16-lane group supplies 8 bytes of row (i >> 2) and receives column i
+//     of 4 consecutive rows; k half 1 = + 4 row groups, second read = + 4 rows.
+//   * the DMA is issued from inline asm (behind the builtin hipcc puts s_waitcnt vmcnt(0) in front of transposing reads); K position =
+//     64 rows of the wave-uniform base; K-tiles that reach past the last contraction row take a per-lane path whose rows >= K come from a
+//     zero page (both operands: the products vanish, nothing is masked afterwards).
+//   * columns are in natural order (a DMA chunk is 8 consecutive columns: no W-row permutation), so the epilogue stores 8-byte pieces; it is
+//     plain or accumulating (C += ...), nothing else: K = 12904 rows make the epilogue irrelevant.
+// Measured against the transposes + NT kernel: profiles/r4_gemm_tn.txt.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(256))) uint4 t8_zero_page[16];
+typedef short tn_v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char tn_lds_char;
+__device__ __forceinline__ void tn_glds_sv(const char* sbase, unsigned voff, const void* lds_dst) {
+    const unsigned long long u = (unsigned long long)(uintptr_t)sbase;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi_ = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    const unsigned long long su = ((unsigned long long)hi_ << 32) | lo;
+    const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_dst);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(su), "s"(d) : "memory", "m0");
+}
+__device__ __forceinline__ void tn_glds_v(const void* gsrc, const void* lds_dst) {
+    const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_dst);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(d) : "memory", "m0");
+}
+__device__ __forceinline__ bf16x8 tn_tr2(tn_lds_char* a) {
+    const tn_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_v4s*)(a));
+    const tn_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_v4s*)(a + 512));
+    union { bf16x8 v; tn_v4s h[2]; } u;
+    u.h[0] = lo; u.h[1] = hi;
+    return u.v;
+}
+#undef T8_SETUP_A
+#undef T8_SETUP_B
+#undef T8_NEXT_A
+#undef T8_NEXT_B
+#undef T8_GLDS
+#undef T8_ISSUE_A0
+#undef T8_ISSUE_A1
+#undef T8_ISSUE_B0
+#undef T8_ISSUE_B1
+#undef T8_READ_A
+#undef T8_READ_B01
+#undef T8_READ_B23
+template <int BN, int ACC>
+__global__ __launch_bounds__(512) void gemm_t8_tn_kernel(const GemmArgs p) {
+    constexpr int NBW = BN / 64;
+    constexpr int HALF = 16384;
+    constexpr int BUF = BN == 256 ? 65536 : 57344;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int nk = ((p.K + 127) / 128) * 2;              // K-tiles of 64 contraction rows, padded to an even count
+    const int nkfull = p.K / 64;                         // K-tiles with all 64 rows inside the operands
+
+    // ---- DMA side: this lane's row of a piece and its 16-byte chunk ----
+    const int r8 = lane >> 3, p8 = lane & 7;
+    const int mloc = wave * 8 + r8;                      // contraction row inside the K-tile
+    const int fdma = ((mloc >> 1) & 1) | (((mloc >> 3) & 1) << 1);
+    const int cch = (((p8 >> 1) ^ fdma) << 1) | (p8 & 1);   // logical 16-byte chunk (8 columns) of the 64-column piece held by physical chunk p8
+    char* const dst2 = smem + wave * 2048;
+    char* const dst1 = smem + 3 * HALF + wave * 1024;
+    unsigned oA0[2], oA1[2], oB0[2], oB1[2];
+    int kA0 = 0, kA1 = 0, kB0 = 0, kB1 = 0;
+    int tA0 = blockIdx.x, tA1 = blockIdx.x, tB0 = blockIdx.x, tB1 = blockIdx.x;
+#define T8_SETUP_A(OFF, H, TILE)                                                                                     \
+    {                                                                                                                \
+        int tm_, tn_;                                                                                                \
+        tile_of_index(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                                                 \
+        const int c0_ = tm_ * 256 + 64 * (H) + cch * 8;                                                              \
+        OFF[0] = (unsigned)(((long)mloc * p.lda + min(c0_, p.M - 8)) * 2);                                           \
+        OFF[1] = (unsigned)(((long)mloc * p.lda + min(c0_ + 128, p.M - 8)) * 2);                                     \
+    }
+#define T8_SETUP_B(OFF, H, TILE)                                                                                     \
+    {                                                                                                                \
+        int tm_, tn_;                                                                                                \
+        tile_of_index(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                                                 \
+        const int c0_ = tn_ * BN + 128 * (H) + cch * 8;                                                              \
+        OFF[0] = (unsigned)(((long)mloc * p.ldw + c0_) * 2);                                                         \
+        OFF[1] = (unsigned)(((long)mloc * p.ldw + c0_ + 64) * 2);                                                    \
+    }
+#define T8_NEXT_A(OFF, KC, TC, H)                                                                                    \
+    if (__builtin_expect(++KC == nk, 0)) { KC = 0; TC += gridDim.x; T8_SETUP_A(OFF, H, TC) }
+#define T8_NEXT_B(OFF, KC, TC, H)                                                                                    \
+    if (__builtin_expect(++KC == nk, 0)) { KC = 0; TC += gridDim.x; T8_SETUP_B(OFF, H, TC) }
+#define T8_GLDS(BASE, LD, KC, OFF, DST)                                                                              \
+    {                                                                                                                \
+        const char* const sb_ = (const char*)(BASE) + (long)(KC) * 128 * (LD);                                       \
+        if (__builtin_expect((KC) < nkfull, 1)) tn_glds_sv(sb_, OFF, DST);                                           \
+        else tn_glds_v((KC) * 64 + mloc < p.K ? (const void*)(sb_ + (OFF)) : (const void*)((const char*)t8_zero_page + p8 * 16), DST); \
+    }
+#define T8_ISSUE_A0(S) { T8_GLDS(p.A, p.lda, kA0, oA0[0], dst2 + (S) * BUF) T8_GLDS(p.A, p.lda, kA0, oA0[1], dst2 + (S) * BUF + 1024) T8_NEXT_A(oA0, kA0, tA0, 0) }
+#define T8_ISSUE_A1(S) { T8_GLDS(p.A, p.lda, kA1, oA1[0], dst2 + (S) * BUF + HALF) T8_GLDS(p.A, p.lda, kA1, oA1[1], dst2 + (S) * BUF + HALF + 1024) T8_NEXT_A(oA1, kA1, tA1, 1) }
+#define T8_ISSUE_B0(S) { T8_GLDS(p.W, p.ldw, kB0, oB0[0], dst2 + (S) * BUF + 2 * HALF) T8_GLDS(p.W, p.ldw, kB0, oB0[1], dst2 + (S) * BUF + 2 * HALF + 1024) T8_NEXT_B(oB0, kB0, tB0, 0) }
+#define T8_ISSUE_B1(S)                                                                                               \
+    {                                                                                                                \
+        if constexpr (BN == 256) { T8_GLDS(p.W, p.ldw, kB1, oB1[0], dst2 + (S) * BUF + 3 * HALF) T8_GLDS(p.W, p.ldw, kB1, oB1[1], dst2 + (S) * BUF + 3 * HALF + 1024) } \
+        else { T8_GLDS(p.W, p.ldw, kB1, oB1[0], dst1 + (S) * BUF) }                                                  \
+        T8_NEXT_B(oB1, kB1, tB1, 1)                                                                                  \
+    }
+    T8_SETUP_A(oA0, 0, tA0)
+    T8_SETUP_A(oA1, 1, tA1)
+    T8_SETUP_B(oB0, 0, tB0)
+    T8_SETUP_B(oB1, 1, tB1)
+
+    // ---- fragment reads ----
+    tn_lds_char* const smem3 = (tn_lds_char*)smem;
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const int fr = ((i16 >> 3) & 1) | ((g4 & 1) << 1);
+    const int lb2 = g4 * 2048 + (i16 >> 2) * 128 + (i16 & 3) * 8, lb1 = g4 * 1024 + (i16 >> 2) * 128 + (i16 & 3) * 8;
+    tn_lds_char* trA[4];
+    tn_lds_char* trB[2];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) trA[mb] = smem3 + lb2 + wr * 1024 + ((mb ^ fr) << 5);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) trB[t] = smem3 + 2 * HALF + lb2 + (wc >> 1) * 1024 + (((2 * (wc & 1) + t) ^ fr) << 5);
+    tn_lds_char* const trB1 = smem3 + 3 * HALF + lb1 + ((wc ^ fr) << 5);           // BN = 192: region 1 = one piece per row group
+#define T8_READ_A(MH, S)                                                                                             \
+    _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                                 \
+        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) fa[MH][mb][kh] = tn_tr2(trA[mb] + (S) * BUF + (MH) * HALF + kh * 8192);
+#define T8_READ_B01(S)                                                                                               \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                    \
+        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) fb[t][kh] = tn_tr2(trB[t] + (S) * BUF + kh * 8192);
+#define T8_READ_B23(S)                                                                                               \
+    _Pragma("unroll") for (int t = 0; t < NBW - 2; ++t)                                                              \
+        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
+            fb[2 + t][kh] = BN == 256 ? tn_tr2(trB[t] + (S) * BUF + HALF + kh * 8192) : tn_tr2(trB1 + (S) * BUF + kh * 4096);
+
+    f32x4 acc[2][4][NBW];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int c = 0; c < NBW; ++c) acc[a][b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[2][4][2], fb[NBW][2];
+
+    if constexpr (BN == 256) {
+        T8_ISSUE_A0(0) T8_ISSUE_B0(0) T8_ISSUE_A1(0) T8_ISSUE_B1(0)
+        T8_ISSUE_B0(1) T8_ISSUE_A0(1) T8_ISSUE_A1(1)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        T8_ISSUE_A0(0) T8_ISSUE_B0(0) T8_ISSUE_A1(0) T8_ISSUE_B1(0)
+        T8_ISSUE_B0(1) T8_ISSUE_A0(1)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    T8_BAR()
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (wr == 1) { T8_BAR() }
+        for (int kt = 0; kt < nk; kt += 2) {
+            if constexpr (BN == 256) { T8_KTILE_256(0) T8_KTILE_256(1) }
+            else { T8_KTILE_192(0) T8_KTILE_192(1) }
+        }
+        if (wr == 0) { T8_BAR() }
+        int tm, tn;
+        tile_of_index(p, tile, ntiles, tm, tn);
+        // epilogue: lane holds C[row = .. + i16][col = .. + 4 g4 + (0..3)] of every block: 8-byte pieces
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const int row = tm * 256 + wr * 128 + mh * 64 + mb * 16 + i16;
+                if (row < p.M) {
+#pragma unroll
+                    for (int t = 0; t < NBW; ++t) {
+                        const int col = tn * BN + (t < 2 ? 32 * wc + 16 * t : (BN == 256 ? 128 + 32 * wc + 16 * (t - 2) : 128 + 16 * wc)) + 4 * g4;
+                        f32x4 v = acc[mh][mb][t];
+                        bf16_t* cp = p.C + (long)row * p.ldc + col;
+                        if constexpr (ACC) {
+                            const uint2 u = *(const uint2*)cp;
+                            v[0] += bf2f(u.x & 0xffff); v[1] += bf2f(u.x >> 16); v[2] += bf2f(u.y & 0xffff); v[3] += bf2f(u.y >> 16);
+                        }
+                        *(uint2*)cp = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                    }
+                }
+            }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int c = 0; c < NBW; ++c) acc[a][b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int BN, int ACC>
+int launch_tn_one(const GemmArgs& a, hipStream_t st) {
+    constexpr int smem = 2 * (BN == 256 ? 65536 : 57344);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_t8_tn_kernel<BN, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    const int grid = min(a.tiles_m * a.tiles_n, orv_num_cus());
+    hipLaunchKernelGGL((gemm_t8_tn_kernel<BN, ACC>), dim3(grid), dim3(512), smem, st, a);
+    return orv_check_launch("orv_gemm_tn_bf16");
+}
+
 template <int BN, int EPI>
 int launch_one(const GemmArgs& a, hipStream_t st) {
     constexpr int smem = 2 * (BN == 256 ? 65536 : 57344) + 8 * 4096;      // two K-tile buffers + the epilogue scratch (160 KiB at BN = 256)
@@ -1169,6 +1375,12 @@ int launch_one(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 namespace orv_gemm {
+int launch_t8_tn(const GemmArgs& a, int bn, int accumulate, hipStream_t st) {
+    if (bn == 256) return accumulate ? launch_tn_one<256, 1>(a, st) : launch_tn_one<256, 0>(a, st);
+    if (bn == 192) return accumulate ? launch_tn_one<192, 1>(a, st) : launch_tn_one<192, 0>(a, st);
+    orv_set_error("orv_gemm_tn_bf16: no kernel for BN=%d", bn);
+    return ORV_EINVAL;
+}
 int launch_t4(const GemmArgs& a, int epi, hipStream_t st) {
     switch (epi) {
         case 0: return launch_t4_one<0>(a, st);

@@ -146,6 +146,14 @@ def layernorm_modulate(x, y, gamma, beta, scale, shift, mod_b, mod_g, grp: Group
     return y
 
 
+def gemm_tn(A, W, C, M, N, K, accumulate=False, lda=None, ldw=None, ldc=None):
+    """C[M, N] (+)= A[K, M]^T . W[K, N]  (both operands row-major over the K contraction rows: dW = dY^T X without transposes)."""
+    _need(A, BF16, "A"), _need(W, BF16, "W"), _need(C, BF16, "C")
+    check(lib().orv_gemm_tn_bf16(_p(A), lda or M, _p(W), ldw or N, _p(C), ldc or N, M, N, K, int(bool(accumulate)), _stream()),
+          "orv_gemm_tn_bf16")
+    return C
+
+
 def modulation_tables(temb, action_emb, w_ptrs, b_ptrs, n_tab, B, T, E, width, text, out=None):
     """All AdaLN tables of a forward: out fp32 [n_tab, B, 1+T, width]; w_ptrs/b_ptrs int64 device tensors of pointers."""
     _need(temb, BF16, "temb")

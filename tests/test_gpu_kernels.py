@@ -153,6 +153,27 @@ def test_gemm_operand_of_4gib_and_more_leaves_the_t8_kernel():
     del big
 
 
+@pytest.mark.parametrize("M,N,K,acc", [(512, 256, 640, False), (1920, 1920, 3226, False), (1920, 7680, 1000, True), (5760, 1920, 777, False),
+                                        (264, 192, 64, True), (1920, 768, 12904, False)])
+def test_gemm_tn_weight_gradient_form(M, N, K, acc):
+    """orv_gemm_tn_bf16: C[M, N] (+)= A[K, M]^T . W[K, N] from row-major operands (transposing LDS reads, zero page behind the last contraction
+    row): both tile widths, contraction lengths that are not multiples of 64 / 128, a ragged last row tile (M % 256 != 0), accumulation."""
+    from orv_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W = q(torch.randn(K, M, generator=g) * 0.5), q(torch.randn(K, N, generator=g) * 0.5)
+    C0 = q(torch.randn(M, N, generator=g))
+    C = C0.to(dev, BF).clone() if acc else torch.full((M, N), float("nan"), dtype=BF, device=dev)
+    ops.gemm_tn(A.to(dev, BF), W.to(dev, BF), C, M, N, K, accumulate=acc)
+    ref = A.t() @ W / 1.0
+    if acc:
+        ref = ref + C0
+    scale = (K ** 0.5) * 0.25
+    assert torch.isfinite(C.float()).all()
+    err = (C.float().cpu() - ref).abs().max().item()
+    assert err <= 1.6e-2 * ref.abs().max().item() + 1e-2 * scale, (err, ref.abs().max().item())
+
+
 def _attention_reference(qkv, B, S, H, gq, bq, gk, bk, rope, nt):
     D = H * 64
     x = qkv.view(B, S, 3, H, 64).permute(2, 0, 3, 1, 4)      # [3,B,H,S,64]
