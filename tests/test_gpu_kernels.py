@@ -174,6 +174,29 @@ def test_gemm_tn_weight_gradient_form(M, N, K, acc):
     assert err <= 1.6e-2 * ref.abs().max().item() + 1e-2 * scale, (err, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("Mtok", [3300, 3226])
+def test_gemm_tn_is_bit_identical_to_the_transposes_plus_nt_path(Mtok):
+    """The opt-in weight-gradient path (ORV_WGRAD_TN=1: orv_gemm_tn_bf16 on the row-major dY, X) against what training._wgrad does by default
+    (orv_transpose_bf16 twice + the NT kernel) at a training shape of one clip: same products, same fp32 accumulation order per K-tile -> equal bits."""
+    from orv_amd import ops
+    dev = _dev()
+    N, K = 5760, 1920
+    g = torch.Generator(device=dev).manual_seed(5)
+    dY = (torch.randn(Mtok, N, device=dev, generator=g) * 0.5).to(BF)
+    X = (torch.randn(Mtok, K, device=dev, generator=g) * 0.5).to(BF)
+    dW_tn = torch.empty(N, K, dtype=BF, device=dev)
+    ops.gemm_tn(dY, X, dW_tn, N, K, Mtok)
+    dYT, XT = ops.transpose(dY, Mtok, N), ops.transpose(X, Mtok, K)
+    dW_nt = torch.empty(N, K, dtype=BF, device=dev)
+    ops.gemm(dYT, XT, None, dW_nt, N, K, dYT.shape[1])
+    ref = dY.float().t() @ X.float()
+    close(dW_nt, ref.cpu())
+    if dYT.shape[1] % 128 == 0:            # the NT call is on the t8 kernel (same K-tile order): bit-identical
+        assert torch.equal(dW_tn, dW_nt)
+    else:
+        close(dW_tn, ref.cpu())
+
+
 def _attention_reference(qkv, B, S, H, gq, bq, gk, bk, rope, nt):
     D = H * 64
     x = qkv.view(B, S, 3, H, 64).permute(2, 0, 3, 1, 4)      # [3,B,H,S,64]
