@@ -192,9 +192,12 @@ __global__ __launch_bounds__(256) void gated_bwd_kernel(const bf16_t* __restrict
         for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
-                const int c = tid + 256 * i;
+                // unconditional, clamped (round 4): behind `if (c < nchunk)` hipcc branched around every load and waited for it - the eight
+                // loads of a pass went out one round trip after the other (cdna guide, ".s-level traps" (c))
+                const int c = min(tid + 256 * i, nchunk - 1);
                 const long row = (long)b * seq + min(rb + k, s1 - 1);
-                if (c < nchunk) { ud[k][i] = *(const uint4*)(dout + row * D + c * 8); uy[k][i] = *(const uint4*)(y + row * D + c * 8); }
+                ud[k][i] = *(const uint4*)(dout + row * D + c * 8);
+                uy[k][i] = *(const uint4*)(y + row * D + c * 8);
             }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -302,20 +305,18 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const LnBwdArgs p) {
             ps[k] = 0.f;
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
-                if (live[i] && k < nr) {
-                    const int c = tid + 256 * i;
-                    const uint4 ux = *(const uint4*)(p.x + xrow[k] * D + c * 8);
-                    const uint4 ud = *(const uint4*)(p.dy + row * D + c * 8);
-                    const uint32_t wx[4] = {ux.x, ux.y, ux.z, ux.w}, wd[4] = {ud.x, ud.y, ud.z, ud.w};
+                // unconditional, clamped loads (round 4; the values of dead chunks / rows are zeroed afterwards): behind
+                // `if (live && k < nr)` every load sat in its own branch with its own wait
+                const int c = min(tid + 256 * i, nchunk - 1);
+                const bool on = live[i] && k < nr;
+                const uint4 ux = *(const uint4*)(p.x + xrow[k] * D + c * 8);
+                const uint4 ud = *(const uint4*)(p.dy + row * D + c * 8);
+                const uint32_t wx[4] = {ux.x, ux.y, ux.z, ux.w}, wd[4] = {ud.x, ud.y, ud.z, ud.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        xv[k][i][2 * e] = bf2f(wx[e] & 0xffff); xv[k][i][2 * e + 1] = bf2f(wx[e] >> 16);
-                        dv[k][i][2 * e] = bf2f(wd[e] & 0xffff); dv[k][i][2 * e + 1] = bf2f(wd[e] >> 16);
-                        ps[k] += xv[k][i][2 * e] + xv[k][i][2 * e + 1];
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) xv[k][i][e] = dv[k][i][e] = 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    xv[k][i][2 * e] = on ? bf2f(wx[e] & 0xffff) : 0.f; xv[k][i][2 * e + 1] = on ? bf2f(wx[e] >> 16) : 0.f;
+                    dv[k][i][2 * e] = on ? bf2f(wd[e] & 0xffff) : 0.f; dv[k][i][2 * e + 1] = on ? bf2f(wd[e] >> 16) : 0.f;
+                    ps[k] += xv[k][i][2 * e] + xv[k][i][2 * e + 1];
                 }
             }
         }
