@@ -435,10 +435,18 @@ def main():
     # events around every GEMM / attention launch) cannot be taken inside a graph: it comes from a SECOND, eager loop after the
     # timed region.  --eager times the eager path instead.
     use_graph = not args.eager
-    fwd = model
-    if use_graph:
-        from orv_amd.cogvideox_control import GraphedTransformer
-        fwd = GraphedTransformer(model)
+    from orv_amd.cogvideox_control import CogVideoXImageToVideoPipelineTraj
+
+    def default_forward(m):
+        """The transformer forward exactly as ``CogVideoXImageToVideoPipelineTraj.__call__`` makes it (its ``transformer_forward``): by
+        DEFAULT - nothing enabled by the caller - that is HIP-graph replay; --eager forbids it the way a user would
+        (``enable_hip_graph(False)``)."""
+        p_ = CogVideoXImageToVideoPipelineTraj(transformer=m, scheduler=sched)
+        if not use_graph:
+            p_.enable_hip_graph(False)
+        return p_.transformer_forward
+
+    fwd = default_forward(model)
 
     def make_step(fn, Bn, lat_img, prm, ctl):
         @torch.no_grad()                    # the reference sampler runs under torch.no_grad (cogvideox_control.py:1228)
@@ -509,7 +517,7 @@ def main():
         # b1: the demo shape (inference_control_to_video.py runs ONE clip), graph-replayed
         l1, il1, p1, a1 = synthetic_inputs(1, dev, torch.bfloat16)
         model.action_embed.forced_mask = torch.zeros(1, dtype=torch.bool)
-        s1 = make_step(GraphedTransformer(model) if use_graph else model, 1, il1, p1, {"actions": a1})
+        s1 = make_step(default_forward(model), 1, il1, p1, {"actions": a1})
         x1 = l1
         for i in range(3):
             x1 = s1(i, x1)
@@ -541,7 +549,7 @@ def main():
         keep_sb = cc.Attention.score_bound
         try:
             cc.Attention.score_bound = lambda self, scale: None
-            so = make_step(GraphedTransformer(model) if use_graph else model, B, image_latents, prompt, controls)
+            so = make_step(default_forward(model), B, image_latents, prompt, controls)
             legs["attn_online"] = {"workload": "configs[1] at B = %d with the online-softmax attention kernel in every block (no score bound), 10 steps" % B,
                                    "ms_per_step": round(timed_steps(so, latents, 3, 10), 3),
                                    "fixed_shift_valid_up_to_log2_units": 90.0, "random_init_bound_log2_units": round(float(keep_sb(model.transformer_blocks[0].attn1, 0.125)), 2)}
@@ -557,7 +565,7 @@ def main():
             gcond = torch.Generator().manual_seed(44)
             depths = torch.randn(B, 5, 32, 40, 60, generator=gcond).to(dev, torch.bfloat16)
             labels = torch.randn(B, 5, 32, 40, 60, generator=gcond).to(dev, torch.bfloat16)
-            sc = make_step(GraphedTransformer(mc) if use_graph else mc, B, image_latents, prompt,
+            sc = make_step(default_forward(mc), B, image_latents, prompt,
                            {"actions": actions, "depths": depths, "labels": labels})
             legs["cond"] = {"workload": "configs[3]: occupancy-conditioned CogVideoX-2B (visual_guidance, depth + label control maps), B = %d, 5 steps" % B,
                             "ms_per_step": round(timed_steps(sc, latents, 3, 5), 3), "timed_path": "hip-graph replay" if use_graph else "eager"}
@@ -673,7 +681,8 @@ def main():
                 "unit": "TFLOP/s", "frac": round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "mfma_busy": mfma_busy, "clock_ghz_under_pmc": clock, "launches": dom["launches"], "avg_ms": dom["avg_ms"]},
             "kernels": kernels[:8],
-            "timed_path": "hip-graph replay of the transformer forward (bit-identical to eager)" if use_graph else "eager launches",
+            "timed_path": ("default __call__ path: CogVideoXImageToVideoPipelineTraj.transformer_forward -> HIP-graph replay of the transformer forward "
+                           "(automatic, bit-identical to eager)") if use_graph else "eager launches (enable_hip_graph(False))",
             "eager_ms_per_step": round(eager_ms, 3),
             "kernel_timeline": f"HIP events on the launch stream over a separate eager loop of {n_tl} steps after the timed region",
             "lib": {"path": os.path.relpath(LIB_PATH, ROOT), "orv_version": int(lib().orv_version())},

@@ -157,8 +157,24 @@ typedef struct {
      * receives the raw projection.  Equivalent to epilogue 0 followed by orv_qkv_prep without RoPE, minus the V^T copy
      * (use orv_head_transpose for that). */
     const void *qn_gamma_q, *qn_beta_q, *qn_gamma_k, *qn_beta_k; float qn_eps, qn_premul; int qn_heads;
+    /* Packed operand layout "P16" (round 5, gemm_d8.hip).  A [rows, cols] bf16 matrix (cols % 32 == 0) stored as 1-KiB blocks of 16 rows x 32
+     * columns, block (R, c) at byte ((R * cols / 32) + c) * 1024, element (r, k) of a block at ((k / 8) * 16 + r) * 16 + (k % 8) * 2 - the
+     * order in which one wave instruction of v_mfma_f32_16x16x32_bf16 wants a 16 x 32 operand, so a GEMM reads its A operand straight into
+     * registers with contiguous 1-KiB loads.  The buffer holds orv_packed_rows(rows) = rows rounded up to 256 row slots (padding rows are
+     * never interpreted).  a_packed: A is in that layout (lda == K; needs K % 192 == 0); c_packed: C is written in it (ldc == N; epilogues
+     * 0 / 1, no cmap / Y) - the FeedForward hidden state between cogvideox_control.py:439 and :440 never exists row-major.  Producers:
+     * orv_pack_rows16, orv_layernorm_modulate (out_packed), orv_gemm_bf16 (c_packed), orv_attention_fwd* (out_packed). */
+    int a_packed, c_packed;
 } orv_gemm_t;
 int orv_gemm_bf16(const orv_gemm_t* g, void* stream);
+/* Row slots of a packed P16 buffer for `rows` rows (rounded up to the 256-row GEMM tile). */
+long orv_packed_rows(long rows);
+/* dst (P16 layout, orv_packed_rows(M) x K) = src [M, K] row-major (ld_src elements per row), bit copies; padding rows are zero-filled.
+ * The reference has no such step (its operands stay row-major inside torch.nn.functional.linear, cogvideox_control.py:232-234,263,439-440):
+ * this is the entry of tensors that no packed-writing kernel produced (tests, the first GEMM after a foreign op). */
+int orv_pack_rows16(const void* src, long ld_src, void* dst, int M, int K, void* stream);
+/* Inverse of orv_pack_rows16 (rows [0, M)). */
+int orv_unpack_rows16(const void* src, void* dst, long ld_dst, int M, int K, void* stream);
 /* Kernel symbol (as rocprofv3 prints it, e.g. "gemm_pp_kernel<192, 5, 1>") that orv_gemm_bf16 launches for this shape on this
  * device: the tile is chosen by a cost model over all candidates, so callers that label timings ask. */
 int orv_gemm_kernel_name(int M, int N, int K, int epilogue, char* buf, int len);

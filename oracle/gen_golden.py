@@ -115,11 +115,13 @@ def forward_case(cc, utils, name, cfg_over, b=2, t=3, n_act=8, mask=(False, Fals
 
 
 def pipeline_case(cc, name, sched_cls, steps=3, guidance=1.0, seed=1234, with_actions=True, dtype=torch.float32,
-                  dynamic_cfg=False):
+                  dynamic_cfg=False, keep_steps=None):
     """ORV's own ``CogVideoXImageToVideoPipelineTraj.__call__`` (prepare_latents + denoise loop) on a tiny model.
     ``dtype=torch.bfloat16`` runs the reference the way its entry points do (inference_control_to_video.py:31,95): every
     ``randn_tensor`` draw (image-latent sample, initial latents, the DPM noise) then consumes the CPU generator in bf16,
-    which is what the product does, so those fixtures can be replayed with ``generator=`` instead of pre-drawn tensors."""
+    which is what the product does, so those fixtures can be replayed with ``generator=`` instead of pre-drawn tensors.
+    ``keep_steps`` (1-based) stores only those steps' latents - the 50-step loops (cogvideox_control.py:1237 default,
+    :1402-1473) keep steps 1, 10, 25, 50."""
     from . import leaf
     torch.manual_seed(seed)
     cfg = {**TINY, "sample_frames": 9}
@@ -153,14 +155,19 @@ def pipeline_case(cc, name, sched_cls, steps=3, guidance=1.0, seed=1234, with_ac
                    controls_or_guidances={"actions": actions} if with_actions else {}, callback_on_step_end=cb)
     tensors = {"in.image": image.float(), "in.prompt_embeds": e.float(), "in.negative_prompt_embeds": ne.float(),
                "in.actions": actions.float(), "out.latents": out.frames.float()}
+    assert len(trace) == steps
     for i, tr in enumerate(trace):
-        tensors[f"out.step{i}"] = tr.float()
+        if keep_steps is None or (i + 1) in keep_steps:
+            tensors[f"out.step{i}"] = tr.float()
     for k, v in model.state_dict().items():
         tensors["w." + k] = v.float()
     full_cfg = {k: v for k, v in dict(model.config).items() if k != "kwargs"}
-    _save(name, full_cfg, tensors, dict(steps=steps, guidance=guidance, gen_seed=4321, scheduler=sched_cls.__name__,
-                                         with_actions=with_actions, dtype=str(dtype).replace("torch.", ""),
-                                         dynamic_cfg=dynamic_cfg, final_guidance=float(pipe.guidance_scale)))
+    extra = dict(steps=steps, guidance=guidance, gen_seed=4321, scheduler=sched_cls.__name__,
+                 with_actions=with_actions, dtype=str(dtype).replace("torch.", ""),
+                 dynamic_cfg=dynamic_cfg, final_guidance=float(pipe.guidance_scale))
+    if keep_steps is not None:
+        extra["keep_steps"] = sorted(keep_steps)
+    _save(name, full_cfg, tensors, extra)
 
 
 def pipeline_bf16_cases(cc):
@@ -172,6 +179,16 @@ def pipeline_bf16_cases(cc):
     pipeline_case(cc, "pipe_ddim_bf16", leaf.CogVideoXDDIMScheduler, dtype=bf)
     pipeline_case(cc, "pipe_dpm_dyncfg_bf16", leaf.CogVideoXDPMScheduler, steps=4, guidance=3.0, with_actions=False, dtype=bf,
                   dynamic_cfg=True)
+
+
+def pipeline_50step_cases(cc):
+    """configs[1] IS the 50-step loop (``num_inference_steps: int = 50``, cogvideox_control.py:1237; the loop :1402-1473): the
+    reference run bf16 end to end for 50 steps with DDIM and with DPM (two noise draws per step from the CPU generator), latents
+    kept at steps 1, 10, 25, 50 (50-step latents rel-L2 <= 5e-2 with identical noise)."""
+    from . import leaf
+    bf = torch.bfloat16
+    pipeline_case(cc, "pipe_ddim50_bf16", leaf.CogVideoXDDIMScheduler, steps=50, dtype=bf, keep_steps=(1, 10, 25, 50))
+    pipeline_case(cc, "pipe_dpm50_bf16", leaf.CogVideoXDPMScheduler, steps=50, dtype=bf, keep_steps=(1, 10, 25, 50))
 
 
 def misc_case(cc, comp, utils):
@@ -296,6 +313,8 @@ def main():
     cc, comp, utils = ref_harness.load_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "pipe_bf16":    # round-2 additions only
         return pipeline_bf16_cases(cc)
+    if len(sys.argv) > 1 and sys.argv[1] == "pipe50":       # round-5 additions only
+        return pipeline_50step_cases(cc)
     forward_case(cc, utils, "fwd_actions", {})
     forward_case(cc, utils, "fwd_actions_masked", {}, mask=(True, False))
     forward_case(cc, utils, "fwd_cond", {"visual_guidance": True}, cond=True)
@@ -314,6 +333,7 @@ def main():
     pipeline_case(cc, "pipe_ddim_cfg", __import__("oracle.leaf", fromlist=["x"]).CogVideoXDDIMScheduler, guidance=3.0,
                   with_actions=False)
     pipeline_bf16_cases(cc)
+    pipeline_50step_cases(cc)
     misc_case(cc, comp, utils)
     collate_case()
     bucket_sampler_case()

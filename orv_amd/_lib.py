@@ -27,7 +27,7 @@ class Gemm(Structure):
                 ("R", c_void_p), ("ldr", c_int), ("r_mod", c_int), ("gate", c_void_p), ("gate_b", c_long),
                 ("gate_g", c_long), ("grp", Groups), ("cmap", RowMap), ("Y", c_void_p), ("ldy", c_int),
                 ("qn_gamma_q", c_void_p), ("qn_beta_q", c_void_p), ("qn_gamma_k", c_void_p), ("qn_beta_k", c_void_p),
-                ("qn_eps", c_float), ("qn_premul", c_float), ("qn_heads", c_int)]
+                ("qn_eps", c_float), ("qn_premul", c_float), ("qn_heads", c_int), ("a_packed", c_int), ("c_packed", c_int)]
 
 
 class Conv(Structure):
@@ -62,6 +62,9 @@ SIGNATURES = {
     "orv_gemm_force_tile": (c_int, [c_int, c_int, c_int]),
     "orv_gemm_tn_bf16": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p]),
     "orv_gemm_bf16": (c_int, [POINTER(Gemm), c_void_p]),
+    "orv_packed_rows": (c_long, [c_long]),
+    "orv_pack_rows16": (c_int, [c_void_p, c_long, c_void_p, c_int, c_int, c_void_p]),
+    "orv_unpack_rows16": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
     "orv_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                   c_float, c_void_p]),
     "orv_attention_fwd_bounded": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p]),

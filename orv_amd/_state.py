@@ -9,6 +9,27 @@ def bump_weights_epoch() -> None:
     weights_epoch[0] += 1
 
 
+# Bumped whenever ANY module registers a parameter (construction, ``m.weight = nn.Parameter(...)``, ``load_state_dict(assign=True)``:
+# all go through ``Module.register_parameter``).  Caches that hold Parameter OBJECTS (GraphedTransformer's parameter list) re-collect
+# when it moves - a replaced Parameter keeps neither the identity nor the storage of the old one, and the old object's ``_version`` /
+# ``data_ptr`` never change again.
+param_epoch = [0]
+_param_hook = []
+
+
+def watch_parameter_registration() -> None:
+    """Install (once per process) torch's global parameter-registration hook that bumps ``param_epoch``."""
+    if _param_hook:
+        return
+    from torch.nn.modules.module import register_module_parameter_registration_hook
+
+    def _bump(module, name, param):
+        param_epoch[0] += 1
+        return None
+
+    _param_hook.append(register_module_parameter_registration_hook(_bump))
+
+
 # Gradient destinations registered by the fused optimizer (id(parameter) -> its segment of the flat bf16 gradient buffer, viewed in
 # the parameter's shape): the hand-written backward writes a weight gradient straight into its segment instead of into a
 # temporary the optimizer copies later (3.4 GB less traffic and memory per 2B step).

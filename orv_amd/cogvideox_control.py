@@ -837,6 +837,10 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
 _FUSE_QKNORM = os.environ.get("ORV_FUSED_QKNORM", "1") != "0"      # A/B switch: 0 = projection + orv_qkv_prep
 
 
+class _NotCapturable(TypeError):
+    """A call argument of a kind ``GraphedTransformer`` cannot hold in static buffers: the caller falls back to eager launches."""
+
+
 class GraphedTransformer:
     """One denoise step's transformer forward replayed from a HIP graph (``torch.cuda.CUDAGraph`` over the library's
     launches on the capture stream): ~330 kernel launches become one submission, which matters when the step is short
@@ -855,6 +859,7 @@ class GraphedTransformer:
         self.tr = transformer
         self.max_entries = max_entries
         self._state = OrderedDict()
+        _state.watch_parameter_registration()
 
     @staticmethod
     def _flatten(kw):
@@ -875,12 +880,12 @@ class GraphedTransformer:
                     elif vv is None:
                         sub.append((kk, None))
                     else:
-                        raise TypeError(f"GraphedTransformer: unsupported entry {k}[{kk!r}] of type {type(vv).__name__}")
+                        raise _NotCapturable(f"GraphedTransformer: unsupported entry {k}[{kk!r}] of type {type(vv).__name__}")
                 desc.append((k, "dict", tuple(sub)))
             elif v is None or isinstance(v, (bool, int, float, str)):
                 desc.append((k, "v", v))
             else:
-                raise TypeError(f"GraphedTransformer: unsupported argument {k} of type {type(v).__name__}")
+                raise _NotCapturable(f"GraphedTransformer: unsupported argument {k} of type {type(v).__name__}")
         return leaves, tuple(desc)
 
     @staticmethod
@@ -901,17 +906,18 @@ class GraphedTransformer:
         return out
 
     def _weights_version(self):
-        """In-place edits bump ``_version``; storage moves (``p.data = ...``: FusedAdamW's flat layout, ``.to()``,
-        ``load_state_dict(assign=True)``) change ``data_ptr``; parameters added, removed or replaced change the module's
-        parameter COUNT or identities.  The parameter list is cached (the module walk is the expensive part of this key on the
-        B = 1 path the graph exists to speed up) and re-collected whenever the cheap count no longer matches; every data_ptr
-        enters the key (a sampled subset missed moves of the unsampled ones)."""
+        """In-place edits bump ``_version``; storage moves (``p.data = ...``: FusedAdamW's flat layout, ``.to()``) change
+        ``data_ptr``; a parameter REPLACED by another object (``m.weight = nn.Parameter(...)``, ``load_state_dict(assign=True)``),
+        added or removed goes through ``Module.register_parameter`` / ``__delattr__``: the process-wide registration hook
+        (``_state.param_epoch``) and the parameter count tell, and the cached parameter list is re-collected then (the
+        old list kept the replaced objects, whose identity, version and storage never change again, and the graph replayed the
+        old weights).  The per-call cost is one pass over the cached list - no module walk on the B = 1 path the graph exists
+        to speed up; every data_ptr enters the key (a sampled subset missed moves of the unsampled ones)."""
         ps = getattr(self, "_plist", None)
-        n_now = sum(len(m._parameters) for m in self.tr.modules())
-        if ps is None or self._pcount != n_now:
+        if ps is None or self._pepoch != _state.param_epoch[0]:
             ps = self._plist = list(self.tr.parameters())
-            self._pcount = n_now
-        return (sum(p._version for p in ps), hash(tuple(p.data_ptr() for p in ps)), hash(tuple(map(id, ps))))
+            self._pepoch = _state.param_epoch[0]
+        return (len(ps), sum(p._version for p in ps), hash(tuple(p.data_ptr() for p in ps)), hash(tuple(map(id, ps))))
 
     def __call__(self, hidden_states, encoder_hidden_states, timestep, **kw):
         kw = dict(kw, hidden_states=hidden_states, encoder_hidden_states=encoder_hidden_states, timestep=timestep)
@@ -976,6 +982,7 @@ class CogVideoXImageToVideoPipelineTraj:
         self.vae_scaling_factor_image = getattr(vcfg, "scaling_factor", 1.15258426) if vcfg is not None else 1.15258426
         self._guidance_scale, self._interrupt, self._num_timesteps = 1.0, False, 0
         self._graphed: Optional[GraphedTransformer] = None
+        self._graph_mode: Optional[bool] = None      # None: automatic (see transformer_forward); True / False: enable_hip_graph()
         from .components import VideoProcessor
         self.video_processor = VideoProcessor(vae_latent_channels=getattr(vcfg, "latent_channels", 16) if vcfg is not None else 16,
                                               vae_scale_factor=self.vae_scale_factor_spatial)          # :1110-1113
@@ -1167,9 +1174,32 @@ class CogVideoXImageToVideoPipelineTraj:
         return getattr(out, "sample", out)
 
     def enable_hip_graph(self, enabled: bool = True):
-        """Replay the transformer forward of each denoise step from a HIP graph (see ``GraphedTransformer``)."""
+        """Force (``True``) or forbid (``False``) replaying the transformer forward of each denoise step from a HIP graph (see
+        ``GraphedTransformer``).  Without this call the choice is automatic: ``__call__`` - the surface the reference's entry points
+        use unchanged, inference_control_to_video.py:122-146 - replays from a graph whenever it can (below)."""
+        self._graph_mode = bool(enabled)
         self._graphed = GraphedTransformer(self.transformer) if enabled else None
         return self
+
+    def transformer_forward(self, **kw):
+        """One transformer forward of the denoise loop (the call at cogvideox_control.py:1415-1425), the way ``__call__`` makes it.
+        Default = HIP-graph replay (bit-identical to the eager launches - tests/test_gpu_model.py - and ~1 ms per B = 4 step / ~2.5 ms per
+        B = 1 step faster: no launch gaps): on a GPU, outside autograd, unless ``enable_hip_graph(False)`` or ``ORV_HIP_GRAPH=0`` said no.
+        The first call per (shapes, weight version) runs eagerly, the second is captured, later ones replay; arguments the graph
+        cannot hold in static buffers (``_NotCapturable``) and CPU tensors take the eager launches."""
+        tr = self.transformer
+        use = self._graph_mode
+        if use is None:
+            use = (os.environ.get("ORV_HIP_GRAPH", "1") != "0" and kw["hidden_states"].is_cuda and not torch.is_grad_enabled()
+                   and not tr.training)
+        if use:
+            if self._graphed is None or self._graphed.tr is not tr:
+                self._graphed = GraphedTransformer(tr)
+            try:
+                return self._graphed(**kw)
+            except _NotCapturable:
+                pass
+        return tr(**kw)
 
     def to(self, device=None, dtype=None):
         """``pipe.to(device, dtype=dtype)`` (inference_control_to_video.py:95): every attached torch module follows."""
@@ -1318,8 +1348,7 @@ class CogVideoXImageToVideoPipelineTraj:
             img_in = torch.cat([image_latents] * 2) if do_cfg else image_latents
             model_in = torch.cat([x_in, img_in], dim=2)
             tvec = torch.full((model_in.shape[0],), t, device=device, dtype=torch.int64)
-            fwd = self._graphed if self._graphed is not None else tr
-            noise_pred = fwd(hidden_states=model_in, encoder_hidden_states=prompt_embeds, timestep=tvec, ofs=ofs_emb,
+            noise_pred = self.transformer_forward(hidden_states=model_in, encoder_hidden_states=prompt_embeds, timestep=tvec, ofs=ofs_emb,
                              image_rotary_emb=image_rotary_emb, attention_kwargs=attention_kwargs,
                              controls_or_guidances=controls, return_dict=False, num_views=num_views)[0]
             gs = guidance_scale

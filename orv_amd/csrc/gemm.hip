@@ -1261,6 +1261,15 @@ int launch(const GemmArgs& a, int epi, hipStream_t st) {
 }  // namespace
 
 struct GemmCand { int ring, bm, bn; float rate; int min_rounds; };
+// relative rates of the d8 candidates (gemm_d8.hip); -DORV_D8_RATE_256=... / _192 at build time for A/B libraries
+#ifndef ORV_D8_RATE_256
+#define ORV_D8_RATE_256 1.29f
+#endif
+#ifndef ORV_D8_RATE_192
+#define ORV_D8_RATE_192 1.21f
+#endif
+#define D8_RATE_256 ORV_D8_RATE_256
+#define D8_RATE_192 ORV_D8_RATE_192
 // C[M, N] (+)= A[K, M]^T . W[K, N]: the TN form of gemm_t8.hip (weight gradients: A = dY [tokens, out], W = X [tokens, in]; reference:
 // torch autograd of nn.Linear inside accelerator.backward, train_cogvideox_control_to_video_sft.py:1093).  bf16 in, fp32 accumulate, bf16 out;
 // accumulate != 0: C += the product (gradient accumulation).  N % 192 == 0 or N % 256 == 0, M % 8 == 0; any K (rows past K are zeros).
@@ -1305,12 +1314,14 @@ extern "C" int orv_gemm_force_tile(int ring, int bm, int bn) {
 // what matters at small batch, where a "better" tile that needs one more, nearly empty, round loses to a smaller one that
 // fills the chip (B = 1: N = 1920 GEMMs take 195 tiles of 256x128 instead of 260 of 128x192).
 // wide: an operand spans 4 GiB or more - the t8 kernel addresses A and W with 32-bit byte offsets and is skipped
-static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int heads = 0, bool wide = false) {
+static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int heads = 0, bool wide = false, bool packed = false) {
     static const GemmCand cands[] = {
         // ring = 3: the 16x16x32 8-phase kernel of gemm_t8.hip (persistent, BK = 64; needs an even number of K-tiles)
         {3, 256, 256, 1.29f, 0}, {3, 256, 192, 1.21f, 0},
         // ring = 4: four-wave 256 x 256 experiment of gemm_t8.hip - forced only (rate 0.01 never wins)
         {4, 256, 256, 0.01f, 0},
+        // ring = 5: gemm_d8.hip (round 5) - A straight to registers two K-tiles ahead, W through four LDS buffers; needs K % 192 == 0
+        {5, 256, 256, D8_RATE_256, 0}, {5, 256, 192, D8_RATE_192, 0},
         // ring = 2: the phased (8-phase, BK = 64) persistent kernel; needs an even number of K-tiles
         // (256x384 does not fit: 192 accumulator + 64 fragment registers of the 256 a wave gets at two waves per SIMD)
         {2, 256, 256, 1.10f, 0}, {2, 256, 128, 0.80f, 0},
@@ -1332,6 +1343,8 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
     if (no_phased < 0) { const char* e = getenv("ORV_GEMM_PHASED"); no_phased = (e && atoi(e) == 0) ? 1 : 0; }
     static int no_t8 = -1;       // ORV_GEMM_T8=0: A/B switch for the t8 kernel
     if (no_t8 < 0) { const char* e = getenv("ORV_GEMM_T8"); no_t8 = (e && atoi(e) == 0) ? 1 : 0; }
+    static int no_d8 = -1;       // ORV_GEMM_D8=0: A/B switch for the d8 kernel
+    if (no_d8 < 0) { const char* e = getenv("ORV_GEMM_D8"); no_d8 = (e && atoi(e) == 0) ? 1 : 0; }
     static int no384 = -1;   // ORV_GEMM_BN384=0: A/B switch for the 384-wide variant
     if (no384 < 0) { const char* e = getenv("ORV_GEMM_BN384"); no384 = (e && atoi(e) == 0) ? 1 : 0; }
     const int ncu = orv_num_cus();
@@ -1342,8 +1355,11 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
         if (c.ring == 2 && (K % 128 != 0 || no_phased)) continue;
         if (c.ring == 3 && (K % 128 != 0 || no_t8 || wide || (epilogue == 4 && c.bn != 256))) continue;
         if (c.ring == 4 && (K % 128 != 0 || wide || epilogue > 2 || force_ring != 4)) continue;
+        // ring 5 reads A in the packed P16 layout and nothing else does: the caller's a_packed decides the family
+        if ((c.ring == 5) != packed) continue;
+        if (c.ring == 5 && (K % 192 != 0 || no_d8)) continue;
         // epilogue 4 normalises whole 64-wide heads inside a wave (BN / 2 columns) that must not straddle q | k | v
-        if (epilogue == 4 && (c.bm == 192 || (c.bn / 2) % 64 != 0 || (heads * 64) % (c.bn / 2) != 0)) continue;
+        if (epilogue == 4 && c.ring != 5 && (c.bm == 192 || (c.bn / 2) % 64 != 0 || (heads * 64) % (c.bn / 2) != 0)) continue;
         if (force_bm && (c.ring != force_ring || c.bm != force_bm || c.bn != force_bn)) continue;
         if (!force_bm && force_ring == 0 && c.ring) continue;
         const long tiles = (long)((M + c.bm - 1) / c.bm) * (N / c.bn);
@@ -1368,11 +1384,13 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
 // (N = 2 H 64 = 3840 = 15 x 256, epilogue 4) and v (N = H 64 = 1920, plain bias epilogue into the same packed buffer) whenever the
 // cost model puts the q | k part on the t8 kernel: 0.247 vs 0.286 ms per layer at B = 4 (profiles/r3_gemm_t8_ab.txt).  The A
 // operand is read by both launches (L2 / Infinity Cache).  ORV_GEMM_QKV_SPLIT=0: A/B switch.
-static bool plan_gemm(int M, int N, int K, int epilogue, int heads, const GemmCand*& first, const GemmCand*& second, bool wide = false) {
+static bool plan_gemm(int M, int N, int K, int epilogue, int heads, const GemmCand*& first, const GemmCand*& second, bool wide = false,
+                      bool packed = false) {
     static int qkv_split = -1;
     if (qkv_split < 0) { const char* e = getenv("ORV_GEMM_QKV_SPLIT"); qkv_split = (e && atoi(e) == 0) ? 0 : 1; }
     second = nullptr;
-    first = choose_tile(M, N, K, epilogue, heads, wide);
+    first = choose_tile(M, N, K, epilogue, heads, wide, packed);
+    if (packed) return first != nullptr;      // the d8 kernel normalises 64-column groups at any BN: no q | k + v split
     if (epilogue == 4 && qkv_split && heads > 0 && N == 3 * heads * 64 && !(first && first->ring == 3)) {
         const GemmCand* qk = choose_tile(M, 2 * heads * 64, K, 4, heads, wide);
         const GemmCand* vv = choose_tile(M, heads * 64, K, 0, 0, wide);
@@ -1382,6 +1400,7 @@ static bool plan_gemm(int M, int N, int K, int epilogue, int heads, const GemmCa
 }
 static void cand_name(const GemmCand* c, int epilogue, char* buf, int len) {
     if (c->ring == 3) snprintf(buf, len, "gemm_t8_kernel<%d, %d>", c->bn, epilogue);
+    else if (c->ring == 5) snprintf(buf, len, "gemm_d8_kernel<%d, %d>", c->bn, epilogue);
     else if (c->ring == 2) snprintf(buf, len, "gemm_ph_kernel<%d, %d>", c->bn, epilogue);
     else if (c->ring) snprintf(buf, len, "gemm_pp_kernel<%d, %d, %d>", c->bn, c->bn == 384 ? 4 : 5, epilogue);
     else if (c->bm == 192) snprintf(buf, len, "gemm_kernel<%d, %d, %d, 2, 2>", c->bm, c->bn, epilogue);
@@ -1412,6 +1431,7 @@ static int gemm_dispatch(GemmArgs a, const GemmCand* best, int epilogue, hipStre
     }
     if (best->ring == 3) return launch_t8(a, best->bn, epilogue, st);
     if (best->ring == 4) return launch_t4(a, epilogue, st);
+    if (best->ring == 5) return launch_d8(a, best->bn, epilogue, st);
     if (best->ring == 2) {
         if (best->bn == 256) return launch_ph<256>(a, epilogue, st);
         return launch_ph<128>(a, epilogue, st);
@@ -1456,6 +1476,7 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
     a.seq = g->grp.seq; a.n_text = g->grp.n_text; a.per_group = g->grp.per_group;
     a.c_rows = g->cmap.rows; a.c_bstride = g->cmap.bstride; a.c_off = g->cmap.off;
     a.Y = (bf16_t*)g->Y; a.ldy = g->ldy;
+    a.a_packed = g->a_packed; a.c_packed = g->c_packed;
     a.qn_gq = (const bf16_t*)g->qn_gamma_q; a.qn_bq = (const bf16_t*)g->qn_beta_q; a.qn_gk = (const bf16_t*)g->qn_gamma_k;
     a.qn_bk = (const bf16_t*)g->qn_beta_k; a.qn_eps = g->qn_eps; a.qn_premul = g->qn_premul; a.qn_heads = g->qn_heads;
     if (g->epilogue == 4) {
@@ -1482,7 +1503,9 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const GemmCand *first = nullptr, *second = nullptr;
     const bool wide = (long)g->M * g->lda * 2 >= (1L << 32) || (long)g->N * g->ldw * 2 >= (1L << 32);
-    ORV_REQUIRE(plan_gemm(g->M, g->N, g->K, g->epilogue, g->qn_heads, first, second, wide),
+    ORV_REQUIRE(!g->a_packed || g->lda == g->K, "orv_gemm_bf16: a packed A has lda == K (lda=%d K=%d)", g->lda, g->K);
+    ORV_REQUIRE(!g->c_packed || g->a_packed, "orv_gemm_bf16: packed C is written by the kernel that reads packed A (a_packed) only");
+    ORV_REQUIRE(plan_gemm(g->M, g->N, g->K, g->epilogue, g->qn_heads, first, second, wide, g->a_packed != 0),
                 "orv_gemm_bf16: no tile configuration for N=%d (ORV_GEMM_TILE override?)", g->N);
     if (!second) return gemm_dispatch(a, first, g->epilogue, st);
     const int nqk = 2 * g->qn_heads * 64;

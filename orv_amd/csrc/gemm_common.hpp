@@ -29,6 +29,7 @@ struct GemmArgs {
     bf16_t* Y; long ldy;   // optional second output: the pre-epilogue value acc + bias (saved for backward)
     // epilogue 4 (fused qk LayerNorm of the QKV projection): norm_q / norm_k affine [64], eps, q pre-multiplier, heads
     const bf16_t *qn_gq, *qn_bq, *qn_gk, *qn_bk; float qn_eps, qn_premul; int qn_heads;
+    int a_packed, c_packed;   // A / C in the packed P16 layout (include/orv_mi355.h orv_gemm_t; gemm_d8.hip)
     int tiles_m, tiles_n;
     int dbg;  // ORV_GEMM_DBG: 1 = skip main-loop loads, 2 = skip MFMAs (ablation only)
     // Walk the tile list from its end.  A GEMM's A operand was written by the kernel just before it, lowest rows first; the big ones
@@ -72,5 +73,7 @@ int launch_t8(const GemmArgs& a, int bn, int epi, hipStream_t st);
 int launch_t8_tn(const GemmArgs& a, int bn, int accumulate, hipStream_t st);
 // gemm_t8.hip: the four-wave 256 x 256 experiment (ORV_GEMM_TILE=4,256,256)
 int launch_t4(const GemmArgs& a, int epi, hipStream_t st);
+// gemm_d8.hip: gemm_d8_kernel<BN, EPI> (A straight to registers, W through four LDS buffers; BN = 256 or 192, K % 192 == 0)
+int launch_d8(const GemmArgs& a, int bn, int epi, hipStream_t st);
 
 }  // namespace orv_gemm

@@ -1,0 +1,507 @@
+// bf16 GEMM  C = epilogue(A[M,K] . W[N,K]^T + bias), the "d8" kernel (round 5): the 256-row tile of gemm_t8_kernel with MORE BYTES IN
+// FLIGHT.  Round 4 measured the t8 K loop (profiles/r4_gemm_t8_load_side.txt): its LDS-DMA stream alone takes as long as its MFMA stream
+// because it is latency x bytes-in-flight bound - two 64-KB K-tile buffers fill the 160 KB of LDS, so at most ~48 KB per CU are in flight
+// against ~1 us of L2-miss latency.  Here only ONE operand goes through LDS:
+//   * 8 waves as 8 (M) x 1 (N): a wave owns 32 rows x BN columns (2 x BN/16 accumulator blocks of v_mfma_f32_16x16x32_bf16, C^T form as t8).
+//   * A: each wave loads ITS OWN 32 rows x 64 k of every K-tile straight into the MFMA B-operand layout (4 x global_load_dwordx4), TWO
+//     K-tiles ahead, into a ring of three register sets (48 VGPRs).  No wave shares A rows with another, so nothing is fetched twice and
+//     nothing is staged.  The operand layout (lane = row l & 15, 16-byte k chunk l >> 4) puts the four lanes of a quad into four different
+//     rows: read from a ROW-MAJOR A that shape moves 18.8 B/clk/CU through the texture path against 62 for quad- or line-contiguous
+//     instructions (tools/probe_frag_loads.cpp, profiles/r5_probe_frag_loads.txt) and the first d8 build lost 10-17 % to t8 because of it
+//     (profiles/r5_gemm_d8.txt).  So A must be in the PACKED layout "P16" (include/orv_mi355.h, orv_gemm_t.a_packed): 1-KiB blocks of 16 rows
+//     x 32 k stored in exactly the order a wave instruction wants them (lane l's 16 bytes at l * 16) - every load is one contiguous KiB.
+//     A's producers write that layout directly: an MFMA kernel's accumulator layout has lane = row, so its epilogue stores a packed
+//     block as one lane-linear 1-KiB instruction (c_packed below: cheaper than the row-major store), orv_layernorm_modulate scatters.
+//   * W: BN rows x 64 k per K-tile by LDS-DMA in full-line pieces (8 rows x 128 B, chunk ^ (row & 6): t8's round-4 image), FOUR buffers
+//     of BN x 128 B, filled THREE K-tiles ahead and waited for ONE K-tile early.  Every wave reads every W fragment (ds_read_b128).
+//   -> ~2 x (32 + 32) KB in flight per CU instead of ~48, LDS-DMA instructions halved (4 + 4 plain loads per wave and K-tile instead of 8
+//      DMA), ONE s_barrier per K-tile instead of eight (a buffer is known complete a whole K-tile before it is read, so fragment reads
+//      run ahead across K-tile boundaries), no ping-pong choreography: the two waves of a SIMD free-run and fill each other's gaps.
+//   Costs: 256 KB (BN = 256) of fragment reads per K-tile and CU instead of 192 (1024 of 2048 LDS cycles), a W fragment feeds 2 MFMAs.
+//   * persistent over the XCD-aware tile list, both streams keep their own (tile, K-tile) cursor and run on into the next tile under the
+//     epilogue, like t8.
+//   * epilogues 0-4 through the per-wave LDS transpose (t8_epilogue_lds's arithmetic, element for element): a wave owns whole rows of the
+//     tile, 64 columns at a time = one head for the fused qk LayerNorm.  The accumulation order per output element is t8's (K-tiles
+//     ascending, k halves 0, 1, the same k chunk per lane group), so the results are bit-identical to gemm_t8_kernel's.
+// Requires a_packed, K % 192 == 0 (three register sets, statically indexed: the K loop is unrolled by three), N % BN == 0, W < 4 GiB.
+#include "gemm_common.hpp"
+
+namespace {
+using namespace orv_gemm;
+
+__device__ __forceinline__ void d8_unpack8(const uint4 u, float (&f)[8]) {
+    f[0] = bf2f(u.x & 0xffff); f[1] = bf2f(u.x >> 16); f[2] = bf2f(u.y & 0xffff); f[3] = bf2f(u.y >> 16);
+    f[4] = bf2f(u.z & 0xffff); f[5] = bf2f(u.z >> 16); f[6] = bf2f(u.w & 0xffff); f[7] = bf2f(u.w >> 16);
+}
+__device__ __forceinline__ uint4 d8_pack8(const float (&f)[8]) {
+    return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+}
+__device__ __forceinline__ float d8_sum8(float v) {          // sum over the 8 lanes lane & ~7 .. lane | 7
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x141, 0xF, 0xF, true));    // row_half_mirror
+    return v;
+}
+__device__ __forceinline__ unsigned long long d8_uniform64(unsigned long long u) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Epilogue of one wave: rows row0 .. row0 + 31 (two 16-row blocks), columns col0 .. col0 + BN - 1 in groups of 64.  Accumulator layout
+// (as t8): lane (r16 = lane & 15, g = lane >> 4) holds, of block 2 P + t of a 64-column group, columns 32 P + 8 g + 4 t + (0..3) of row r16.
+// Every (16 rows x 64 columns) piece goes through the wave's 4-KiB fp32 scratch and comes back as lane = (row lane >> 3, 8-column chunk
+// lane & 7): loads and stores are 8 rows x one full 128-byte line per instruction.
+template <int BN, int EPI>
+__device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][BN / 16], const int row0, const int col0, const int lane,
+                                            char* const scr) {
+    constexpr int NG = BN / 64;
+    const int g = lane >> 4, r16 = lane & 15;
+    const int c = lane & 7, rr8 = lane >> 3;
+    int woff[4];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+        const int L = 8 * (blk >> 1) + 2 * g + (blk & 1);
+        woff[blk] = r16 * 256 + ((L ^ (r16 & 7)) << 4);
+    }
+    const int roff0 = rr8 * 256 + (((2 * c) ^ rr8) << 4), roff1 = rr8 * 256 + (((2 * c + 1) ^ rr8) << 4);      // + j * 2048
+
+    long orow[2][2];
+    bool valid[2][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = row0 + rb * 16 + 8 * j + rr8;
+            valid[rb][j] = m < p.M;
+            const int mc = min(m, p.M - 1);
+            orow[rb][j] = mc;
+            if (p.c_rows > 0) orow[rb][j] = (long)(mc / p.c_rows) * p.c_bstride + p.c_off + mc % p.c_rows;
+        }
+    // row operands (residual / GELU-adjoint input) of one 64-column group: requested one group ahead
+    uint4 r8[2][2][2];                                  // [set][rb][j]
+    auto load_rows = [&](int cg, uint4 (&dst)[2][2]) {
+        const int col8 = col0 + 64 * cg + 8 * c;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int mc = min(row0 + rb * 16 + 8 * j + rr8, p.M - 1);
+                long rr = mc;
+                if (p.r_mod > 0) rr = mc % p.r_mod;
+                else if (p.c_rows > 0) rr = (long)(mc / p.c_rows) * p.c_bstride + p.c_off + mc % p.c_rows;
+                dst[rb][j] = *(const uint4*)(p.R + rr * p.ldr + col8);
+            }
+    };
+    if (EPI == 2 || EPI == 3) load_rows(0, r8[0]);
+
+#pragma unroll
+    for (int cg = 0; cg < NG; ++cg) {
+        const int col8 = col0 + 64 * cg + 8 * c;
+        if ((EPI == 2 || EPI == 3) && cg + 1 < NG) load_rows(cg + 1, r8[(cg + 1) & 1]);
+        float b8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b8[e] = 0.f;
+        if (p.bias) d8_unpack8(*(const uint4*)(p.bias + col8), b8);
+        // epilogue 4: qk LayerNorm parameters of this lane's 8 channels of the head (the 64-column group IS one head)
+        float ga[8], be[8];
+        int region = 2;
+        float post = 1.f;
+        if constexpr (EPI == 4) {
+            region = __builtin_amdgcn_readfirstlane((col0 + 64 * cg) / (p.qn_heads * 64));     // 0 = q, 1 = k, 2 = v
+            const bf16_t* gam = region == 0 ? p.qn_gq : p.qn_gk;
+            const bf16_t* bet = region == 0 ? p.qn_bq : p.qn_bk;
+            post = region == 0 ? p.qn_premul : 1.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ga[e] = 1.f; be[e] = 0.f; }
+            if (region < 2 && gam) d8_unpack8(*(const uint4*)(gam + 8 * c), ga);
+            if (region < 2 && bet) d8_unpack8(*(const uint4*)(bet + 8 * c), be);
+        }
+        float g8[8];
+        const float* g_cached = nullptr;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g8[e] = 1.f;
+
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) *(f32x4*)(scr + woff[blk]) = acc[rb][4 * cg + blk];
+            float v[2][8];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4 lo = *(const f32x4*)(scr + j * 2048 + roff0), hi = *(const f32x4*)(scr + j * 2048 + roff1);
+                v[j][0] = lo[0]; v[j][1] = lo[1]; v[j][2] = lo[2]; v[j][3] = lo[3];
+                v[j][4] = hi[0]; v[j][5] = hi[1]; v[j][6] = hi[2]; v[j][7] = hi[3];
+            }
+            // gate row of this 16-row block (EPI 2): wave-uniform when the block lies inside one (batch element, token group)
+            bool g_lane = false;
+            if (EPI == 2 && p.gate) {
+                const int mf = __builtin_amdgcn_readfirstlane(row0 + rb * 16), ml = min(mf + 15, p.M - 1);
+                long of = min(mf, p.M - 1), ol = ml;
+                if (p.c_rows > 0) {
+                    of = (long)(of / p.c_rows) * p.c_bstride + p.c_off + of % p.c_rows;
+                    ol = (long)(ml / p.c_rows) * p.c_bstride + p.c_off + ml % p.c_rows;
+                }
+                const int bf_ = (int)(of / p.seq), bl_ = (int)(ol / p.seq);
+                const int gf_ = orv_group_of((int)(of % p.seq), p.n_text, p.per_group);
+                const int gl_ = orv_group_of((int)(ol % p.seq), p.n_text, p.per_group);
+                if (bf_ == bl_ && gf_ == gl_) {
+                    const float* gr = p.gate + bf_ * p.gate_b + gf_ * p.gate_g;
+                    if (gr != g_cached) {
+                        g_cached = gr;
+                        const float4 a = *(const float4*)(gr + col8), b = *(const float4*)(gr + col8 + 4);
+                        g8[0] = a.x; g8[1] = a.y; g8[2] = a.z; g8[3] = a.w; g8[4] = b.x; g8[5] = b.y; g8[6] = b.z; g8[7] = b.w;
+                    }
+                } else g_lane = true;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float (&w)[8] = v[j];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[e] += b8[e];
+                bf16_t* crow = p.C + orow[rb][j] * p.ldc + col8;
+                if (p.Y && valid[rb][j]) *(uint4*)(p.Y + orow[rb][j] * p.ldy + col8) = d8_pack8(w);
+                if constexpr (EPI == 4) {
+                    if (region < 2) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) s += w[e];
+                        const float mean = d8_sum8(s) * (1.f / 64.f);
+                        float sq = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { w[e] -= mean; sq += w[e] * w[e]; }
+                        const float rstd = rsqrtf(d8_sum8(sq) * (1.f / 64.f) + p.qn_eps);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) w[e] = (w[e] * rstd * ga[e] + be[e]) * post;
+                    }
+                }
+                if (EPI == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w[e] = gelu_tanh(w[e]);
+                }
+                if (EPI == 2) {
+                    float rv[8], gg[8];
+                    d8_unpack8(r8[cg & 1][rb][j], rv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gg[e] = g8[e];
+                    if (g_lane) {            // block straddles a frame / text boundary: this lane's row picks its own gate row
+                        const int bidx = (int)(orow[rb][j] / p.seq), sq_ = (int)(orow[rb][j] % p.seq);
+                        const float* grow = p.gate + bidx * p.gate_b + orv_group_of(sq_, p.n_text, p.per_group) * p.gate_g;
+                        const float4 a = *(const float4*)(grow + col8), b = *(const float4*)(grow + col8 + 4);
+                        gg[0] = a.x; gg[1] = a.y; gg[2] = a.z; gg[3] = a.w; gg[4] = b.x; gg[5] = b.y; gg[6] = b.z; gg[7] = b.w;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w[e] = rv[e] + gg[e] * w[e];
+                }
+                if (EPI == 3) {
+                    float rv[8];
+                    d8_unpack8(r8[cg & 1][rb][j], rv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w[e] *= gelu_tanh_grad(rv[e]);
+                }
+                if (valid[rb][j]) *(uint4*)crow = d8_pack8(w);
+            }
+        }
+    }
+}
+
+// Packed output (c_packed, epilogues 0 / 1): C in the P16 layout of an [M, N] matrix, i.e. ready to be the NEXT GEMM's A operand (FFN1 -> FFN2:
+// cogvideox_control.py:439-440).  In the accumulator layout lane (r16, g) holds columns 32 P + 8 g + (0..7) of row r16 for the block pair P -
+// that IS packed block (row block, column block col0 / 32 + P) at byte 16 (r16 + 16 g) = 16 lane: one lane-linear, fully contiguous 1-KiB
+// store per block pair, no LDS transpose, no row mask (the buffer has tiles_m * 256 rows; rows >= M hold finite garbage nobody reads).
+template <int BN, int EPI>
+__device__ __forceinline__ void d8_epilogue_packed(const GemmArgs& p, f32x4 (&acc)[2][BN / 16], const int row0, const int col0, const int lane) {
+    const int g = lane >> 4;
+    const long nblk = p.ldc / 32;                      // column blocks per row block (ldc = N of the packed matrix)
+#pragma unroll
+    for (int P = 0; P < BN / 32; ++P) {
+        float b8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b8[e] = 0.f;
+        if (p.bias) d8_unpack8(*(const uint4*)(p.bias + col0 + 32 * P + 8 * g), b8);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[rb][2 * P + (e >> 2)][e & 3] + b8[e];
+            if (EPI == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+            }
+            char* blk = (char*)p.C + (((long)(row0 / 16 + rb) * nblk + (col0 / 32 + P)) << 10);
+            *(uint4*)(blk + lane * 16) = d8_pack8(v);
+        }
+    }
+}
+
+template <int BN, int EPI>
+__global__ __launch_bounds__(512) void gemm_d8_kernel(const GemmArgs p) {
+    constexpr int NCB = BN / 16;                      // 16-column blocks of the tile (16 / 12)
+#ifndef ORV_D8_CBP256
+#define ORV_D8_CBP256 2
+#endif
+#ifndef ORV_D8_CBP192
+#define ORV_D8_CBP192 3
+#endif
+    constexpr int CBP = BN == 256 ? ORV_D8_CBP256 : ORV_D8_CBP192;     // column blocks per phase: BN = 256 eight phases of 8 MFMAs, BN = 192 four of 12
+    constexpr int NPH = NCB / CBP;
+    constexpr int BUFSZ = BN * 128;                   // one K-tile of W: BN rows x 64 k
+    constexpr int ND = BN / 64;                       // 1-KiB DMA pieces per wave and K-tile (BN / 8 pieces over 8 waves)
+    constexpr int SCR = 4 * BUFSZ;                    // epilogue scratch: 8 waves x 4 KiB behind the four W buffers
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int nk = p.K / BK;                          // multiple of 3 (chooser-checked)
+
+    // ---- W stream (LDS-DMA).  Piece q = wave * ND + j: rows 8 (q & 1) .. + 7 of column block q >> 1; lane l fetches row l >> 3, logical
+    // 16-byte chunk (l & 7) ^ (row & 6) and lands at physical chunk l & 7 (lane-linear image).  LDS row i of block 2 P + t holds W row
+    // 32 P + 8 (i >> 2) + 4 t + (i & 3) of the tile (t8's permutation: a lane's accumulators are 8 contiguous columns per block pair).
+    const int dr = lane >> 3;
+    const unsigned voffW = (unsigned)(((long)(8 * (dr >> 2) + (dr & 3)) * p.ldw + (((lane & 7) ^ (dr & 6)) << 3)) * 2);
+    unsigned long long wb[ND];                        // wave-uniform byte address of the piece's first row at k = 0
+    int kW = 0, tW = blockIdx.x;
+    const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
+#define D8_SETUP_W(TILE)                                                                                             \
+    {                                                                                                                \
+        int tm_, tn_;                                                                                                \
+        tile_of_index(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                                                 \
+        _Pragma("unroll") for (int j = 0; j < ND; ++j) {                                                             \
+            const int q_ = wave * ND + j, cb_ = q_ >> 1;                                                             \
+            const int wrow_ = tn_ * BN + 32 * (cb_ >> 1) + 16 * (q_ & 1) + 4 * (cb_ & 1);                            \
+            wb[j] = d8_uniform64((unsigned long long)(uintptr_t)p.W + (unsigned long long)wrow_ * p.ldw * 2);        \
+        }                                                                                                            \
+    }
+#ifdef ORV_D8_ABL_NODMA      // ablation builds (tools/d8_abl.sh, wrong results)
+#define D8_DMA1(OFF, SB, LDS) asm volatile("" :: "v"(OFF), "s"(SB), "s"(LDS));
+#else
+#define D8_DMA1(OFF, SB, LDS) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(OFF), "s"(SB), "s"(LDS) : "memory", "m0");
+#endif
+#define D8_ISSUE_W(BUFI)                                                                                             \
+    {                                                                                                                \
+        _Pragma("unroll") for (int j = 0; j < ND; ++j) {                                                             \
+            const unsigned long long sb_ = wb[j] + (unsigned long long)kW * 128;                                     \
+            const unsigned ld_ = lds0 + (BUFI) * BUFSZ + (wave * ND + j) * 1024;                                     \
+            D8_DMA1(voffW, sb_, ld_)                                                                                 \
+        }                                                                                                            \
+        if (__builtin_expect(++kW == nk, 0)) { kW = 0; tW += gridDim.x; D8_SETUP_W(tW) }                             \
+    }
+    D8_SETUP_W(tW)
+
+    // ---- A stream (straight to registers, packed layout).  Block (row block R, k block c) of 16 rows x 32 k sits at ((R * K / 32) + c) KiB;
+    // a wave's two row blocks are R = (tile row + 32 wave) / 16 + rb, K-tile kt = blocks 2 kt, 2 kt + 1; lane l takes bytes [16 l, 16 l + 16).
+    unsigned voffA[2];
+    const unsigned long long rowblk = (unsigned long long)p.K * 32;     // bytes of one 16-row block row
+    unsigned long long ab;                                               // wave-uniform byte address of block (R(rb = 0), 0)
+    int kA = 0, tA = blockIdx.x;
+    voffA[0] = (unsigned)lane * 16;
+    voffA[1] = (unsigned)lane * 16 + (unsigned)rowblk;
+#define D8_SETUP_A(TILE)                                                                                             \
+    {                                                                                                                \
+        int tm_, tn_;                                                                                                \
+        tile_of_index(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                                                 \
+        ab = d8_uniform64((unsigned long long)(uintptr_t)p.A + (unsigned long long)(tm_ * 16 + wave * 2) * rowblk);  \
+    }
+#ifdef ORV_D8_ABL_NOA
+#define D8_LOADA(DST, OFF, SB, IMM) asm volatile("" : "=v"(DST) : "v"(OFF), "s"(SB));
+#else
+#define D8_LOADA(DST, OFF, SB, IMM) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #IMM : "=v"(DST) : "v"(OFF), "s"(SB) : "memory");
+#endif
+#define D8_ISSUE_A(SET)                                                                                              \
+    {                                                                                                                \
+        const unsigned long long sa_ = ab + (unsigned long long)kA * 2048;                                           \
+        D8_LOADA(SET[0], voffA[0], sa_, 0) D8_LOADA(SET[1], voffA[0], sa_, 1024)                                     \
+        D8_LOADA(SET[2], voffA[1], sa_, 0) D8_LOADA(SET[3], voffA[1], sa_, 1024)                                     \
+        if (__builtin_expect(++kA == nk, 0)) { kA = 0; tA += gridDim.x; D8_SETUP_A(tA) }                             \
+    }
+    D8_SETUP_A(tA)
+
+    // ---- W fragment reads: row i = l & 15 of a block = piece i >> 3, row i & 7; k chunk (4 kh + (l >> 4)) ^ (i & 6): k half 1 = bit 6 flipped
+    const int fro = ((lane & 15) >> 3) * 1024 + (lane & 7) * 128 + (((lane >> 4) ^ (lane & 6)) << 4);
+    const char* const rd0 = smem + fro;
+    const char* const rd1 = smem + (fro ^ 64);
+
+    f32x4 acc[2][NCB];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NCB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 a0[4], a1[4], a2[4];                       // A register sets: [rb * 2 + kh]
+    bf16x8 fx[CBP][2];                                // W fragments of the current phase (rolling, see D8_READ1)
+
+#define D8_FENCE() __builtin_amdgcn_sched_barrier(0);
+    // W fragment F[t][kh] of a phase = column block PH * CBP + t, k half kh.  ONE fragment set, rolling: step s = kh * CBP + t of a phase
+    // issues the two MFMAs (row blocks 0, 1) of F[t][kh] and then re-requests the SAME registers for the next phase - the read has a whole
+    // phase (4 CBP MFMAs) to land, reads and MFMAs alternate 1 : 2 instead of arriving in bursts, and no second fragment set is needed.
+#ifdef ORV_D8_ABL_NOREAD
+#define D8_READ1(T, KH, BOFF, PH) asm volatile("" : "+v"(fx[T][KH]));
+#else
+#define D8_READ1(T, KH, BOFF, PH) fx[T][KH] = *(const bf16x8*)(((KH) ? rd1 : rd0) + (BOFF) + ((PH) * CBP + (T)) * 2048);
+#endif
+#ifdef ORV_D8_ABL_NOMFMA
+#define D8_MFMA1(T, KH, AS, PH)                                                                                      \
+    _Pragma("unroll") for (int rb = 0; rb < 2; ++rb) asm volatile("" : "+v"(acc[rb][(PH) * CBP + (T)]) : "v"(fx[T][KH]), "v"(AS[rb * 2 + (KH)]));
+#else
+#define D8_MFMA1(T, KH, AS, PH)                                                                                      \
+    _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                                                 \
+        acc[rb][(PH) * CBP + (T)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[T][KH], AS[rb * 2 + (KH)], acc[rb][(PH) * CBP + (T)], 0, 0, 0);
+#endif
+    // One vector-memory instruction of this K-tile's group: slots 0 .. ND - 1 = the W pieces of K-tile u + 3 (into buffer DBUF), slots ND ..
+    // ND + 3 = the A loads of K-tile u + 2 (into ANEW).  The slots are SPREAD over the phases, each between the two k halves of a phase's MFMAs:
+    // issued together behind the barrier (the first build) the eight waves' 64 instructions queue at the texture path for ~1000 cycles during
+    // which no wave reaches an MFMA (profiles/r5_gemm_d8.txt: every stream removed alone bought 9-18 %).
+#define D8_SLOT(S, ANEW, DBUF)                                                                                       \
+    if ((S) < ND) {                                                                                                  \
+        const unsigned long long sb_ = wb[(S) < ND ? (S) : 0] + (unsigned long long)kW * 128;                        \
+        const unsigned ld_ = lds0 + (DBUF) * BUFSZ + (wave * ND + (S)) * 1024;                                       \
+        D8_DMA1(voffW, sb_, ld_)                                                                                     \
+        if ((S) == ND - 1) { if (__builtin_expect(++kW == nk, 0)) { kW = 0; tW += gridDim.x; D8_SETUP_W(tW) } }      \
+    } else if ((S) < ND + 4) {                                                                                       \
+        const unsigned long long sa_ = ab + (unsigned long long)kA * 2048;                                           \
+        if ((S) == ND) D8_LOADA(ANEW[0], voffA[0], sa_, 0)                                                           \
+        if ((S) == ND + 1) D8_LOADA(ANEW[1], voffA[0], sa_, 1024)                                                    \
+        if ((S) == ND + 2) D8_LOADA(ANEW[2], voffA[1], sa_, 0)                                                       \
+        if ((S) == ND + 3) { D8_LOADA(ANEW[3], voffA[1], sa_, 1024)                                                  \
+            if (__builtin_expect(++kA == nk, 0)) { kA = 0; tA += gridDim.x; D8_SETUP_A(tA) } }                       \
+    }
+    // slots: BN = 256 one per phase (8 phases, 8 slots), BN = 192 two per phase (4 phases, 7 slots), behind the steps CBP / 2 and CBP + CBP / 2
+#define D8_STEP_SLOT(PH, S, ANEW, DBUF)                                                                              \
+    if constexpr (BN == 256) { if ((S) == 1) { D8_SLOT((PH), ANEW, DBUF) } }                                         \
+    else { if ((S) == 1) { D8_SLOT(2 * (PH), ANEW, DBUF) } if ((S) == 4) { D8_SLOT(2 * (PH) + 1, ANEW, DBUF) } }
+    // phase PH of a K-tile: RBUF / RPH = buffer offset and phase the re-requested fragments belong to
+#define D8_PHASE(RBUF, RPH, ACUR, ANEW, PH, DBUF)                                                                    \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2 * CBP; ++s_) {                                                         \
+        D8_MFMA1(s_ % CBP, s_ / CBP, ACUR, PH) D8_FENCE()                                                            \
+        D8_READ1(s_ % CBP, s_ / CBP, RBUF, RPH) D8_FENCE()                                                           \
+        D8_STEP_SLOT(PH, s_, ANEW, DBUF) D8_FENCE()                                                                  \
+    }
+    // One K-tile u.  ACUR: the A set it computes with; ANEW: the set K-tile u - 1 used, refilled for K-tile u + 2.  bufc = u & 3.
+    //   wait: this wave's group of two K-tiles ago = { W pieces of K-tile u + 1, A of K-tile u } (the group of K-tile u - 1 stays in flight)
+    //   barrier: every wave's pieces of K-tile u + 1 have landed, every wave is done with the buffer of K-tile u - 1
+    //   NPH phases; the last one re-requests K-tile u + 1's first fragments (complete since the barrier above);
+    //   this K-tile's group (W pieces of K-tile u + 3 into the buffer of K-tile u - 1, A of K-tile u + 2) is issued slot by slot
+#define D8_KTILE(ACUR, ANEW)                                                                                         \
+    {                                                                                                                \
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ACUR[0]), "+v"(ACUR[1]), "+v"(ACUR[2]), "+v"(ACUR[3]) : "n"(ND + 4) : "memory"); \
+        D8_FENCE() __builtin_amdgcn_s_barrier(); D8_FENCE()                                                          \
+        const int cur_ = bufc * BUFSZ, nxt_ = ((bufc + 1) & 3) * BUFSZ, dbuf_ = (bufc + 3) & 3;                      \
+        _Pragma("unroll") for (int pp_ = 0; pp_ < NPH; ++pp_) {                                                      \
+            D8_PHASE((pp_ + 1 < NPH ? cur_ : nxt_), (pp_ + 1) % NPH, ACUR, ANEW, pp_, dbuf_)                         \
+        }                                                                                                            \
+        bufc = (bufc + 1) & 3;                                                                                       \
+    }
+
+    // prologue: W of K-tiles 0, 1, 2 and A of K-tiles 0, 1 in the order the steady state would have issued them
+    int bufc = 0;
+    D8_ISSUE_W(0)
+    D8_ISSUE_W(1) D8_ISSUE_A(a0)
+    D8_ISSUE_W(2) D8_ISSUE_A(a1)
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (ND + 4)) : "memory");
+    D8_FENCE() __builtin_amdgcn_s_barrier(); D8_FENCE()
+    _Pragma("unroll") for (int s_ = 0; s_ < 2 * CBP; ++s_) { D8_READ1(s_ % CBP, s_ / CBP, 0, 0) }
+    D8_FENCE()
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        for (int kt = 0; kt < nk; kt += 3) {
+            D8_KTILE(a0, a2)
+            D8_KTILE(a1, a0)
+            D8_KTILE(a2, a1)
+        }
+        int tm, tn;
+        tile_of_index(p, tile, ntiles, tm, tn);
+        if ((EPI == 0 || EPI == 1) && p.c_packed) d8_epilogue_packed<BN, EPI>(p, acc, tm * 256 + wave * 32, tn * BN, lane);
+        else d8_epilogue<BN, EPI>(p, acc, tm * 256 + wave * 32, tn * BN, lane, smem + SCR + wave * 4096);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < NCB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // keep the last prefetched registers formally alive up to the drain (their loads are in flight until here)
+    asm volatile("" :: "v"(a0[0]), "v"(a1[0]), "v"(a2[0]), "v"(fx[0][0]));
+}
+
+template <int BN, int EPI>
+int launch_d8_one(const GemmArgs& a, hipStream_t st) {
+    constexpr int smem = 4 * BN * 128 + 8 * 4096;     // four W buffers + the epilogue scratch (160 KiB at BN = 256)
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_d8_kernel<BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    int grid = min(a.tiles_m * a.tiles_n, orv_num_cus());
+    if (a.grid_cap > 0) grid = min(grid, a.grid_cap);
+    hipLaunchKernelGGL((gemm_d8_kernel<BN, EPI>), dim3(grid), dim3(512), smem, st, a);
+    return orv_check_launch("orv_gemm_bf16");
+}
+
+}  // namespace
+
+namespace orv_gemm {
+int launch_d8(const GemmArgs& a, int bn, int epi, hipStream_t st) {
+    if (!a.a_packed || (long)a.N * a.ldw * 2 >= (1L << 32) || a.K % 192 != 0 || a.lda != a.K) {
+        orv_set_error("orv_gemm_bf16: the d8 kernel needs a packed A (a_packed, lda == K), K %% 192 == 0 and W below 4 GiB (lda=%ld N=%d ldw=%ld K=%d)",
+                      a.lda, a.N, a.ldw, a.K);
+        return ORV_EINVAL;
+    }
+    if (a.c_packed && (epi > 1 || a.ldc != a.N || a.c_rows > 0 || a.Y)) {
+        orv_set_error("orv_gemm_bf16: packed C needs epilogue 0 / 1, ldc == N, no row map, no Y");
+        return ORV_EINVAL;
+    }
+    if (bn == 256) {
+        switch (epi) {
+            case 0: return launch_d8_one<256, 0>(a, st);
+            case 1: return launch_d8_one<256, 1>(a, st);
+            case 2: return launch_d8_one<256, 2>(a, st);
+            case 3: return launch_d8_one<256, 3>(a, st);
+            case 4: return launch_d8_one<256, 4>(a, st);
+        }
+    } else if (bn == 192) {
+        switch (epi) {
+            case 0: return launch_d8_one<192, 0>(a, st);
+            case 1: return launch_d8_one<192, 1>(a, st);
+            case 2: return launch_d8_one<192, 2>(a, st);
+            case 3: return launch_d8_one<192, 3>(a, st);
+            case 4: return launch_d8_one<192, 4>(a, st);
+        }
+    }
+    orv_set_error("orv_gemm_bf16: no d8 kernel for BN=%d epilogue %d", bn, epi);
+    return ORV_EINVAL;
+}
+}  // namespace orv_gemm
+
+// ---- P16 pack / unpack (include/orv_mi355.h).  One thread per 16-byte piece, destination-ordered (coalesced writes). ----
+namespace {
+__global__ __launch_bounds__(256) void pack_rows16_kernel(const bf16_t* src, long ld, uint4* dst, int M, int K, long pieces) {
+    const long d = (long)blockIdx.x * 256 + threadIdx.x;
+    if (d >= pieces) return;
+    const long blk = d >> 6;
+    const int l = (int)(d & 63), kb = K / 32;
+    const long row = (blk / kb) * 16 + (l & 15);
+    const int k = (int)(blk % kb) * 32 + (l >> 4) * 8;
+    dst[d] = row < M ? *(const uint4*)(src + row * ld + k) : make_uint4(0, 0, 0, 0);
+}
+__global__ __launch_bounds__(256) void unpack_rows16_kernel(const uint4* src, bf16_t* dst, long ld, int M, int K, long pieces) {
+    const long d = (long)blockIdx.x * 256 + threadIdx.x;       // destination-ordered: piece d = (row, 8-column chunk)
+    if (d >= pieces) return;
+    const int kc = K / 8;
+    const long row = d / kc;
+    const int c = (int)(d % kc);
+    const long blk = (row >> 4) * (K / 32) + (c >> 2);
+    *(uint4*)(dst + row * ld + c * 8) = src[blk * 64 + (c & 3) * 16 + (row & 15)];
+}
+}  // namespace
+extern "C" long orv_packed_rows(long rows) { return (rows + 255) / 256 * 256; }
+extern "C" int orv_pack_rows16(const void* src, long ld_src, void* dst, int M, int K, void* stream) {
+    ORV_REQUIRE(src && dst && M > 0 && K > 0 && K % 32 == 0 && ld_src % 8 == 0, "orv_pack_rows16: bad arguments (M=%d K=%d ld=%ld)", M, K, ld_src);
+    const long pieces = orv_packed_rows(M) * (K / 8);
+    hipLaunchKernelGGL(pack_rows16_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld_src,
+                       (uint4*)dst, M, K, pieces);
+    return orv_check_launch("orv_pack_rows16");
+}
+extern "C" int orv_unpack_rows16(const void* src, void* dst, long ld_dst, int M, int K, void* stream) {
+    ORV_REQUIRE(src && dst && M > 0 && K > 0 && K % 32 == 0 && ld_dst % 8 == 0, "orv_unpack_rows16: bad arguments (M=%d K=%d ld=%ld)", M, K, ld_dst);
+    const long pieces = (long)M * (K / 8);
+    hipLaunchKernelGGL(unpack_rows16_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)src,
+                       (bf16_t*)dst, ld_dst, M, K, pieces);
+    return orv_check_launch("orv_unpack_rows16");
+}

@@ -20,6 +20,16 @@ def rel_l2(got, ref):
     return ((got - ref).norm() / ref.norm()).item()
 
 
+def slice_rel_l2(got, ref):
+    """Largest rel-L2 over single frames and single channels of a [B, T, C, H, W] latent (a whole-tensor norm cannot see an error
+    confined to one frame or one channel): max over (b, t) and over (b, c) of ||got - ref|| / ||ref|| of that slice."""
+    got, ref = got.float().cpu(), ref.float().cpu()
+    d = got - ref
+    per_frame = d.flatten(2).norm(dim=2) / ref.flatten(2).norm(dim=2).clamp_min(1e-12)                              # [B, T]
+    per_chan = d.transpose(1, 2).flatten(2).norm(dim=2) / ref.transpose(1, 2).flatten(2).norm(dim=2).clamp_min(1e-12)  # [B, C]
+    return max(per_frame.max().item(), per_chan.max().item())
+
+
 def build(cfg, weights, dev):
     from orv_amd.cogvideox_control import CogVideoXTransformer3DModelTraj
     m = CogVideoXTransformer3DModelTraj(**cfg)
@@ -48,6 +58,10 @@ def test_forward_matches_reference_golden(name):
                                 num_views=extra["num_views"])
     assert out.shape == outs["sample"].shape and out.dtype == BF
     assert rel_l2(out, outs["sample"]) <= 2e-2
+    # ... and no single frame or channel hides a larger error behind the whole-tensor norm (VERDICT r4 weak #1 iv)
+    worst = slice_rel_l2(out, outs["sample"])
+    print(f"[slice-err] {name}: whole {rel_l2(out, outs['sample']):.2e} worst frame / channel {worst:.2e}")
+    assert worst <= 4e-2
     if "is_action_mask" in outs:
         assert torch.equal(is_mask.cpu(), outs["is_action_mask"])
     if "actions_recon" in outs:
@@ -85,7 +99,7 @@ def test_denoise_loop_matches_reference_golden(name):
     assert rel_l2(out.frames, outs["latents"]) <= 5e-2
 
 
-@pytest.mark.parametrize("name", ["pipe_dpm_bf16", "pipe_ddim_bf16", "pipe_dpm_dyncfg_bf16"])
+@pytest.mark.parametrize("name", ["pipe_dpm_bf16", "pipe_ddim_bf16", "pipe_dpm_dyncfg_bf16", "pipe_ddim50_bf16", "pipe_dpm50_bf16"])
 def test_pipeline_with_generator_matches_bf16_reference(name):
     """The reference's own call shape (inference_control_to_video.py:122-146 minus VAE/T5): un-sampled 32-channel moments of
     the reference frame, NO pre-drawn tensors, a CPU ``generator``.  ``prepare_latents`` (:1115-1225: DiagonalGaussian sample
@@ -114,10 +128,13 @@ def test_pipeline_with_generator_matches_bf16_reference(name):
                controls_or_guidances={"actions": ins["actions"].to(dev, BF)} if extra["with_actions"] else {},
                callback_on_step_end=lambda p, i, t, kw: (trace.append(kw["latents"].clone()), {})[1])
     assert len(trace) == extra["steps"]
-    print(f"[loop-err] {name}: per-step rel-L2 " + " ".join(f"{rel_l2(tr, outs[f'step{i}']):.2e}" for i, tr in enumerate(trace)))
-    for i, tr in enumerate(trace):
-        assert rel_l2(tr, outs[f"step{i}"]) <= 5e-2, i
+    kept = [k - 1 for k in extra["keep_steps"]] if "keep_steps" in extra else list(range(extra["steps"]))
+    print(f"[loop-err] {name}: rel-L2 " + " ".join(f"step {i + 1}: {rel_l2(trace[i], outs[f'step{i}']):.2e}" for i in kept))
+    for i in kept:
+        assert rel_l2(trace[i], outs[f"step{i}"]) <= 5e-2, i
+        assert slice_rel_l2(trace[i], outs[f"step{i}"]) <= 1e-1, i
     assert rel_l2(out.frames, outs["latents"]) <= 5e-2
+    assert slice_rel_l2(out.frames, outs["latents"]) <= 1e-1
     if extra["dynamic_cfg"]:
         assert abs(pipe.guidance_scale - extra["final_guidance"]) < 1e-9
 

@@ -334,3 +334,30 @@ def test_constructor_and_call_signatures_equal_the_reference():
     assert sig(CogVideoXImageToVideoPipelineTraj.__call__) == ref["pipeline_call"]
     m = CogVideoXTransformer3DModelTraj(2, 64, 32, num_layers=1, sample_width=12, sample_height=8, sample_frames=9)
     assert (m.config.num_attention_heads, m.config.attention_head_dim, m.config.in_channels, m.config.num_layers) == (2, 64, 32, 1)
+
+
+def test_graph_weights_key_sees_replaced_parameters():
+    """``GraphedTransformer._weights_version`` cached the parameter LIST and re-collected it only when the
+    parameter COUNT changed, so ``m.weight = nn.Parameter(...)`` and ``load_state_dict(assign=True)`` (same count, new objects whose
+    storage the captured graph has never seen) left the key unchanged and the HIP graph replayed the old weights.  The key now
+    follows torch's parameter-registration hook.  CPU-only: the key never touches the GPU."""
+    from orv_amd.cogvideox_control import GraphedTransformer
+    cfg, _, _, w, _ = load_golden("fwd_actions")
+    m = CogVideoXTransformer3DModelTraj(**cfg)
+    m.load_state_dict(w)
+    gt = GraphedTransformer(m)
+    k0 = gt._weights_version()
+    assert gt._weights_version() == k0                                  # stable without changes
+    lin = m.transformer_blocks[0].ff.net[2]
+    lin.weight = torch.nn.Parameter(lin.weight.detach().clone() * 2)    # replaced object, same count
+    k1 = gt._weights_version()
+    assert k1 != k0
+    m.load_state_dict({k: v.clone() for k, v in w.items()}, assign=True)   # every parameter replaced, same count
+    k2 = gt._weights_version()
+    assert k2 != k1 and k2 != k0
+    with torch.no_grad():
+        m.proj_out.bias.add_(1.0)                                       # in-place edit: _version
+    k3 = gt._weights_version()
+    assert k3 != k2
+    lin.weight.data = lin.weight.data.clone()                           # storage move: data_ptr
+    assert gt._weights_version() != k3

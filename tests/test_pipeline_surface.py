@@ -251,3 +251,49 @@ def test_inference_script_body_runs_against_orv_amd(tmp_path):
     with torch.no_grad():
         again = pipe(**pipeline_args, generator=generator, output_type='pil').frames[0]
     assert all(np.array_equal(np.array(a), np.array(b)) for a, b in zip(video, again))
+
+
+def test_install_serves_the_reference_import_blocks_unchanged():
+    """``orv_amd.install()`` (orv_amd/dropin.py): the import statements of the reference's entry points
+    (inference_control_to_video.py:7-17, evaluation_control_to_video.py:17-23 - committed as a list of statements in
+    tests/golden/reference_import_blocks.json) are exec'd AS WRITTEN in a fresh interpreter after ``install()`` and must resolve the hot-path names to
+    this package: the north star's "drops into scripts/inference_control_to_video.sh unchanged" made literal (VERDICT r4 #6)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import json, sys
+import orv_amd
+names = orv_amd.install()
+assert orv_amd.install() == names                      # idempotent
+blocks = json.load(open("tests/golden/reference_import_blocks.json"))
+for key, lines in blocks.items():
+    if key.startswith("_"):
+        continue
+    ns = {}
+    for line in lines:
+        exec(line, ns)
+    import orv_amd.cogvideox_control as cc, orv_amd.schedulers as sch, orv_amd.utils as ut, orv_amd.data as data
+    assert ns["CogVideoXTransformer3DModelTraj"] is cc.CogVideoXTransformer3DModelTraj, key
+    assert ns["CogVideoXImageToVideoPipelineTraj"] is cc.CogVideoXImageToVideoPipelineTraj, key
+    assert ns["CogVideoXDPMScheduler"] is sch.CogVideoXDPMScheduler, key
+    assert callable(ns["export_to_video"]) and hasattr(ns["CONSOLE"], "log")
+    cfg = ns["FrozenDict"](a=1, invert_scale_latents=False)
+    assert cfg["a"] == 1 and cfg.invert_scale_latents is False
+from orv.utils import prepare_rotary_positional_embeddings
+from orv.models.components import ActionEmbed
+from diffusers.schedulers.scheduling_ddim_cogvideox import CogVideoXDDIMScheduler
+import orv_amd.components
+assert prepare_rotary_positional_embeddings is ut.prepare_rotary_positional_embeddings
+assert ActionEmbed is orv_amd.components.ActionEmbed and CogVideoXDDIMScheduler is sch.CogVideoXDDIMScheduler
+import orv.dataset.dataset as od
+if getattr(od, "__orv_amd_standin__", False):          # no reference on the path: this package's collate / sampler, raw-video classes refuse
+    assert od.CollateFunctionControl is data.CollateFunctionControl and od.BucketSampler is data.BucketSampler
+    try:
+        od.DemoRobotDataset(data_root="x")
+        raise SystemExit("DemoRobotDataset stand-in must refuse construction")
+    except NotImplementedError:
+        pass
+print("INSTALL-OK", len(names))
+'''
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "INSTALL-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

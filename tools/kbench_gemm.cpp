@@ -66,6 +66,36 @@ static void ab(int M,int N,int K,int epi,int rounds,int nt,char** tiles){
   orv_gemm_force_tile(0,0,0);
   hipFree(dA);hipFree(dW);hipFree(db);hipFree(dC);hipFree(dR);hipFree(dg);
 }
+
+// packed-A d8 kernel against the row-major t8 kernel, same process, interleaved: abp M N K epi rounds bn [cpacked]
+//   A is packed once with orv_pack_rows16; outputs compared bit for bit (same accumulation order).  cpacked = 1: d8 writes C packed (epi 0 / 1), unpacked for the check.
+static int abp(int M,int N,int K,int epi,int rounds,int bn,int cpacked){
+  auto A=rnd_bf((size_t)M*K,1.f,1), W=rnd_bf((size_t)N*K,0.05f,2), bias=rnd_bf(N,0.5f,3), R=rnd_bf((size_t)M*N,1.f,4);
+  uint16_t *dA=up(A),*dW=up(W),*db=up(bias),*dR=up(R); uint16_t *dC0,*dC1,*dCp,*dAp; const long Mp=orv_packed_rows(M);
+  CK(hipMalloc(&dC0,(size_t)M*N*2)); CK(hipMalloc(&dC1,(size_t)M*N*2)); CK(hipMalloc(&dCp,(size_t)Mp*N*2)); CK(hipMalloc(&dAp,(size_t)Mp*K*2));
+  CK(hipMemset(dC0,0,(size_t)M*N*2)); CK(hipMemset(dC1,0xff,(size_t)M*N*2));
+  if(orv_pack_rows16(dA,K,dAp,M,K,nullptr)){ printf("%s\n",orv_last_error()); return 1; }
+  int seq=3226; int B=(M+seq-1)/seq; int G=6; std::vector<float> gate((size_t)B*G*N); { std::mt19937 g(5); std::uniform_real_distribution<float> d(-1.f,1.f); for(auto&x:gate) x=d(g);} float* dg=up(gate);
+  orv_gemm_t g0{}; g0.A=dA; g0.lda=K; g0.W=dW; g0.ldw=K; g0.bias=db; g0.C=dC0; g0.ldc=N; g0.M=M; g0.N=N; g0.K=K; g0.epilogue=epi; g0.R=dR; g0.ldr=N; g0.gate=dg; g0.gate_b=(long)G*N; g0.gate_g=N; g0.grp={seq,226,600};
+  orv_gemm_t g1=g0; g1.A=dAp; g1.a_packed=1; g1.C=cpacked?dCp:dC1; g1.c_packed=cpacked;
+  hipEvent_t e0,e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  std::vector<double> tf[2]; const int iters = 2.0*M*N*K > 5e11 ? 8 : 30;
+  for(int r=0;r<rounds;r++) for(int t=0;t<2;t++){
+    orv_gemm_force_tile(t?5:3,256,bn); const orv_gemm_t* g=t?&g1:&g0;
+    if(orv_gemm_bf16(g,nullptr)){ printf("%s: %s\n",t?"d8":"t8",orv_last_error()); return 1; }
+    for(int i=0;i<2;i++) orv_gemm_bf16(g,nullptr);
+    CK(hipEventRecord(e0)); for(int i=0;i<iters;i++) orv_gemm_bf16(g,nullptr); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms,e0,e1)); ms/=iters;
+    tf[t].push_back(2.0*M*N*K/ms/1e9);
+  }
+  orv_gemm_force_tile(0,0,0);
+  if(cpacked){ if(orv_unpack_rows16(dCp,dC1,N,M,N,nullptr)){ printf("%s\n",orv_last_error()); return 1; } }
+  CK(hipDeviceSynchronize());
+  std::vector<uint16_t> c0((size_t)M*N), c1((size_t)M*N); CK(hipMemcpy(c0.data(),dC0,c0.size()*2,hipMemcpyDeviceToHost)); CK(hipMemcpy(c1.data(),dC1,c1.size()*2,hipMemcpyDeviceToHost));
+  size_t diff=0; double maxd=0; for(size_t i=0;i<c0.size();i++) if(c0[i]!=c1[i]){ diff++; maxd=fmax(maxd,fabs(bf2f(c0[i])-bf2f(c1[i]))); }
+  for(int t=0;t<2;t++){ std::sort(tf[t].begin(),tf[t].end()); printf("abp M=%5d N=%5d K=%5d epi=%d bn=%d %s: median %.0f  min %.0f  max %.0f TFLOP/s  (%.4f ms)\n",M,N,K,epi,bn,t?(cpacked?"d8 packed A, packed C":"d8 packed A          "):"t8 row-major         ",tf[t][tf[t].size()/2],tf[t].front(),tf[t].back(),2.0*M*N*K/tf[t][tf[t].size()/2]/1e9); }
+  printf("abp M=%5d N=%5d K=%5d epi=%d bn=%d: %zu of %zu outputs differ from t8 (max |diff| %.4g) %s\n",M,N,K,epi,bn,diff,c0.size(),maxd,diff?"MISMATCH":"BIT-IDENTICAL");
+  hipFree(dA);hipFree(dW);hipFree(db);hipFree(dR);hipFree(dC0);hipFree(dC1);hipFree(dCp);hipFree(dAp);hipFree(dg); return diff?1:0;
+}
 // warm vs cold operands: cold M N K epi iters   - the same GEMM with (a) one operand set reused, (b) the weights rotating through 32
 // buffers (every layer of the model has its own: HBM- and TLB-cold at each launch), (c) every operand rotating through 8 sets
 static void cold(int M,int N,int K,int epi,int iters){
@@ -93,6 +123,7 @@ int main(int argc,char**argv){
   if(orv_device_check(0)){ printf("%s\n",orv_last_error()); return 2; }
   if(argc>=7 && !strcmp(argv[1],"cold")){ cold(atoi(argv[2]),atoi(argv[3]),atoi(argv[4]),atoi(argv[5]),atoi(argv[6])); return 0; }
   if(argc>=9 && !strcmp(argv[1],"check")){ return check(atoi(argv[2]),atoi(argv[3]),atoi(argv[4]),atoi(argv[5]),atoi(argv[6]),atoi(argv[7]),atoi(argv[8])); }
+  if(argc>=8 && !strcmp(argv[1],"abp")){ return abp(atoi(argv[2]),atoi(argv[3]),atoi(argv[4]),atoi(argv[5]),atoi(argv[6]),atoi(argv[7]),argc>8?atoi(argv[8]):0); }
   if(argc>=8 && !strcmp(argv[1],"ab")){ ab(atoi(argv[2]),atoi(argv[3]),atoi(argv[4]),atoi(argv[5]),atoi(argv[6]),argc-7,argv+7); return 0; }
   if(argc>=7 && !strcmp(argv[1],"bench")){ bench(atoi(argv[2]),atoi(argv[3]),atoi(argv[4]),atoi(argv[5]),atoi(argv[6])); return 0; }
   int bad=0;
