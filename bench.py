@@ -611,13 +611,11 @@ def main():
             else ("attn_fwd_pp_kernel<false>" if os.environ.get("ORV_ATTN_PP", "1") != "0" else "attn_fwd_v2_kernel")
         for key, ms in timeline.items():
             if key[0] == "gemm":
-                _, M, N, K, epi = key
-                # kernel symbol as orv_gemm_bf16 dispatches it (cost-model tile choice), so it matches the rocprofv3 name
-                import ctypes
-                buf = ctypes.create_string_buffer(64)
-                check(lib().orv_gemm_kernel_name(M, N, K, epi, buf, 64), "orv_gemm_kernel_name")
-                sym = buf.value.decode()
-                flop, name = 2.0 * M * N * K, f"{sym} M={M} N={N} K={K}"
+                M, N, K, epi = key[1:5]
+                ap, cp = (key[5], key[6]) if len(key) > 5 else (0, 0)
+                # kernel symbol as orv_gemm_bf16 dispatches it (cost-model tile choice, packed-operand flags), so it matches the rocprofv3 name
+                sym = ops.gemm_kernel_name(M, N, K, epi, ap, cp)
+                flop, name = 2.0 * M * N * K, f"{sym} M={M} N={N} K={K}" + (" packed A" if ap else "") + (" packed C" if cp else "")
             else:
                 _, b, s, h = key
                 flop, name = 4.0 * b * h * s * s * 64, f"{attn_sym} B={b} S={s} H={h}"

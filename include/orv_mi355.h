@@ -178,6 +178,9 @@ int orv_unpack_rows16(const void* src, void* dst, long ld_dst, int M, int K, voi
 /* Kernel symbol (as rocprofv3 prints it, e.g. "gemm_pp_kernel<192, 5, 1>") that orv_gemm_bf16 launches for this shape on this
  * device: the tile is chosen by a cost model over all candidates, so callers that label timings ask. */
 int orv_gemm_kernel_name(int M, int N, int K, int epilogue, char* buf, int len);
+/* The same for a call with packed operands (orv_gemm_t.a_packed / c_packed); an error when no kernel takes the combination (the caller then
+ * keeps the row-major path). */
+int orv_gemm_kernel_name_packed(int M, int N, int K, int epilogue, int a_packed, int c_packed, char* buf, int len);
 /* Developer switch (sweeps, same-process A/B, per-instantiation tests): pin the tile candidate (kernel family `ring`: 0 simple,
  * 1 ring, 2 phased, 3 t8; tile bm x bn) for all later orv_gemm_bf16 calls of this process; bm = 0 returns to the cost model.
  * Same effect as the environment variable ORV_GEMM_TILE="ring,bm,bn" read at the first call. */
@@ -277,6 +280,11 @@ int orv_attention_fwd(const void* qkv, int ld_qkv, const void* vT, void* out, in
  * otherwise identical to orv_attention_fwd.  lse as there. */
 int orv_attention_fwd_bounded(const void* qkv, int ld_qkv, void* out, int ld_out, float* lse, int B, int S, int H, float scale,
                               float score_bound, void* stream);
+/* orv_attention_fwd_bounded writing `out` in the packed P16 layout (orv_gemm_t: orv_packed_rows(B S) x (H 64) bf16, 16-byte aligned) - the A
+ * operand of the attention out-projection (cogvideox_control.py:263) without a row-major copy.  Needs scale * log2(e) == 1 (q pre-multiplied)
+ * and 0 < score_bound <= orv_attention_static_limit(1): the caller checks and otherwise uses the row-major entry points. */
+int orv_attention_fwd_packed(const void* qkv, int ld_qkv, void* out, float* lse, int B, int S, int H, float scale, float score_bound,
+                             void* stream);
 /* orv_attention_fwd_bounded with a workspace: at shapes whose grid ends in a small extra round of workgroups (the headline shape:
  * 1560 workgroups on 512 slots) the items of that round are cut into key ranges whose unnormalised partial results meet in `ws`
  * (fixed summation order: deterministic).  ws >= orv_attention_ws_bytes(B, S, H) bytes, 256-byte aligned, reusable across calls on one

@@ -59,6 +59,7 @@ SIGNATURES = {
     "orv_qkv_prep_from": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
     "orv_gemm_kernel_name": (c_int, [c_int, c_int, c_int, c_int, ctypes.c_char_p, c_int]),
+    "orv_gemm_kernel_name_packed": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, ctypes.c_char_p, c_int]),
     "orv_gemm_force_tile": (c_int, [c_int, c_int, c_int]),
     "orv_gemm_tn_bf16": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p]),
     "orv_gemm_bf16": (c_int, [POINTER(Gemm), c_void_p]),
@@ -68,6 +69,7 @@ SIGNATURES = {
     "orv_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                   c_float, c_void_p]),
     "orv_attention_fwd_bounded": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p]),
+    "orv_attention_fwd_packed": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p]),
     "orv_attention_static_limit": (c_float, [c_int]),
     "orv_attention_ws_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "orv_attention_fwd_bounded_ws": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p,

@@ -525,10 +525,31 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             # attention workspace: partial results of the key-split last round (orv_attention_fwd_bounded_ws); None when the shape's
             # grid has no small last round (B = 1, B = 2, the 5B widths)
             nb = ops.attention_ws_bytes(B, S, H)
-            self._ws = {key: dict(x=e(M, D), xn=e(M, D), qkv=e(M, 3 * D), att=e(M, D), h=e(M, 4 * D), vis=e(B * Nv, D),
+            # att and h carry orv_packed_rows(M) row slots: on the packed path (below) they hold the P16 layout, else rows [0, M) row-major
+            Mp = ops.packed_rows(M)
+            self._ws = {key: dict(x=e(M, D), xn=e(M, D), qkv=e(M, 3 * D), att=e(Mp, D), h=e(Mp, 4 * D), vis=e(B * Nv, D),
                                   vis2=e(B * Nv, D), s_pad=s_pad,
-                                  attn_ws=torch.empty(nb, dtype=torch.uint8, device=dev) if nb else None)}
+                                  attn_ws=torch.empty(nb, dtype=torch.uint8, device=dev) if nb else None,
+                                  packed=self._packed_plan(M, D))}
         return self._ws[key]
+
+    @staticmethod
+    def _packed_plan(M, D):
+        """Which GEMMs of a block take their A operand in the packed P16 layout (round 5, csrc/gemm_d8.hip: A straight to registers, twice
+        the bytes in flight of the LDS-staged kernel; bit-identical results).  The producer must be an MFMA kernel that writes the layout for
+        free - FFN2's A is FFN1's GELU epilogue (cogvideox_control.py:439 -> :440), the out-projection's A is the attention output (:256-263) -
+        and the d8 kernel must be the better choice for the shape: exactly where the row-major cost model picks the 256 x 192 t8 tile
+        (same tile count; B = 1 and other single-round shapes keep their smaller row-major tiles).  ``ORV_GEMM_PACKED=0``: A/B switch."""
+        plan = {"ffn": False, "out": False}
+        if os.environ.get("ORV_GEMM_PACKED", "1") == "0":
+            return plan
+        t8_192 = "gemm_t8_kernel<192, 2>"
+        if (ops.gemm_kernel_name(M, D, 4 * D, 2) == t8_192 and ops.gemm_kernel_name(M, D, 4 * D, 2, a_packed=True) is not None
+                and ops.gemm_kernel_name(M, 4 * D, D, 1, c_packed=True) is not None):
+            plan["ffn"] = True
+        if ops.gemm_kernel_name(M, D, D, 2) == t8_192 and ops.gemm_kernel_name(M, D, D, 2, a_packed=True) is not None:
+            plan["out"] = True
+        return plan
 
     def _view_pos_table(self, pos, n_view, T, P, dev):
         key = ("posv", n_view, T, P, str(dev))
@@ -673,6 +694,7 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         S = Nt + Nv
         ws = self._workspace(B, S, Nv, dev)
         x, xn, qkv, att, hbuf, s_pad = ws["x"], ws["xn"], ws["qkv"], ws["att"], ws["h"], ws["s_pad"]
+        packed = ws["packed"]
 
         # 1. time (+ofs) embedding  (:762-775)
         tvec = torch.as_tensor(timestep, device=dev).reshape(-1).to(torch.float32)
@@ -793,15 +815,21 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             ops.layernorm_modulate(x, xn, blk.norm1.norm.weight, blk.norm1.norm.bias, m1[..., D:2 * D], m1[..., :D],
                                    mb, mg, grp, B, D, c.norm_eps)
             self._qkv_projection(at, xn, qkv, rope, B, S, heads, Nt, s_pad, scale)
-            ops.attention_fwd(qkv, None, att, B, S, heads, s_pad, 1.0 / LOG2E, score_bound=at.score_bound(scale), ws=ws["attn_ws"])
+            bound = at.score_bound(scale)
+            # packed path: the attention kernel writes its output, the FFN1 GELU epilogue the hidden state, in the P16 layout the d8 GEMM reads
+            att_p = packed["out"] and ws["attn_ws"] is None and ops.attention_packed_ok(bound, 1.0 / LOG2E)
+            if att_p:
+                ops.attention_fwd(qkv, None, att, B, S, heads, s_pad, 1.0 / LOG2E, score_bound=bound, out_packed=True)
+            else:
+                ops.attention_fwd(qkv, None, att, B, S, heads, s_pad, 1.0 / LOG2E, score_bound=bound, ws=ws["attn_ws"])
             ops.gemm(att, at.to_out[0].weight, at.to_out[0].bias, x, M, D, D, epilogue=2, R=x, ldr=D,
-                     gate=m1[..., 2 * D:], gate_b=mb, gate_g=mg, grp=grp)
+                     gate=m1[..., 2 * D:], gate_b=mb, gate_g=mg, grp=grp, a_packed=att_p)
             ops.layernorm_modulate(x, xn, blk.norm2.norm.weight, blk.norm2.norm.bias, m2[..., D:2 * D], m2[..., :D],
                                    mb, mg, grp, B, D, c.norm_eps)
             f0, f2 = blk.ff.net[0].proj, blk.ff.net[2]
-            ops.gemm(xn, f0.weight, f0.bias, hbuf, M, f0.weight.shape[0], D, epilogue=1)
+            ops.gemm(xn, f0.weight, f0.bias, hbuf, M, f0.weight.shape[0], D, epilogue=1, c_packed=packed["ffn"])
             ops.gemm(hbuf, f2.weight, f2.bias, x, M, D, f0.weight.shape[0], epilogue=2, R=x, ldr=D,
-                     gate=m2[..., 2 * D:], gate_b=mb, gate_g=mg, grp=grp)
+                     gate=m2[..., 2 * D:], gate_b=mb, gate_g=mg, grp=grp, a_packed=packed["ffn"])
 
         # 6. head: norm_final is row-wise, so the 2B (:916) and 5B (:911-913) branches are the same arithmetic on the
         #    video rows; read them in place from the joint buffer.

@@ -44,6 +44,9 @@ struct AttnArgs {
     // outputs meet in ws_o / ws_l; ws_cnt[r] counts the arrivals of item r (zeroed by the launch function).
     float* ws_o; float* ws_l; unsigned* ws_cnt;
     int n_full, ks;
+    // orv_attention_fwd_packed: `out` is the P16 layout (include/orv_mi355.h orv_gemm_t) of the [B S, H 64] output, ld_out = H 64 - the A
+    // operand of the out-projection GEMM (gemm_d8.hip) without a row-major copy in between.  attn_fwd_pp_kernel<true, false> only.
+    int out_packed = 0;
 };
 // true = this kernel form is the one the device-side bound selects
 __device__ __forceinline__ bool attn_guard_selects(const AttnArgs& p, bool static_form) {
@@ -793,6 +796,10 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_pp_kernel(const AttnArgs p) {
         // lane holds d = 32 db + 8 qd + 4 hi + (0..3) of row q: groups qd = 2 u (lower half-wave) and 2 u + 1 (upper) are exchanged
         // so that every lane stores ONE aligned 16-byte piece: lower -> d 32 db + 16 u + 0..7, upper -> + 8..15
         bf16_t* op = p.out + (row0 + q) * p.ld_out + h * 64 + hi * 8;
+        // packed output: the piece (row m, columns h 64 + 32 db + 16 u + 8 hi + 0..7) is 16-byte slot (2 u + hi) * 16 + m % 16 of block
+        // (m / 16, 2 h + db): consecutive rows = consecutive slots, so the 32 lanes of a half-wave write 2 x 256 contiguous bytes
+        const long m_ = row0 + q;
+        char* const pblk = (char*)p.out + (((m_ >> 4) * (p.ld_out >> 5) + 2 * h) << 10) + ((hi * 16 + (m_ & 15)) << 4);
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -804,7 +811,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_pp_kernel(const AttnArgs p) {
                 // a of the upper half-wave <-> b of the lower half-wave
                 { const auto r = __builtin_amdgcn_permlane32_swap(a0, b0, false, false); a0 = r[0]; b0 = r[1]; }
                 { const auto r = __builtin_amdgcn_permlane32_swap(a1, b1, false, false); a1 = r[0]; b1 = r[1]; }
-                *(uint4*)(op + db * 32 + u * 16) = make_uint4(a0, a1, b0, b1);
+                if (!SPLIT && p.out_packed) *(uint4*)(pblk + db * 1024 + u * 512) = make_uint4(a0, a1, b0, b1);
+                else *(uint4*)(op + db * 32 + u * 16) = make_uint4(a0, a1, b0, b1);
             }
         if (write_lse && p.lse && hi == 0)
             p.lse[((long)b * p.H + h) * p.S + q] = (STATIC ? __log2f(l_tot) : m_run + __log2f(l_tot)) * 0.6931471805599453f;
@@ -1220,6 +1228,27 @@ extern "C" int orv_attention_fwd_bounded(const void* qkv, int ld_qkv, void* out,
     else
         hipLaunchKernelGGL((attn_fwd_v2_kernel<true, true, true>), grid, dim3(512), 0, (hipStream_t)stream, a);
     return orv_check_launch("orv_attention_fwd_bounded");
+}
+
+// orv_attention_fwd_bounded with the output in the packed P16 layout (orv_gemm_t.a_packed of the out-projection, cogvideox_control.py:263).
+// Only the shift-free ping-pong kernel writes it: the caller checks 0 < score_bound <= orv_attention_static_limit(1) first (else: row-major
+// output + the row-major GEMM).  `out` holds orv_packed_rows(B S) x (H 64) bf16.
+extern "C" int orv_attention_fwd_packed(const void* qkv, int ld_qkv, void* out, float* lse, int B, int S, int H, float scale, float score_bound,
+                                        void* stream) {
+    const float scale_log2 = scale * 1.4426950408889634f;
+    ORV_REQUIRE(qkv && out, "orv_attention_fwd_packed: null operand");
+    ORV_REQUIRE(B > 0 && S > 0 && H > 0, "orv_attention_fwd_packed: empty problem");
+    ORV_REQUIRE(ld_qkv % 8 == 0 && ((uintptr_t)out & 15) == 0, "orv_attention_fwd_packed: misaligned operand");
+    ORV_REQUIRE(fabsf(scale_log2 - 1.0f) < 1e-6f && score_bound > 0.f && score_bound <= ORV_STATIC_LIMIT_PP,
+                "orv_attention_fwd_packed: needs the fused scale (scale * log2 e == 1) and 0 < score_bound <= %g (got scale %g bound %g)",
+                (double)ORV_STATIC_LIMIT_PP, (double)scale, (double)score_bound);
+    AttnArgs a;
+    a.qkv = (const bf16_t*)qkv; a.ld = ld_qkv; a.vT = nullptr; a.out = (bf16_t*)out; a.ld_out = (long)H * 64;
+    a.lse = lse; a.B = B; a.S = S; a.H = H; a.s_pad = 0;
+    a.scale = scale; a.scale_log2 = scale_log2; a.shift = score_bound; a.guard_dev = nullptr; a.guard_limit = 0.f; a.ws_o = a.ws_l = nullptr; a.ws_cnt = nullptr; a.n_full = a.ks = 0;
+    a.out_packed = 1;
+    hipLaunchKernelGGL((attn_fwd_pp_kernel<true>), dim3(((S + 255) / 256) * H * B), dim3(512), 0, (hipStream_t)stream, a);
+    return orv_check_launch("orv_attention_fwd_packed");
 }
 
 // Key-split tail (orv_attention_fwd_bounded_ws).  The grid of the ping-pong kernel is ceil(S / 256) H B workgroups on 2 x CUs slots: at

@@ -1314,7 +1314,7 @@ extern "C" int orv_gemm_force_tile(int ring, int bm, int bn) {
 // what matters at small batch, where a "better" tile that needs one more, nearly empty, round loses to a smaller one that
 // fills the chip (B = 1: N = 1920 GEMMs take 195 tiles of 256x128 instead of 260 of 128x192).
 // wide: an operand spans 4 GiB or more - the t8 kernel addresses A and W with 32-bit byte offsets and is skipped
-static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int heads = 0, bool wide = false, bool packed = false) {
+static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int heads = 0, bool wide = false, bool packed = false, bool cpacked = false) {
     static const GemmCand cands[] = {
         // ring = 3: the 16x16x32 8-phase kernel of gemm_t8.hip (persistent, BK = 64; needs an even number of K-tiles)
         {3, 256, 256, 1.29f, 0}, {3, 256, 192, 1.21f, 0},
@@ -1357,6 +1357,8 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
         if (c.ring == 4 && (K % 128 != 0 || wide || epilogue > 2 || force_ring != 4)) continue;
         // ring 5 reads A in the packed P16 layout and nothing else does: the caller's a_packed decides the family
         if ((c.ring == 5) != packed) continue;
+        // packed C from row-major A: only the t8 kernel's 256-wide GELU epilogue writes it
+        if (cpacked && !packed && !(c.ring == 3 && c.bn == 256 && epilogue == 1)) continue;
         if (c.ring == 5 && (K % 192 != 0 || no_d8)) continue;
         // epilogue 4 normalises whole 64-wide heads inside a wave (BN / 2 columns) that must not straddle q | k | v
         if (epilogue == 4 && c.ring != 5 && (c.bm == 192 || (c.bn / 2) % 64 != 0 || (heads * 64) % (c.bn / 2) != 0)) continue;
@@ -1385,12 +1387,12 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
 // cost model puts the q | k part on the t8 kernel: 0.247 vs 0.286 ms per layer at B = 4 (profiles/r3_gemm_t8_ab.txt).  The A
 // operand is read by both launches (L2 / Infinity Cache).  ORV_GEMM_QKV_SPLIT=0: A/B switch.
 static bool plan_gemm(int M, int N, int K, int epilogue, int heads, const GemmCand*& first, const GemmCand*& second, bool wide = false,
-                      bool packed = false) {
+                      bool packed = false, bool cpacked = false) {
     static int qkv_split = -1;
     if (qkv_split < 0) { const char* e = getenv("ORV_GEMM_QKV_SPLIT"); qkv_split = (e && atoi(e) == 0) ? 0 : 1; }
     second = nullptr;
-    first = choose_tile(M, N, K, epilogue, heads, wide, packed);
-    if (packed) return first != nullptr;      // the d8 kernel normalises 64-column groups at any BN: no q | k + v split
+    first = choose_tile(M, N, K, epilogue, heads, wide, packed, cpacked);
+    if (packed || cpacked) return first != nullptr;      // the d8 kernel normalises 64-column groups at any BN: no q | k + v split
     if (epilogue == 4 && qkv_split && heads > 0 && N == 3 * heads * 64 && !(first && first->ring == 3)) {
         const GemmCand* qk = choose_tile(M, 2 * heads * 64, K, 4, heads, wide);
         const GemmCand* vv = choose_tile(M, heads * 64, K, 0, 0, wide);
@@ -1417,6 +1419,16 @@ extern "C" int orv_gemm_kernel_name(int M, int N, int K, int epilogue, char* buf
         const int n = (int)strlen(buf);
         if (n + 4 < len) { snprintf(buf + n, len - n, " + "); cand_name(c2, 0, buf + n + 3, len - n - 3); }
     }
+    return ORV_OK;
+}
+
+// orv_gemm_kernel_name for a call with packed operands (orv_gemm_t.a_packed / c_packed): fails when no kernel takes that combination
+extern "C" int orv_gemm_kernel_name_packed(int M, int N, int K, int epilogue, int a_packed, int c_packed, char* buf, int len) {
+    ORV_REQUIRE(buf && len > 0 && M > 0 && N > 0 && N % 64 == 0, "orv_gemm_kernel_name_packed: bad arguments");
+    const GemmCand *c = nullptr, *c2 = nullptr;
+    ORV_REQUIRE(plan_gemm(M, N, K, epilogue, epilogue == 4 ? N / 192 : 0, c, c2, false, a_packed != 0, c_packed != 0),
+                "orv_gemm_kernel_name_packed: no kernel for N=%d K=%d epilogue %d a_packed=%d c_packed=%d", N, K, epilogue, a_packed, c_packed);
+    cand_name(c, epilogue, buf, len);
     return ORV_OK;
 }
 
@@ -1504,8 +1516,8 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
     const GemmCand *first = nullptr, *second = nullptr;
     const bool wide = (long)g->M * g->lda * 2 >= (1L << 32) || (long)g->N * g->ldw * 2 >= (1L << 32);
     ORV_REQUIRE(!g->a_packed || g->lda == g->K, "orv_gemm_bf16: a packed A has lda == K (lda=%d K=%d)", g->lda, g->K);
-    ORV_REQUIRE(!g->c_packed || g->a_packed, "orv_gemm_bf16: packed C is written by the kernel that reads packed A (a_packed) only");
-    ORV_REQUIRE(plan_gemm(g->M, g->N, g->K, g->epilogue, g->qn_heads, first, second, wide, g->a_packed != 0),
+    ORV_REQUIRE(!g->c_packed || g->a_packed || g->epilogue == 1, "orv_gemm_bf16: packed C from a row-major A needs epilogue 1 (the t8 GELU epilogue)");
+    ORV_REQUIRE(plan_gemm(g->M, g->N, g->K, g->epilogue, g->qn_heads, first, second, wide, g->a_packed != 0, g->c_packed != 0),
                 "orv_gemm_bf16: no tile configuration for N=%d (ORV_GEMM_TILE override?)", g->N);
     if (!second) return gemm_dispatch(a, first, g->epilogue, st);
     const int nqk = 2 * g->qn_heads * 64;

@@ -363,10 +363,11 @@ __global__ __launch_bounds__(512) void gemm_d8_kernel(const GemmArgs p) {
         if ((S) == ND + 3) { D8_LOADA(ANEW[3], voffA[1], sa_, 1024)                                                  \
             if (__builtin_expect(++kA == nk, 0)) { kA = 0; tA += gridDim.x; D8_SETUP_A(tA) } }                       \
     }
-    // slots: BN = 256 one per phase (8 phases, 8 slots), BN = 192 two per phase (4 phases, 7 slots), behind the steps CBP / 2 and CBP + CBP / 2
+    // the ND + 4 slots of a K-tile are spread evenly over its 2 NCB steps (one step = one W fragment = two MFMAs): slot i sits behind
+    // step ((2 i + 1) * 2 NCB) / (2 (ND + 4))
 #define D8_STEP_SLOT(PH, S, ANEW, DBUF)                                                                              \
-    if constexpr (BN == 256) { if ((S) == 1) { D8_SLOT((PH), ANEW, DBUF) } }                                         \
-    else { if ((S) == 1) { D8_SLOT(2 * (PH), ANEW, DBUF) } if ((S) == 4) { D8_SLOT(2 * (PH) + 1, ANEW, DBUF) } }
+    _Pragma("unroll") for (int i_ = 0; i_ < ND + 4; ++i_)                                                            \
+        if ((PH) * 2 * CBP + (S) == ((2 * i_ + 1) * 2 * NCB) / (2 * (ND + 4))) { D8_SLOT(i_, ANEW, DBUF) }
     // phase PH of a K-tile: RBUF / RPH = buffer offset and phase the re-requested fragments belong to
 #define D8_PHASE(RBUF, RPH, ACUR, ANEW, PH, DBUF)                                                                    \
     _Pragma("unroll") for (int s_ = 0; s_ < 2 * CBP; ++s_) {                                                         \
@@ -374,6 +375,11 @@ __global__ __launch_bounds__(512) void gemm_d8_kernel(const GemmArgs p) {
         D8_READ1(s_ % CBP, s_ / CBP, RBUF, RPH) D8_FENCE()                                                           \
         D8_STEP_SLOT(PH, s_, ANEW, DBUF) D8_FENCE()                                                                  \
     }
+#ifdef ORV_D8_ABL_NOWAIT     // ablation (wrong results): is the K loop waiting for its own loads?
+#define D8_WAIT(ACUR) asm volatile("" : "+v"(ACUR[0]), "+v"(ACUR[1]), "+v"(ACUR[2]), "+v"(ACUR[3]));
+#else
+#define D8_WAIT(ACUR) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ACUR[0]), "+v"(ACUR[1]), "+v"(ACUR[2]), "+v"(ACUR[3]) : "n"(ND + 4) : "memory");
+#endif
     // One K-tile u.  ACUR: the A set it computes with; ANEW: the set K-tile u - 1 used, refilled for K-tile u + 2.  bufc = u & 3.
     //   wait: this wave's group of two K-tiles ago = { W pieces of K-tile u + 1, A of K-tile u } (the group of K-tile u - 1 stays in flight)
     //   barrier: every wave's pieces of K-tile u + 1 have landed, every wave is done with the buffer of K-tile u - 1
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(512) void gemm_d8_kernel(const GemmArgs p) {
     //   this K-tile's group (W pieces of K-tile u + 3 into the buffer of K-tile u - 1, A of K-tile u + 2) is issued slot by slot
 #define D8_KTILE(ACUR, ANEW)                                                                                         \
     {                                                                                                                \
-        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ACUR[0]), "+v"(ACUR[1]), "+v"(ACUR[2]), "+v"(ACUR[3]) : "n"(ND + 4) : "memory"); \
+        D8_WAIT(ACUR)                                                                                                \
         D8_FENCE() __builtin_amdgcn_s_barrier(); D8_FENCE()                                                          \
         const int cur_ = bufc * BUFSZ, nxt_ = ((bufc + 1) & 3) * BUFSZ, dbuf_ = (bufc + 3) & 3;                      \
         _Pragma("unroll") for (int pp_ = 0; pp_ < NPH; ++pp_) {                                                      \

@@ -231,6 +231,12 @@ __device__ __forceinline__ void t8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][4
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] *= gelu_tanh_grad(rv[e]);
                     }
+                    if (BN == 256 && EPI == 1 && p.c_packed) {
+                        // packed P16 output (orv_gemm_t.c_packed: the hidden state of FeedForward, cogvideox_control.py:439 -> :440, as the A
+                        // operand of gemm_d8): lane (r16, g) holds columns 32 P + 8 g + (0..7) of row r16 = slot 16 g + r16 of packed block
+                        // (row block, column block) - one lane-linear, contiguous 1-KiB store; the buffer has tiles_m * 256 row slots (no mask)
+                        if (st_ok) *(uint4*)((char*)p.C + ((((long)((mbase + mh * 64 + mb * 16) >> 4)) * (p.ldc >> 5) + ((nbase + 32 * P) >> 5)) << 10) + lane * 16) = pack8(v);
+                    } else
                     if (valid[mb] && st_ok) *(uint4*)(crow + col8[P]) = pack8(v);
                 }
                 if (TAIL) {
@@ -1393,6 +1399,10 @@ int launch_t4(const GemmArgs& a, int epi, hipStream_t st) {
 int launch_t8(const GemmArgs& a, int bn, int epi, hipStream_t st) {
     if ((long)a.M * a.lda * 2 >= (1L << 32) || (long)a.N * a.ldw * 2 >= (1L << 32)) {
         orv_set_error("orv_gemm_bf16: the t8 kernel addresses A / W with 32-bit byte offsets (M=%d lda=%ld N=%d ldw=%ld)", a.M, a.lda, a.N, a.ldw);
+        return ORV_EINVAL;
+    }
+    if (a.a_packed || (a.c_packed && (bn != 256 || epi != 1 || a.ldc != a.N || a.c_rows > 0 || a.Y))) {
+        orv_set_error("orv_gemm_bf16: the t8 kernel reads row-major A and writes packed C only as BN = 256, epilogue 1, ldc == N, no row map / Y");
         return ORV_EINVAL;
     }
     if (bn == 256) {

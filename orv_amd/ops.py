@@ -177,10 +177,46 @@ def qkv_prep(qkv, vT, gq, bq, gk, bk, rope: Optional[Tuple[torch.Tensor, torch.T
                                   _p(sin), B, S, H, n_text, s_pad, float(eps), float(q_premul), _stream()), "orv_qkv_prep")
 
 
+def packed_rows(rows: int) -> int:
+    """Row slots of a packed P16 buffer holding ``rows`` rows (include/orv_mi355.h ``orv_gemm_t``: rounded up to the 256-row GEMM tile)."""
+    return int(lib().orv_packed_rows(int(rows)))
+
+
+def pack_rows16(src, M, K, dst=None, ld_src=None):
+    """Row-major ``src`` [M, K] -> packed P16 ``dst`` [packed_rows(M), K] (bit copies, padding rows zero)."""
+    _need(src, BF16, "src")
+    if dst is None:
+        dst = torch.empty(packed_rows(M), K, dtype=BF16, device=src.device)
+    check(lib().orv_pack_rows16(_p(src), ld_src or K, _p(_need(dst, BF16, "dst")), M, K, _stream()), "orv_pack_rows16")
+    return dst
+
+
+def unpack_rows16(src, M, K, dst=None, ld_dst=None):
+    """Packed P16 ``src`` -> row-major ``dst`` [M, K]."""
+    _need(src, BF16, "src")
+    if dst is None:
+        dst = torch.empty(M, K, dtype=BF16, device=src.device)
+    check(lib().orv_unpack_rows16(_p(src), _p(_need(dst, BF16, "dst")), ld_dst or K, M, K, _stream()), "orv_unpack_rows16")
+    return dst
+
+
+def gemm_kernel_name(M, N, K, epilogue=0, a_packed=False, c_packed=False) -> Optional[str]:
+    """Kernel symbol ``gemm`` launches for this call, or None when no kernel takes the packed-operand combination."""
+    import ctypes
+    buf = ctypes.create_string_buffer(96)
+    if a_packed or c_packed:
+        rc = lib().orv_gemm_kernel_name_packed(M, N, K, epilogue, int(bool(a_packed)), int(bool(c_packed)), buf, 96)
+        return buf.value.decode() if rc == 0 else None
+    check(lib().orv_gemm_kernel_name(M, N, K, epilogue, buf, 96), "orv_gemm_kernel_name")
+    return buf.value.decode()
+
+
 def gemm(A, W, bias, C, M, N, K, epilogue=0, R=None, r_mod=0, gate=None, gate_b=0, gate_g=0, grp: Optional[Groups] = None,
-         cmap: Optional[RowMap] = None, lda=None, ldw=None, ldc=None, ldr=None, Y=None, ldy=None, qknorm=None):
+         cmap: Optional[RowMap] = None, lda=None, ldw=None, ldc=None, ldr=None, Y=None, ldy=None, qknorm=None,
+         a_packed=False, c_packed=False):
     """``qknorm`` = (gamma_q, beta_q, gamma_k, beta_k, eps, q_premul, heads) with ``epilogue=4``: the QKV projection with the
-    per-head qk LayerNorm fused (no RoPE)."""
+    per-head qk LayerNorm fused (no RoPE).  ``a_packed`` / ``c_packed``: A is read / C is written in the packed P16 layout
+    (include/orv_mi355.h ``orv_gemm_t``; buffers of ``packed_rows(M)`` row slots)."""
     _need(A, BF16, "A"), _need(W, BF16, "W"), _need(C, BF16, "C")
     g = Gemm()
     if qknorm is not None:
@@ -194,7 +230,8 @@ def gemm(A, W, bias, C, M, N, K, epilogue=0, R=None, r_mod=0, gate=None, gate_b=
     g.grp = grp or Groups(0, 0, 0)
     g.cmap = cmap or RowMap(0, 0, 0)
     g.Y, g.ldy = _p(Y), ldy or N
-    with _timed(("gemm", M, N, K, epilogue)):
+    g.a_packed, g.c_packed = int(bool(a_packed)), int(bool(c_packed))
+    with _timed(("gemm", M, N, K, epilogue) + ((int(bool(a_packed)), int(bool(c_packed))) if (a_packed or c_packed) else ())):
         check(lib().orv_gemm_bf16(g, _stream()), "orv_gemm_bf16")
     return C
 
@@ -218,11 +255,25 @@ def attention_ws_bytes(B, S, H):
     return int(lib().orv_attention_ws_bytes(int(B), int(S), int(H)))
 
 
-def attention_fwd(qkv, vT, out, B, S, H, s_pad, scale, lse=None, ld_qkv=None, ld_out=None, score_bound=None, score_bound_dev=None, ws=None):
+def attention_packed_ok(score_bound, scale) -> bool:
+    """Can ``attention_fwd(..., out_packed=True)`` run this call?  (Only the shift-free ping-pong kernel writes the packed layout.)"""
+    return (score_bound is not None and 0.0 < float(score_bound) <= float(lib().orv_attention_static_limit(1))
+            and abs(float(scale) * 1.4426950408889634 - 1.0) < 1e-6
+            and os.environ.get("ORV_ATTN_PP", "1") != "0" and os.environ.get("ORV_ATTN_STATIC", "1") != "0")
+
+
+def attention_fwd(qkv, vT, out, B, S, H, s_pad, scale, lse=None, ld_qkv=None, ld_out=None, score_bound=None, score_bound_dev=None, ws=None,
+                  out_packed=False):
     """``score_bound`` (V in place only): a guaranteed upper bound of |q . k| * scale * log2(e) over the whole call - the kernel
     then runs its fixed-shift softmax when the bound is small enough (``orv_attention_fwd_bounded``).  ``score_bound_dev``: the
-    same bound as a one-element fp32 DEVICE tensor (``orv_attention_fwd_bounded_dev``: no host read; training)."""
+    same bound as a one-element fp32 DEVICE tensor (``orv_attention_fwd_bounded_dev``: no host read; training).
+    ``out_packed``: ``out`` is a packed P16 buffer [packed_rows(B S), H 64] (``orv_attention_fwd_packed``; check ``attention_packed_ok``)."""
     _need(qkv, BF16, "qkv"), _need(out, BF16, "out")
+    if out_packed:
+        with _timed(("attention", B, S, H)):
+            check(lib().orv_attention_fwd_packed(_p(qkv), ld_qkv or 3 * H * 64, _p(out), _p(lse), B, S, H, float(scale), float(score_bound),
+                                                 _stream()), "orv_attention_fwd_packed")
+        return out
     if score_bound_dev is not None and vT is None:
         _need(score_bound_dev, torch.float32, "score_bound_dev")
         if score_bound_dev.numel() != 1:

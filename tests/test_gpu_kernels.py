@@ -886,3 +886,183 @@ def test_attention_16x16x32_variant_matches_in_a_subprocess():
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "passed" in r.stdout
+
+
+# ---- round 5: packed P16 operands (include/orv_mi355.h orv_gemm_t), the d8 GEMM that reads them, their producers ----
+@pytest.mark.parametrize("M,K", [(1, 32), (300, 192), (3226, 1920), (4097, 64)])
+def test_pack_rows16_is_index_exact_and_invertible(M, K):
+    """orv_pack_rows16 / orv_unpack_rows16: element (r, k) sits at block ((r / 16) * K / 32 + k / 32) KiB, slot ((k % 32) / 8) * 16 + r % 16,
+    lane-linear - checked against the index formula itself (bit copies), padding rows zero, round trip exact."""
+    from orv_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M, K, generator=g).to(BF).to(dev)
+    p = ops.pack_rows16(a, M, K)
+    Mp = ops.packed_rows(M)
+    assert p.shape == (Mp, K) and Mp % 256 == 0 and Mp - M < 256
+    ref = torch.zeros(Mp, K, dtype=BF, device=dev)
+    ref[:M] = a
+    # [R, 16, C, 4, 8] (row block, row, k block, chunk, element) -> [R, C, 4, 16, 8]
+    want = ref.view(Mp // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(Mp, K)
+    assert torch.equal(p.view(torch.int16), want.view(torch.int16))
+    assert torch.equal(ops.unpack_rows16(p, M, K).view(torch.int16), a.view(torch.int16))
+
+
+@pytest.mark.parametrize("bn", [256, 192])
+def test_d8_gemm_on_packed_a_is_bit_identical_to_t8(bn):
+    """gemm_d8_kernel (A straight to registers from the packed layout, W through four LDS buffers, one barrier per K-tile) accumulates every
+    output element in gemm_t8_kernel's order (K-tiles ascending, k halves 0 / 1, the same k chunk per lane group) and runs the same epilogue
+    arithmetic: bias, GELU, gated residual with per-token-group gates straddling 16-row blocks, row scatter, r_mod, GELU adjoint, the Y side
+    output - bit-identical; the fused qk LayerNorm reduces in another lane order (8-lane DPP sums vs half-swaps): tolerance.  Ragged M,
+    one K-tile triple (K = 192) up to K = 1920, single- and multi-round grids."""
+    from orv_amd import ops
+    from orv_amd._lib import lib
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(50 + bn)
+    N = bn * 3
+
+    def same(a, b, what):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (what, (a.float() - b.float()).abs().max().item())
+
+    for M, K in [(100, 384), (3226 * 2, 384), (12904, 1920), (70000, 384)]:      # K % 128 == 0 (t8) and K % 192 == 0 (d8)
+        A = torch.randn(M, K, device=dev, generator=g).to(BF)
+        W = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(BF)
+        bias = torch.randn(N, device=dev, generator=g).to(BF)
+        R = torch.randn(M, N, device=dev, generator=g).to(BF)
+        Ap = ops.pack_rows16(A, M, K)
+        assert ops.gemm_kernel_name(M, N, K, 0, a_packed=True).startswith("gemm_d8_kernel<")
+        for epi in (0, 1, 2, 3):
+            outs = []
+            for packed in (False, True):
+                C = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+                Y = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+                lib().orv_gemm_force_tile(5 if packed else 3, 256, bn)       # N = 3 bn divides by both widths: pin the one under test
+                try:
+                    ops.gemm(Ap if packed else A, W, None if epi == 3 else bias, C, M, N, K, epilogue=epi, Y=Y, a_packed=packed,
+                             **(dict(R=R, ldr=N) if epi >= 2 else {}))
+                finally:
+                    lib().orv_gemm_force_tile(0, 0, 0)
+                outs.append((C, Y))
+            same(outs[0][0], outs[1][0], (bn, M, K, epi, "C")), same(outs[0][1], outs[1][1], (bn, M, K, epi, "Y"))
+    # gated residual with token groups (gate rows change inside 16-row blocks), row scatter into a joint buffer, r_mod residual
+    # K = 192 (one trip of the three-K-tile loop: the t8 kernel cannot run it) against whatever the row-major cost model picks: tolerance
+    M, K = 777, 192
+    A = torch.randn(M, K, device=dev, generator=g).to(BF)
+    W = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(BF)
+    bias = torch.randn(N, device=dev, generator=g).to(BF)
+    c0 = torch.empty(M, N, dtype=BF, device=dev)
+    c1 = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+    ops.gemm(A, W, bias, c0, M, N, K, epilogue=1)
+    lib().orv_gemm_force_tile(5, 256, bn)
+    try:
+        ops.gemm(ops.pack_rows16(A, M, K), W, bias, c1, M, N, K, epilogue=1, a_packed=True)
+    finally:
+        lib().orv_gemm_force_tile(0, 0, 0)
+    assert ((c1.float() - c0.float()).abs() <= 1.0e-2 * c0.float().abs() + 1.5e-2).all()
+    seq, n_text, per_group, Bn = 500, 19, 37, 3
+    Mv = (seq - n_text) * Bn
+    K = 384
+    A = torch.randn(Mv, K, device=dev, generator=g).to(BF)
+    W = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(BF)
+    bias = torch.randn(N, device=dev, generator=g).to(BF)
+    n_groups = 1 + (seq - n_text + per_group - 1) // per_group
+    gate = torch.randn(Bn, n_groups, N, device=dev, generator=g)
+    base = torch.randn(Bn * seq, N, device=dev, generator=g).to(BF)
+    Rm = torch.randn(97, N, device=dev, generator=g).to(BF)
+    Ap = ops.pack_rows16(A, Mv, K)
+
+    def both(fn):
+        res = []
+        for packed in (False, True):
+            lib().orv_gemm_force_tile(5 if packed else 3, 256, bn)
+            try:
+                res.append(fn(Ap if packed else A, packed))
+            finally:
+                lib().orv_gemm_force_tile(0, 0, 0)
+        return res
+
+    def fn_gate(a, packed):
+        C = base.clone()
+        ops.gemm(a, W, bias, C, Mv, N, K, epilogue=2, R=C, ldr=N, gate=gate, gate_b=n_groups * N, gate_g=N,
+                 grp=ops.Groups(seq, n_text, per_group), cmap=ops.RowMap(seq - n_text, seq, n_text), a_packed=packed)
+        return C
+
+    def fn_rmod(a, packed):
+        C = torch.full((Mv, N), float("nan"), dtype=BF, device=dev)
+        ops.gemm(a, W, bias, C, Mv, N, K, epilogue=2, R=Rm, ldr=N, r_mod=97, a_packed=packed)
+        return C
+    same(*both(fn_gate), (bn, "gate + cmap")), same(*both(fn_rmod), (bn, "r_mod"))
+    # fused qk LayerNorm (both widths: the d8 kernel normalises 64-column groups at any BN; t8 only at BN = 256)
+    heads = 4 if bn == 256 else 6
+    Nq, M, K = 3 * heads * 64, 3226, 384
+    A = torch.randn(M, K, device=dev, generator=g).to(BF)
+    W = (torch.randn(Nq, K, device=dev, generator=g) / K ** 0.5).to(BF)
+    bias = torch.randn(Nq, device=dev, generator=g).to(BF)
+    aff = [torch.randn(64, device=dev, generator=g).to(BF) for _ in range(4)]
+    Ap = ops.pack_rows16(A, M, K)
+
+    def fn_qk(a, packed):
+        C = torch.full((M, Nq), float("nan"), dtype=BF, device=dev)
+        Y = torch.full((M, Nq), float("nan"), dtype=BF, device=dev)
+        ops.gemm(a, W, bias, C, M, Nq, K, epilogue=4, Y=Y, qknorm=(aff[0], aff[1], aff[2], aff[3], 1e-6, 0.18, heads), a_packed=packed)
+        return C, Y
+    (c0, y0) = fn_qk(A, False)
+    lib().orv_gemm_force_tile(5, 256, bn)
+    try:
+        assert ops.gemm_kernel_name(M, Nq, K, 4, a_packed=True) == f"gemm_d8_kernel<{bn}, 4>"
+        (c1, y1) = fn_qk(Ap, True)
+    finally:
+        lib().orv_gemm_force_tile(0, 0, 0)
+    assert torch.isfinite(c1.float()).all() and torch.isfinite(y1.float()).all()
+    assert ((y1.float() - y0.float()).abs() <= 1.0e-2 * y0.float().abs() + 1.5e-2).all()
+    assert ((c1.float() - c0.float()).abs() <= 2e-2 * c0.float().abs() + 6e-2).all()
+
+
+def test_packed_c_from_the_gelu_epilogues_and_the_attention_kernel():
+    """The producers of the packed layout: gemm_t8_kernel<256, 1> (FFN1 of the product path) and gemm_d8_kernel<.., 0 / 1> store a block
+    pair as one lane-linear KiB, attn_fwd_pp_kernel its 16-byte output pieces into slot order - each unpacks to exactly what the row-major
+    form of the same call wrote."""
+    from orv_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(77)
+    for M, N, K in [(300, 768, 384), (12904, 7680, 1920), (3226, 1024, 256)]:
+        A = torch.randn(M, K, device=dev, generator=g).to(BF)
+        W = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(BF)
+        bias = torch.randn(N, device=dev, generator=g).to(BF)
+        C = torch.empty(M, N, dtype=BF, device=dev)
+        ops.gemm(A, W, bias, C, M, N, K, epilogue=1)
+        name = ops.gemm_kernel_name(M, N, K, 1, c_packed=True)
+        assert name == "gemm_t8_kernel<256, 1>", name
+        Cp = torch.full((ops.packed_rows(M), N), float("nan"), dtype=BF, device=dev)
+        ops.gemm(A, W, bias, Cp, M, N, K, epilogue=1, c_packed=True)
+        # the row-major call may have taken another kernel (cost model); compare against the t8 kernel pinned
+        from orv_amd._lib import lib
+        lib().orv_gemm_force_tile(3, 256, 256)
+        try:
+            ops.gemm(A, W, bias, C, M, N, K, epilogue=1)
+        finally:
+            lib().orv_gemm_force_tile(0, 0, 0)
+        assert torch.equal(ops.unpack_rows16(Cp, M, N).view(torch.int16), C.view(torch.int16)), (M, N, K)
+        if K % 192 == 0:
+            Ap = ops.pack_rows16(A, M, K)
+            for epi in (0, 1):
+                Cp2 = torch.full((ops.packed_rows(M), N), float("nan"), dtype=BF, device=dev)
+                C2 = torch.empty(M, N, dtype=BF, device=dev)
+                ops.gemm(Ap, W, bias, Cp2, M, N, K, epilogue=epi, a_packed=True, c_packed=True)
+                ops.gemm(Ap, W, bias, C2, M, N, K, epilogue=epi, a_packed=True)
+                assert torch.equal(ops.unpack_rows16(Cp2, M, N).view(torch.int16), C2.view(torch.int16)), (M, N, K, epi)
+    # attention
+    for B, S, H in [(2, 333, 2), (1, 3226, 3), (3, 100, 5)]:
+        D = H * 64
+        qkv = (torch.randn(B * S, 3 * D, device=dev, generator=g) * 0.7).to(BF)
+        bound = float((qkv[:, :D].float().abs().max() * qkv[:, D:2 * D].float().abs().max() * 64).item())       # crude, holds
+        bound = min(bound, 89.0)
+        qs = qkv.clone()
+        qs[:, :D] = (qkv[:, :D].float() * (bound / 64 / max(1e-6, (qkv[:, :D].float().abs().max() * qkv[:, D:2 * D].float().abs().max()).item()))).to(BF)
+        out = torch.full((B * S, D), float("nan"), dtype=BF, device=dev)
+        ops.attention_fwd(qs, None, out, B, S, H, 0, 1.0 / LOG2E, score_bound=bound)
+        assert ops.attention_packed_ok(bound, 1.0 / LOG2E)
+        outp = torch.full((ops.packed_rows(B * S), D), float("nan"), dtype=BF, device=dev)
+        ops.attention_fwd(qs, None, outp, B, S, H, 0, 1.0 / LOG2E, score_bound=bound, out_packed=True)
+        assert torch.isfinite(out.float()).all()
+        assert torch.equal(ops.unpack_rows16(outp, B * S, D).view(torch.int16), out.view(torch.int16)), (B, S, H)
