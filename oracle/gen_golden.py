@@ -191,6 +191,21 @@ def pipeline_50step_cases(cc):
     pipeline_case(cc, "pipe_dpm50_bf16", leaf.CogVideoXDPMScheduler, steps=50, dtype=bf, keep_steps=(1, 10, 25, 50))
 
 
+def transformer_config_case():
+    """The field sets of the reference's own transformer configs (config/transformer/*.json, selected by
+    config/traj_image_1.4b_*.yaml:14-17 through ``from_config(load_config(path), **extra_init_kwargs)``,
+    train_cogvideox_control_to_video_sft.py:286-290): D = 1792 / 28 heads, D = 1536 / 24 heads + RoPE, in_channels = 256.  Data
+    only (keys and values), one entry per file."""
+    import glob
+    out = {}
+    for path in sorted(glob.glob(os.path.join(ref_harness.REFERENCE_ROOT, "config", "transformer", "*.json"))):
+        with open(path) as f:
+            out[os.path.basename(path)] = json.load(f)
+    with open(os.path.join(OUT, "reference_transformer_configs.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("transformer configs:", sorted(out))
+
+
 def misc_case(cc, comp, utils):
     """Small standalone functions ORV authored: action padding + ActionEmbed/ActionRecon, crop-region helper."""
     torch.manual_seed(1234)
@@ -310,6 +325,8 @@ def main():
         return collate_case()
     if len(sys.argv) > 1 and sys.argv[1] == "signatures":
         return signature_case()
+    if len(sys.argv) > 1 and sys.argv[1] == "configs":
+        return transformer_config_case()
     cc, comp, utils = ref_harness.load_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "pipe_bf16":    # round-2 additions only
         return pipeline_bf16_cases(cc)
@@ -338,6 +355,7 @@ def main():
     collate_case()
     bucket_sampler_case()
     signature_case()
+    transformer_config_case()
 
 
 if __name__ == "__main__":

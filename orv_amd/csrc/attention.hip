@@ -423,6 +423,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_v2_kernel(const AttnArgs p) {
 //     guide T13 ordering).
 //   * epilogue: O rows leave as 16-byte pieces (two 8-byte column groups exchanged between lane and lane ^ 32, guide T21).
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef ORV_ATTN_W64_DEFAULT
+#define ORV_ATTN_W64_DEFAULT 0
+#endif
 constexpr int PP_SLOTS = 2;        // K / V tiles resident per operand (tile t in slot t % 2, staged one tile ahead).  Measured and
 // dropped: three slots with the tiles staged TWO ahead from inline-asm LDS-DMA (so that hipcc's vmcnt(0) in front of every
 // ds_read_b64_tr_b16 that follows a DMA builtin cannot drain the stream) and counted vmcnt(2) waits - 0.365-0.373 ms against
@@ -820,6 +823,241 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_pp_kernel(const AttnArgs p) {
 }
 
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// "w64" (round 5): 64 query rows per wave.  In attn_fwd_pp_kernel every wave re-reads the whole 16-KB K + V tile for its 32 rows:
+// 128 KB of fragment reads per 256-row tile step, a fragment feeds one MFMA, and a matrix segment lasts 2.5-3 x its MFMA time
+// (profiles/r3_attention_pingpong.txt).  Here a wave owns TWO 32-row query blocks, so every K fragment (QK^T) and every V^T fragment (PV) feeds
+// two MFMAs: half the LDS traffic and half the DMA per score, twice the MFMA time behind every read.  256 registers per wave (O^T 64, S^T 64,
+// P 32, Q 32, fragments 32): ONE 8-wave workgroup per CU.  A 512-row item would quantise badly (S = 3226: 7 items per head, the last 30 % full;
+// 840 items on 256 slots), so the workgroup is TWO independent 4-wave groups, each with its own 256-row item (own (b, h), own K / V slots:
+// 64 KiB of LDS) - the items and the grid quantisation of the 8-wave kernel (1560 items = 780 workgroups on 256 CUs) - and the barrier
+// choreography of attn_fwd_pp_kernel between them: group 0 (the first wave of every SIMD) is in its matrix segment X_t = { PV_{t-1} ; QK^T_t }
+// while group 1 (the second wave of every SIMD) is in its vector segment Y_t, one barrier apart.  A first build with 4-wave workgroups (the
+// SIMD partner in another, unsynchronised workgroup) ran the two waves of a SIMD in phase: 0.400 ms against 0.348 (profiles/r5_attention_w64.txt).
+// Fixed-shift softmax only (STATIC of the pp kernel), V in place.  Per group and tile: K_{t+1} is issued at the start of X_t, V_t at the start
+// of Y_t (inline-asm LDS-DMA: behind the builtin hipcc drains the stream with vmcnt(0) in front of every transposing read), both waited for
+// at the end of Y_t.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long w64_uniform64(unsigned long long u) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ void w64_glds(unsigned voff, unsigned long long sbase, unsigned lds_dst) {
+    const unsigned d = __builtin_amdgcn_readfirstlane(lds_dst);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(d) : "memory", "m0");
+}
+__global__ __launch_bounds__(512, 2) void attn_fwd_w64_kernel(const AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem_all[2 * 2 * PP_SLOTS * TILE_BYTES];   // group 0: K slots | V slots, group 1: K slots | V slots
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave8 >> 2, wave = wave8 & 3;
+    char* const smem = smem_all + grp * (2 * PP_SLOTS * TILE_BYTES);
+    const int l31 = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
+    const int nqt = (p.S + 255) / 256;
+    const int nitems = nqt * p.H * p.B;
+    const int item_ = 2 * orv_xcd_item(blockIdx.x, gridDim.x) + grp;       // the two groups take neighbouring query tiles (mostly one head: K / V shared in L2)
+    const bool item_ok = item_ < nitems;
+    const int item = min(item_, nitems - 1);
+    const int bh = item / nqt, h = bh % p.H, b = bh / p.H;
+    const int q0 = (item % nqt) * 256 + wave * 64;
+    const int D = p.H * 64;
+    const long row0 = (long)b * p.S;
+    const bool act = __builtin_amdgcn_readfirstlane((int)(item_ok && q0 < p.S)) != 0;
+
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qr = min(q0 + 32 * qb + l31, p.S - 1);
+        const bf16_t* qp = p.qkv + (row0 + qr) * p.ld + h * 64 + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *(const bf16x8*)(qp + ks * 16);
+    }
+    // ---- staging: wave w moves rows 16 w .. 16 w + 15 (two 1-KiB pieces) of the K tile AND of the V tile.  32-bit per-lane byte offsets
+    // against a wave-uniform base that carries the tile position (saddr form: no 64-bit vector address arithmetic in the loop) ----
+    auto off_of = [&](int op, int j, int t) {
+        const int sr = wave * 16 + j * 8 + (lane >> 3), slot = lane & 7;
+        const int chunk = op == 0 ? (slot ^ ((sr >> 1) & 7)) : (slot ^ (((sr >> 1) & 1) << 2));
+        const int rr = min(t * KV + sr, p.S - 1) - t * KV;                       // keys past S read the last valid row, their P is forced to 0
+        return (unsigned)(((long)rr * p.ld + (op == 0 ? D : 2 * D) + h * 64 + chunk * 8) * 2);
+    };
+    const unsigned ok0 = off_of(0, 0, 0), ok1 = off_of(0, 1, 0), ov0 = off_of(1, 0, 0), ov1 = off_of(1, 1, 0);
+    const int nt = (p.S + KV - 1) / KV;
+    const bool ragged = (p.S & (KV - 1)) != 0;
+    auto stage = [&](int op, int t) {
+        const unsigned d = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)smem + op * PP_SLOTS * TILE_BYTES + (t % PP_SLOTS) * TILE_BYTES + wave * 2048;
+        const unsigned long long sb = w64_uniform64((unsigned long long)(uintptr_t)(p.qkv + (row0 + (long)t * KV) * p.ld));
+        unsigned o0 = op == 0 ? ok0 : ov0, o1 = op == 0 ? ok1 : ov1;
+        if (__builtin_expect(ragged && t == nt - 1, 0)) { o0 = off_of(op, 0, t); o1 = off_of(op, 1, t); }
+        w64_glds(o0, sb, d);
+        w64_glds(o1, sb, d + 1024);
+    };
+
+    f32x16 oT[2][2], sT[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { oT[a][i][e] = 0.f; sT[a][i][e] = 0.f; }
+    union { bf16x8 v; uint32_t u[4]; } pf[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pf[a][i].u[e] = 0u;
+    float l_run[2] = {0.f, 0.f};
+    const int row_off = l31 * 128;
+    const int r16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int v_row = (4 * hi + (r16 >> 2)) * 128 + g16 * 32 + (r16 & 3) * 8;
+    const int v_off0 = v_row + ((r16 >> 3) << 6);
+    const int v_off1 = v_row + ((1 - (r16 >> 3)) << 6);
+#define W64_FENCE() __builtin_amdgcn_sched_barrier(0);
+#define W64_PV(VA0, VA1, KK)                                                                                              \
+    oT[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(VA0, pf[0][KK].v, oT[0][0], 0, 0, 0);                              \
+    oT[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(VA0, pf[1][KK].v, oT[1][0], 0, 0, 0);                              \
+    oT[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(VA1, pf[0][KK].v, oT[0][1], 0, 0, 0);                              \
+    oT[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(VA1, pf[1][KK].v, oT[1][1], 0, 0, 0);
+#define W64_QK(KF, KS, KB, ACC0, ACC1)                                                                                    \
+    sT[0][KB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(KF, qf[0][KS], ACC0, 0, 0, 0);                                    \
+    sT[1][KB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(KF, qf[1][KS], ACC1, 0, 0, 0);
+    // matrix part of iteration t: PV of tile t - 1 (t > 0), QK^T of tile t (t < nt); fragment reads one group ahead of their MFMAs
+    auto seg_x = [&](int t) {
+        const char* sK = smem + (t % PP_SLOTS) * TILE_BYTES + row_off;
+        auto kread = [&](int kb, int ks) { return *(const bf16x8*)(sK + kb * 4096 + (((ks * 2 + hi) ^ sw) * 16)); };
+        bf16x8 k0, k1, k2, k3;
+        if (t > 0) {
+            const char* sV = smem + PP_SLOTS * TILE_BYTES + ((t - 1) % PP_SLOTS) * TILE_BYTES;
+            bf16x8 va0 = tr_read_pair(sV + v_off0, sV + 8 * 128 + v_off0), va1 = tr_read_pair(sV + v_off1, sV + 8 * 128 + v_off1);
+            bf16x8 vb0 = tr_read_pair(sV + 2048 + v_off0, sV + 2048 + 8 * 128 + v_off0), vb1 = tr_read_pair(sV + 2048 + v_off1, sV + 2048 + 8 * 128 + v_off1);
+            W64_FENCE()
+            W64_PV(va0, va1, 0)
+            W64_FENCE()
+            va0 = tr_read_pair(sV + 4096 + v_off0, sV + 4096 + 8 * 128 + v_off0); va1 = tr_read_pair(sV + 4096 + v_off1, sV + 4096 + 8 * 128 + v_off1);
+            W64_FENCE()
+            W64_PV(vb0, vb1, 1)
+            W64_FENCE()
+            vb0 = tr_read_pair(sV + 6144 + v_off0, sV + 6144 + 8 * 128 + v_off0); vb1 = tr_read_pair(sV + 6144 + v_off1, sV + 6144 + 8 * 128 + v_off1);
+            W64_FENCE()
+            W64_PV(va0, va1, 2)
+            W64_FENCE()
+            if (t < nt) { k0 = kread(0, 0); k1 = kread(0, 1); }
+            W64_FENCE()
+            W64_PV(vb0, vb1, 3)
+            W64_FENCE()
+            if (t < nt) { k2 = kread(0, 2); k3 = kread(0, 3); }
+            W64_FENCE()
+        } else {
+            k0 = kread(0, 0); k1 = kread(0, 1); k2 = kread(0, 2); k3 = kread(0, 3);
+            W64_FENCE()
+        }
+        if (t < nt) {
+            f32x16 z;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) z[e] = 0.f;
+            W64_QK(k0, 0, 0, z, z)
+            W64_QK(k1, 1, 0, sT[0][0], sT[1][0])
+            W64_FENCE()
+            k0 = kread(1, 0); k1 = kread(1, 1);
+            W64_FENCE()
+            W64_QK(k2, 2, 0, sT[0][0], sT[1][0])
+            W64_QK(k3, 3, 0, sT[0][0], sT[1][0])
+            W64_FENCE()
+            k2 = kread(1, 2); k3 = kread(1, 3);
+            W64_FENCE()
+            W64_QK(k0, 0, 1, z, z)
+            W64_QK(k1, 1, 1, sT[0][1], sT[1][1])
+            W64_QK(k2, 2, 1, sT[0][1], sT[1][1])
+            W64_QK(k3, 3, 1, sT[0][1], sT[1][1])
+            W64_FENCE()
+        }
+    };
+    auto seg_y = [&](int t) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            if (t == nt - 1 && ragged) {
+                const int kv0 = t * KV;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (key >= p.S) sT[qb][kb][r] = -INFINITY;
+                    }
+            }
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = fast_exp2(sT[qb][kb][r]);
+                    sT[qb][kb][r] = pv;
+                    psum += pv;
+                }
+            l_run[qb] += psum;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int kb = kk >> 1, r0 = (kk & 1) * 8;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pf[qb][kk].u[i] = pack2bf(sT[qb][kb][r0 + 2 * i], sT[qb][kb][r0 + 2 * i + 1]);
+            }
+        }
+    };
+#define W64_BAR()                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    __builtin_amdgcn_s_barrier();                                                                 \
+    __builtin_amdgcn_sched_barrier(0);
+    // prologue: K_0 of both groups lands before anybody reads.  Barrier intervals: group 0 runs X_t in I_2t and Y_t in I_2t+1, group 1 one later.
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    W64_BAR()
+    if (grp == 1) { W64_BAR() }
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) stage(0, t + 1);                          // K_{t+1} -> the slot K_{t-1} left after X_{t-1}
+        W64_FENCE()
+        seg_x(t);
+        W64_BAR()
+        stage(1, t);                                              // V_t -> the slot V_{t-2} left after X_{t-1}
+        W64_FENCE()
+        seg_y(t);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of K_{t+1} and V_t
+        W64_BAR()
+    }
+    seg_x(nt);
+    if (grp == 0) { W64_BAR() }
+#undef W64_BAR
+
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float l_tot = sum_with_partner_half(l_run[qb]);
+        const int q = q0 + 32 * qb + l31;
+        const float inv = 1.0f / l_tot;
+        if (act && q < p.S) {
+            bf16_t* op = p.out + (row0 + q) * p.ld_out + h * 64 + hi * 8;
+            const long m_ = row0 + q;
+            char* const pblk = (char*)p.out + (((m_ >> 4) * (p.ld_out >> 5) + 2 * h) << 10) + ((hi * 16 + (m_ & 15)) << 4);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    uint32_t a0 = pack2bf(oT[qb][db][(2 * u) * 4 + 0] * inv, oT[qb][db][(2 * u) * 4 + 1] * inv);
+                    uint32_t a1 = pack2bf(oT[qb][db][(2 * u) * 4 + 2] * inv, oT[qb][db][(2 * u) * 4 + 3] * inv);
+                    uint32_t b0 = pack2bf(oT[qb][db][(2 * u + 1) * 4 + 0] * inv, oT[qb][db][(2 * u + 1) * 4 + 1] * inv);
+                    uint32_t b1 = pack2bf(oT[qb][db][(2 * u + 1) * 4 + 2] * inv, oT[qb][db][(2 * u + 1) * 4 + 3] * inv);
+                    { const auto r = __builtin_amdgcn_permlane32_swap(a0, b0, false, false); a0 = r[0]; b0 = r[1]; }
+                    { const auto r = __builtin_amdgcn_permlane32_swap(a1, b1, false, false); a1 = r[0]; b1 = r[1]; }
+                    if (p.out_packed) *(uint4*)(pblk + db * 1024 + u * 512) = make_uint4(a0, a1, b0, b1);
+                    else *(uint4*)(op + db * 32 + u * 16) = make_uint4(a0, a1, b0, b1);
+                }
+            if (p.lse && hi == 0) p.lse[((long)b * p.H + h) * p.S + q] = __log2f(l_tot) * 0.6931471805599453f;
+        }
+    }
+#undef W64_FENCE
+#undef W64_PV
+#undef W64_QK
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // The ping-pong kernel on v_mfma_f32_16x16x32_bf16 (fixed-shift softmax only).  Why: with nothing but MFMAs in the loop the part
 // sustains 1968 TFLOP/s on random bf16 operands with the 16-wide shape and 1747 with the 32-wide one (profiles/
@@ -1197,6 +1435,12 @@ extern "C" int orv_attention_fwd(const void* qkv, int ld_qkv, const void* vT, vo
 // Above the limit this is orv_attention_fwd (online softmax).  A bound that does not hold gives wrong results and, far enough
 // off, inf: the caller owns the guarantee (tests/test_gpu_kernels.py exercises a violated bound to show it is a contract).
 constexpr float ORV_STATIC_LIMIT_PP = 90.f, ORV_STATIC_LIMIT_V2 = 60.f;
+// ORV_ATTN_W64: 1 = the 64-rows-per-wave kernel for the shift-free softmax, 0 = the 8-wave ping-pong kernel (A/B switch; default below)
+static bool attn_use_w64() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ORV_ATTN_W64"); v = e ? (atoi(e) != 0) : ORV_ATTN_W64_DEFAULT; }
+    return v != 0;
+}
 extern "C" int orv_attention_fwd_bounded(const void* qkv, int ld_qkv, void* out, int ld_out, float* lse, int B, int S, int H,
                                          float scale, float score_bound, void* stream) {
     const float scale_log2 = scale * 1.4426950408889634f;
@@ -1221,7 +1465,9 @@ extern "C" int orv_attention_fwd_bounded(const void* qkv, int ld_qkv, void* out,
     if (use_pp < 0) { const char* e = getenv("ORV_ATTN_PP"); use_pp = (e && atoi(e) == 0) ? 0 : 1; }
     static int use_m16 = -1;         // ORV_ATTN_M16=1: the 16x16x32 form of the ping-pong kernel (A/B switch)
     if (use_m16 < 0) { const char* e = getenv("ORV_ATTN_M16"); use_m16 = (e && atoi(e) != 0) ? 1 : 0; }
-    if (use_pp && use_m16 && ld_out % 8 == 0 && ((uintptr_t)out & 15) == 0)
+    if (use_pp && attn_use_w64() && ld_out % 8 == 0 && ((uintptr_t)out & 15) == 0)
+        hipLaunchKernelGGL(attn_fwd_w64_kernel, dim3((grid.x + 1) / 2), dim3(512), 0, (hipStream_t)stream, a);
+    else if (use_pp && use_m16 && ld_out % 8 == 0 && ((uintptr_t)out & 15) == 0)
         hipLaunchKernelGGL(attn_fwd_m16_kernel, grid, dim3(512), 0, (hipStream_t)stream, a);
     else if (use_pp && ld_out % 8 == 0 && ((uintptr_t)out & 15) == 0)
         hipLaunchKernelGGL((attn_fwd_pp_kernel<true>), grid, dim3(512), 0, (hipStream_t)stream, a);
@@ -1247,7 +1493,8 @@ extern "C" int orv_attention_fwd_packed(const void* qkv, int ld_qkv, void* out, 
     a.lse = lse; a.B = B; a.S = S; a.H = H; a.s_pad = 0;
     a.scale = scale; a.scale_log2 = scale_log2; a.shift = score_bound; a.guard_dev = nullptr; a.guard_limit = 0.f; a.ws_o = a.ws_l = nullptr; a.ws_cnt = nullptr; a.n_full = a.ks = 0;
     a.out_packed = 1;
-    hipLaunchKernelGGL((attn_fwd_pp_kernel<true>), dim3(((S + 255) / 256) * H * B), dim3(512), 0, (hipStream_t)stream, a);
+    if (attn_use_w64()) hipLaunchKernelGGL(attn_fwd_w64_kernel, dim3((((S + 255) / 256) * H * B + 1) / 2), dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((attn_fwd_pp_kernel<true>), dim3(((S + 255) / 256) * H * B), dim3(512), 0, (hipStream_t)stream, a);
     return orv_check_launch("orv_attention_fwd_packed");
 }
 

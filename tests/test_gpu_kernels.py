@@ -1066,3 +1066,16 @@ def test_packed_c_from_the_gelu_epilogues_and_the_attention_kernel():
         ops.attention_fwd(qs, None, outp, B, S, H, 0, 1.0 / LOG2E, score_bound=bound, out_packed=True)
         assert torch.isfinite(out.float()).all()
         assert torch.equal(ops.unpack_rows16(outp, B * S, D).view(torch.int16), out.view(torch.int16)), (B, S, H)
+
+
+def test_attention_w64_variant_passes_the_attention_tests():
+    """attn_fwd_w64_kernel (64 query rows per wave: every K / V^T fragment feeds two MFMAs; two 4-wave groups with their own 256-row item per
+    workgroup, the ping-pong barrier choreography between the groups; opt-in ORV_ATTN_W64=1 - measured slower than the 8-wave kernel,
+    profiles/r5_attention_w64.txt): the shift-free attention tests and the packed-output test of this file, run in a fresh interpreter with
+    the switch on."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_kernels.py", "-x", "-q", "-k",
+                        "fixed_shift or packed_c_from or gamma_product"], cwd=root, env=dict(os.environ, ORV_ATTN_W64="1"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

@@ -600,3 +600,77 @@ def test_full_depth_5b_checkpointed_training_steps():
     assert peak < 80.0, peak         # parameters + gradients + moments are 62 GiB; resident activations at B = 1 add ~15 more
     del model, opt
     torch.cuda.empty_cache()
+
+
+def _reference_transformer_configs():
+    import json, os
+    from conftest import ROOT
+    with open(os.path.join(ROOT, "tests", "golden", "reference_transformer_configs.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", ["base_1.4b_480_320.json", "base_1.4b_480_320_rope.json", "base_1b_480_320_rope.json",
+                                  "base_1.4b_480_320_opensora.json"])
+def test_reference_transformer_configs_forward_and_gradients_vs_oracle(name):
+    """The transformer configs the reference itself ships (config/transformer/*.json -> ``from_config(load_config(path), **kwargs)``,
+    train_cogvideox_control_to_video_sft.py:286-290, selected by config/traj_image_1.4b_*.yaml:14-17): D = 1792 / 28 heads
+    (N = 1792 / 5376 / 7168 are not multiples of 192: the tile chooser's other branches), D = 1536 / 24 heads with RoPE,
+    in_channels = 256 / out_channels = 128.  Two layers of each at the configured 17 x 320 x 480 size: inference forward and
+    parameter gradients against the fp32 oracle (VERDICT r4 #7)."""
+    from orv_amd.cogvideox_control import CogVideoXTransformer3DModelTraj
+    from orv_amd.utils import prepare_rotary_positional_embeddings
+    dev = torch.device("cuda:0")
+    fields = _reference_transformer_configs()[name]
+    torch.manual_seed(11)
+    m = CogVideoXTransformer3DModelTraj.from_config(fields, num_layers=2, modulate_encoder_hidden_states=False)    # the yaml's kwarg
+    c = m.config
+    D = c.num_attention_heads * c.attention_head_dim
+    assert D == {"base_1b_480_320_rope.json": 1536}.get(name, 1792) and len(m.transformer_blocks) == 2
+    for p in m.parameters():
+        if p.ndim >= 2:
+            p.data.normal_(0, 0.02)
+        p.data.copy_(p.data.to(BF).float())
+    cin, cout = c.in_channels, c.out_channels
+    ins = dict(hidden_states=torch.randn(1, 5, cin, 40, 60).to(BF).float(),
+               encoder_hidden_states=(torch.randn(1, 226, 4096) * 0.2).to(BF).float(),
+               actions=torch.randn(1, 16, 7).to(BF).float(), timestep=torch.tensor([400]))
+    rope = None
+    if c.use_rotary_positional_embeddings:
+        rope = prepare_rotary_positional_embeddings(height=320, width=480, num_frames=5, vae_scale_factor_spatial=8, patch_size=2,
+                                                    patch_size_t=None, attention_head_dim=64, device=torch.device("cpu"))
+        ins["rope_cos"], ins["rope_sin"] = rope
+    w = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    wout = torch.randn(1, 5, cout, 40, 60)
+    ref_out, ref_g = _oracle_grads(dict(c), w, ins, torch.zeros(1, dtype=torch.bool), wout)
+    m = m.to(dev, BF)
+    m.action_embed.forced_mask = torch.zeros(1, dtype=torch.bool)
+    kw = dict(image_rotary_emb=None if rope is None else tuple(r.to(dev) for r in rope), return_dict=False)
+    args = (ins["hidden_states"].to(dev, BF), ins["encoder_hidden_states"].to(dev, BF), {"actions": ins["actions"].to(dev)},
+            ins["timestep"].to(dev))
+    m.eval()
+    with torch.no_grad():
+        out = m(*args, **kw)[0]
+    assert out.shape == ref_out.shape and rel_l2(out, ref_out) <= 2e-2, rel_l2(out, ref_out)
+    m.train()
+    out_t = m(*args, **kw)[0]
+    (out_t.float() * wout.to(dev)).sum().backward()
+    named = dict(m.named_parameters())
+    for k in ["transformer_blocks.0.ff.net.0.proj.weight", "transformer_blocks.0.ff.net.2.weight", "transformer_blocks.0.attn1.to_q.weight",
+              "transformer_blocks.0.attn1.to_v.weight", "transformer_blocks.0.attn1.to_out.0.weight", "transformer_blocks.1.ff.net.2.weight",
+              "transformer_blocks.1.attn1.to_k.weight", "transformer_blocks.0.norm1.linear.weight", "patch_embed.proj.weight",
+              "proj_out.weight", "action_embed.mlp.0.weight"]:
+        assert rel_l2(named[k].grad, ref_g[k]) <= grad_bound(k), (name, k, rel_l2(named[k].grad, ref_g[k]))
+
+
+def test_reference_config_widths_land_on_mfma_tiles():
+    """N = 1792 / 5376 / 7168 (D = 1792: q|k|v and FeedForward of the reference's 1.4B configs) and 1536 / 4608 / 6144 at M = 12904:
+    every per-block GEMM must be served by an MFMA tile kernel of this library (no width falls through to an error) - the symbol is
+    printed so the run records which."""
+    from orv_amd import ops
+    for D in (1792, 1536):
+        for (N, K, epi) in [(3 * D, D, 4), (D, D, 2), (4 * D, D, 1), (D, 4 * D, 2)]:
+            name = ops.gemm_kernel_name(12904, N, K, epi)
+            print(f"[tile] D={D} N={N} K={K} epi={epi}: {name}")
+            assert name and ("gemm_t8_kernel" in name or "gemm_ph_kernel" in name or "gemm_pp_kernel" in name or "gemm_kernel<" in name), name
+            if D == 1792 and N % 256 == 0:
+                assert "gemm_t8_kernel<256" in name, name            # 1792 = 7 x 256, 7168 = 28 x 256: the t8 kernel's 256-wide tile
