@@ -305,6 +305,14 @@ def train_mode(args, model, latents, image_latents, prompt, actions, sched, dev,
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
     seen = ranks_seen(world, dev)
+    assert seen == world, f"{seen} of {world} ranks answered the census"
+    # the gradient exchange of the LAST step (sharding.FlatGradReducer): collectives, payload, exposed (non-overlapped) time
+    exch = getattr(opt, "last_exchange", None)
+    exch = exch.stats() if exch is not None else {"collectives": 0, "bytes": 0, "exposed_ms": None}
+    if world > 1 and exch["exposed_ms"] is not None:
+        w = torch.tensor([exch["exposed_ms"]], device=dev, dtype=torch.float64)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        exch["exposed_ms"] = float(w.item())
     if rank == 0:
         c_ = cfg or {**CFG_2B, "num_layers": args.layers}
         S_ = 226 + (latents.shape[1] // (c_.get("patch_size_t") or 1)) * (latents.shape[3] // 2) * (latents.shape[4] // 2)
@@ -317,6 +325,10 @@ def train_mode(args, model, latents, image_latents, prompt, actions, sched, dev,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "achieved_tflops_attn_ffn": round(value * fl / 1e12, 1), "final_loss": float(loss),
             "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+            "exchange": {"collective": "all-reduce (SUM) of the flat bf16 gradient buffer, RCCL, overlapped with the backward",
+                         "collectives_per_step": exch["collectives"], "bytes_per_rank_per_step": exch["bytes"],
+                         "exposed_ms_max_over_ranks": None if exch["exposed_ms"] is None else round(exch["exposed_ms"], 3),
+                         "note": "N = 1: no exchange is issued"},
             "config": {"workload": ("configs[4]: CogVideoX1.5-5B SFT step, DROID 256x384x29f latents [B,8,16,32,48], p_t=2, RoPE, "
                                     "ofs, bf16 params+grads, " + ("activation checkpointing (block-level recompute)" if getattr(args, "grad_ckpt", False) else "all activations resident (no recompute)")) if is5b else
                                    "configs[2]: CogVideoX-2B SFT step, 320x480x17f latents, bf16 params+grads, DP",
@@ -397,7 +409,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get("ORV_DIST_BACKEND", "nccl")     # "gloo": functional test of the N > 1 path on ONE GPU (ranks share it)
-        if backend != "nccl":
+        if backend != "nccl" or os.environ.get("ORV_SAME_GPU"):   # ORV_SAME_GPU=1: the ranks share the visible GPUs also under nccl (tools/multi_rank_check.sh)
             local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
         if backend == "nccl":

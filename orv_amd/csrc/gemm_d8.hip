@@ -51,6 +51,9 @@ __device__ __forceinline__ unsigned long long d8_uniform64(unsigned long long u)
 // (as t8): lane (r16 = lane & 15, g = lane >> 4) holds, of block 2 P + t of a 64-column group, columns 32 P + 8 g + 4 t + (0..3) of row r16.
 // Every (16 rows x 64 columns) piece goes through the wave's 4-KiB fp32 scratch and comes back as lane = (row lane >> 3, 8-column chunk
 // lane & 7): loads and stores are 8 rows x one full 128-byte line per instruction.
+#ifndef D8_RSETS
+#define D8_RSETS 2
+#endif
 template <int BN, int EPI>
 __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][BN / 16], const int row0, const int col0, const int lane,
                                             char* const scr) {
@@ -78,7 +81,7 @@ __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][B
             if (p.c_rows > 0) orow[rb][j] = (long)(mc / p.c_rows) * p.c_bstride + p.c_off + mc % p.c_rows;
         }
     // row operands (residual / GELU-adjoint input) of one 64-column group: requested one group ahead
-    uint4 r8[2][2][2];                                  // [set][rb][j]
+    uint4 r8[D8_RSETS][2][2];                           // [set][rb][j]
     auto load_rows = [&](int cg, uint4 (&dst)[2][2]) {
         const int col8 = col0 + 64 * cg + 8 * c;
 #pragma unroll
@@ -97,7 +100,8 @@ __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][B
 #pragma unroll
     for (int cg = 0; cg < NG; ++cg) {
         const int col8 = col0 + 64 * cg + 8 * c;
-        if ((EPI == 2 || EPI == 3) && cg + 1 < NG) load_rows(cg + 1, r8[(cg + 1) & 1]);
+        if (D8_RSETS == 2 && (EPI == 2 || EPI == 3) && cg + 1 < NG) load_rows(cg + 1, r8[(cg + 1) & 1]);
+        if (D8_RSETS == 1 && (EPI == 2 || EPI == 3) && cg > 0) load_rows(cg, r8[0]);
         float b8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) b8[e] = 0.f;
@@ -180,7 +184,7 @@ __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][B
                 }
                 if (EPI == 2) {
                     float rv[8], gg[8];
-                    d8_unpack8(r8[cg & 1][rb][j], rv);
+                    d8_unpack8(r8[cg & (D8_RSETS - 1)][rb][j], rv);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) gg[e] = g8[e];
                     if (g_lane) {            // block straddles a frame / text boundary: this lane's row picks its own gate row
@@ -194,7 +198,7 @@ __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][B
                 }
                 if (EPI == 3) {
                     float rv[8];
-                    d8_unpack8(r8[cg & 1][rb][j], rv);
+                    d8_unpack8(r8[cg & (D8_RSETS - 1)][rb][j], rv);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) w[e] *= gelu_tanh_grad(rv[e]);
                 }

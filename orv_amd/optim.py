@@ -165,6 +165,7 @@ class FusedAdamW:
             f["g_mask"].copy_(torch.tensor(has_grad, dtype=torch.bfloat16))
             if overlap is not None:
                 overlap[0].finish(average=False)         # the rest of the buffer (mask segment included), wait
+                self.last_exchange = overlap[0]          # bookkeeping for bench.py (collectives, bytes, exposed time): .stats()
             else:
                 from .sharding import allreduce_flat_
                 allreduce_flat_(f["g"], _AR_CHUNK, average=False)

@@ -66,6 +66,8 @@ class FlatGradReducer:
         self.ready_flag, self.sent = [False] * n, [False] * n
         self.min_elems, self.max_elems = min_elems, max_elems
         self.handles, self.n_collectives = [], 0
+        self.bytes_sent = 0                                   # payload bytes handed to all-reduce (per rank)
+        self.exposed = None                                   # (event, event) on the compute stream around finish()'s waits
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
 
     def _send(self, a: int, b: int):
@@ -76,6 +78,7 @@ class FlatGradReducer:
             if self.world > 1:
                 self.handles.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.n_collectives += 1
+            self.bytes_sent += piece.numel() * piece.element_size()
         for i in range(a, b):
             self.sent[i] = True
 
@@ -103,9 +106,25 @@ class FlatGradReducer:
         """Send everything not sent yet (segments never marked count as final: zeros or already-copied gradients), wait for
         all collectives, average.  Returns the number of collectives issued."""
         self._scan(force=True)
+        timed = self.flat.is_cuda and self.world > 1
+        if timed:                                             # what the compute stream waits for here is the NON-overlapped part of the exchange
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for h in self.handles:
             h.wait()
+        if timed:
+            e1.record()
+            self.exposed = (e0, e1)
         self.handles = []
         if average and self.world > 1:
             self.flat.mul_(1.0 / self.world)
         return self.n_collectives
+
+    def stats(self) -> Dict:
+        """Exchange bookkeeping of the finished step: collectives, payload bytes per rank, exposed (non-overlapped) milliseconds on the
+        compute stream (None without a GPU group; synchronises on the second event)."""
+        ms = None
+        if self.exposed is not None:
+            self.exposed[1].synchronize()
+            ms = self.exposed[0].elapsed_time(self.exposed[1])
+        return {"collectives": self.n_collectives, "bytes": self.bytes_sent, "exposed_ms": ms}
