@@ -544,6 +544,20 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         if os.environ.get("ORV_GEMM_PACKED", "1") == "0":
             return plan
         t8_192 = "gemm_t8_kernel<192, 2>"
+        # FeedForward pair: wherever FFN1 can write the packed hidden state (the t8 kernel's 256-wide GELU epilogue) and a d8 tile takes
+        # FFN2 - measured better at B = 4 (256 x 192 tiles: -0.7 % in the model), B = 2 and B = 1 (256 x 128 tiles against the single-round
+        # simple kernels: 0.203 -> 0.180 ms and 0.118 -> 0.093 ms standalone, profiles/r5_gemm_d8_b1.txt)
+        if (ops.gemm_kernel_name(M, D, 4 * D, 2, a_packed=True) is not None
+                and ops.gemm_kernel_name(M, 4 * D, D, 1, c_packed=True) is not None):
+            plan["ffn"] = True
+        # out-projection (K = D: 30 K-tiles, epilogue-heavy): where the row-major model picks the 256 x 192 t8 tile (B = 4: -6 %) and where the
+        # 256 x 128 d8 tiles fit ONE round of the CUs (B = 1: 0.037 -> 0.033 ms); in between (B = 2: 390 tiles) the row-major kernel wins
+        if ops.gemm_kernel_name(M, D, D, 2, a_packed=True) is not None:
+            one_round = D % 128 == 0 and -(-M // 256) * (D // 128) <= _num_cus()
+            if ops.gemm_kernel_name(M, D, D, 2) == t8_192 or one_round:
+                plan["out"] = True
+        return plan
+        t8_192 = "gemm_t8_kernel<192, 2>"
         if (ops.gemm_kernel_name(M, D, 4 * D, 2) == t8_192 and ops.gemm_kernel_name(M, D, 4 * D, 2, a_packed=True) is not None
                 and ops.gemm_kernel_name(M, 4 * D, D, 1, c_packed=True) is not None):
             plan["ffn"] = True
@@ -863,6 +877,10 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
 # sampler pipeline (:1090-1489)
 # ------------------------------------------------------------------------------------------------------------------
 _FUSE_QKNORM = os.environ.get("ORV_FUSED_QKNORM", "1") != "0"      # A/B switch: 0 = projection + orv_qkv_prep
+
+
+def _num_cus() -> int:
+    return torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count if torch.cuda.is_available() else 256
 
 
 class _NotCapturable(TypeError):

@@ -1270,6 +1270,10 @@ struct GemmCand { int ring, bm, bn; float rate; int min_rounds; };
 #endif
 #define D8_RATE_256 ORV_D8_RATE_256
 #define D8_RATE_192 ORV_D8_RATE_192
+#ifndef ORV_D8_RATE_128
+#define ORV_D8_RATE_128 1.20f
+#endif
+#define D8_RATE_128 ORV_D8_RATE_128
 // C[M, N] (+)= A[K, M]^T . W[K, N]: the TN form of gemm_t8.hip (weight gradients: A = dY [tokens, out], W = X [tokens, in]; reference:
 // torch autograd of nn.Linear inside accelerator.backward, train_cogvideox_control_to_video_sft.py:1093).  bf16 in, fp32 accumulate, bf16 out;
 // accumulate != 0: C += the product (gradient accumulation).  N % 192 == 0 or N % 256 == 0, M % 8 == 0; any K (rows past K are zeros).
@@ -1321,7 +1325,7 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
         // ring = 4: four-wave 256 x 256 experiment of gemm_t8.hip - forced only (rate 0.01 never wins)
         {4, 256, 256, 0.01f, 0},
         // ring = 5: gemm_d8.hip (round 5) - A straight to registers two K-tiles ahead, W through four LDS buffers; needs K % 192 == 0
-        {5, 256, 256, D8_RATE_256, 0}, {5, 256, 192, D8_RATE_192, 0},
+        {5, 256, 256, D8_RATE_256, 0}, {5, 256, 192, D8_RATE_192, 0}, {5, 256, 128, D8_RATE_128, 0},
         // ring = 2: the phased (8-phase, BK = 64) persistent kernel; needs an even number of K-tiles
         // (256x384 does not fit: 192 accumulator + 64 fragment registers of the 256 a wave gets at two waves per SIMD)
         {2, 256, 256, 1.10f, 0}, {2, 256, 128, 0.80f, 0},

@@ -51,8 +51,10 @@ __device__ __forceinline__ unsigned long long d8_uniform64(unsigned long long u)
 // (as t8): lane (r16 = lane & 15, g = lane >> 4) holds, of block 2 P + t of a 64-column group, columns 32 P + 8 g + 4 t + (0..3) of row r16.
 // Every (16 rows x 64 columns) piece goes through the wave's 4-KiB fp32 scratch and comes back as lane = (row lane >> 3, 8-column chunk
 // lane & 7): loads and stores are 8 rows x one full 128-byte line per instruction.
+// residual register sets of the row-operand epilogues: 1 = the rows of a 64-column group are requested when the group starts (no spills); 2 = one
+// group ahead (10-34 VGPR spills at 256 registers).  Same box, interleaved x 3: FFN2 0.2953 -> 0.2937 ms, out-projection 0.0990 -> 0.0970 (profiles/r5_gemm_d8_b1.txt)
 #ifndef D8_RSETS
-#define D8_RSETS 2
+#define D8_RSETS 1
 #endif
 template <int BN, int EPI>
 __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][BN / 16], const int row0, const int col0, const int lane,
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(512) void gemm_d8_kernel(const GemmArgs p) {
 #ifndef ORV_D8_CBP192
 #define ORV_D8_CBP192 3
 #endif
-    constexpr int CBP = BN == 256 ? ORV_D8_CBP256 : ORV_D8_CBP192;     // column blocks per phase: BN = 256 eight phases of 8 MFMAs, BN = 192 four of 12
+    constexpr int CBP = BN == 256 ? ORV_D8_CBP256 : (BN == 192 ? ORV_D8_CBP192 : 2);     // column blocks per phase: BN = 256 eight phases of 8 MFMAs, BN = 192 four of 12, BN = 128 four of 8
     constexpr int NPH = NCB / CBP;
     constexpr int BUFSZ = BN * 128;                   // one K-tile of W: BN rows x 64 k
     constexpr int ND = BN / 64;                       // 1-KiB DMA pieces per wave and K-tile (BN / 8 pieces over 8 waves)
@@ -464,6 +466,13 @@ int launch_d8(const GemmArgs& a, int bn, int epi, hipStream_t st) {
             case 2: return launch_d8_one<256, 2>(a, st);
             case 3: return launch_d8_one<256, 3>(a, st);
             case 4: return launch_d8_one<256, 4>(a, st);
+        }
+    } else if (bn == 128) {
+        switch (epi) {
+            case 0: return launch_d8_one<128, 0>(a, st);
+            case 1: return launch_d8_one<128, 1>(a, st);
+            case 2: return launch_d8_one<128, 2>(a, st);
+            case 4: return launch_d8_one<128, 4>(a, st);
         }
     } else if (bn == 192) {
         switch (epi) {
