@@ -109,6 +109,14 @@ class FusedAdamW:
         self._overlap = (red, filled)
         return hook
 
+    def averaged_grads(self):
+        """{parameter: averaged gradient copy} after a data-parallel ``step()`` (the flat buffer holds the SUM over ranks, see ``step``)."""
+        import torch.distributed as dist
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        if self._flat is None:
+            return {}
+        return {p: (v.float() / world).to(v.dtype) for p, v in zip(self.params, self._flat["views_g"])}
+
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
             p.grad = None
@@ -120,7 +128,10 @@ class FusedAdamW:
     @torch.no_grad()
     def step(self, average_over: Optional[int] = None) -> float:
         """One update.  ``average_over=world_size`` first averages the flat gradient buffer over the default process group
-        (data parallel, one exchange per step).  Returns the pre-clip global gradient norm (the only host read, issued after
+        (data parallel, one exchange per step).  NOTE: under data parallel the exchange is a SUM and 1 / world is folded
+        into the clip coefficient and the returned norm, so after ``step()`` the ``p.grad`` views that alias the flat segments hold
+        ``world x`` the mean gradient (also for segments this rank never produced); code that inspects ``p.grad`` afterwards
+        (per-parameter norm logging) must divide by the world size - ``averaged_grads()`` returns such copies.  Returns the pre-clip global gradient norm (the only host read, issued after
         every kernel of the step is queued)."""
         if not self.params:
             return 0.0

@@ -52,13 +52,19 @@ _WGRAD_TN = os.environ.get("ORV_WGRAD_TN", "0") == "1"
 def _wgrad(dY2d, X2d, dW, M, N, K, accumulate=True, bias_sum=None):
     """dW[N,K] (+)= dY[M,N]^T . X[M,K]  through two transposes and the NT GEMM (contraction over the M rows).
     ``bias_sum`` (fp32 [N]): += column sums of dY, taken by the transpose that reads dY anyway."""
-    if _WGRAD_TN and N % 8 == 0 and K % 8 == 0 and dY2d.is_contiguous() and X2d.is_contiguous():
+    if (_WGRAD_TN and N % 8 == 0 and K % 8 == 0 and dY2d.is_contiguous() and X2d.is_contiguous() and dW.is_contiguous()
+            and dW.data_ptr() % 16 == 0):
         # opt-in (ORV_WGRAD_TN=1): orv_gemm_tn_bf16 reads dY and X row-major (transposing LDS reads) - no transposed copies; the bias
         # gradient then costs its own pass over dY.  Only where the tile count fills the chip (the [1920, 1920] out-projection gradient is
         # 80 tiles of 256 x 192: slower); a tall gradient ([7680, 1920]) is computed as dW^T = X^T dY on 256-wide tiles and transposed.
         # Measured against the transposes + NT kernel: profiles/r4_gemm_tn.txt.
         def tiles(rows, cols):
-            return -(-rows // 256) * (cols // 256 if cols % 256 == 0 else cols // 192) if (cols % 256 == 0 or cols % 192 == 0) else 0
+            """256-row x (256 | 192)-column tiles of a [rows, cols] gradient; 0 when neither width divides cols"""
+            if cols % 256 == 0:
+                return -(-rows // 256) * (cols // 256)
+            if cols % 192 == 0:
+                return -(-rows // 256) * (cols // 192)
+            return 0
         direct, flipped = tiles(N, K), (tiles(K, N) if not accumulate else 0)
         if max(direct, flipped) >= 200:
             if bias_sum is not None:

@@ -468,6 +468,8 @@ class AutoencoderKLCogVideoX(nn.Module):
             prev = new
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
 
+    MAX_TILE_STREAMS = 3
+
     def _tiled(self, fn, x, frame_batch, tile_h, tile_w, blend_h_ext, blend_w_ext, limit_h, limit_w):
         """Tiled decode / encode on channels-last ``x`` [B, T, H, W, C] (diffusers ``tiled_decode`` / ``tiled_encode``): ``fn`` on
         overlapping tiles (stride = tile x (1 - overlap factor); each tile frame-batched with its own conv caches and GroupNorm
@@ -487,21 +489,25 @@ class AutoencoderKLCogVideoX(nn.Module):
         if use_streams:
             self._prepack(fn)                    # weight repacking happens once, on THIS stream, before anybody forks
             cur = torch.cuda.current_stream(x.device)
+            # at most MAX_TILE_STREAMS side streams, tiles dealt round-robin (the caching allocator keeps one pool PER stream and
+            # every in-flight tile's activations are live at once, so an uncapped stream count multiplies peak memory with the tile count;
+            # the reference geometry has 4 tiles = 3 side streams, larger frames reuse them)
+            n_side = min(len(coords) - 1, self.MAX_TILE_STREAMS)
             side = getattr(self, "_tile_streams", None)
-            if side is None or len(side) < len(coords) - 1 or side[0].device != x.device:
-                side = self._tile_streams = [torch.cuda.Stream(device=x.device) for _ in range(len(coords) - 1)]
+            if side is None or len(side) < n_side or side[0].device != x.device:
+                side = self._tile_streams = [torch.cuda.Stream(device=x.device) for _ in range(n_side)]
             fork = torch.cuda.Event()
             fork.record(cur)
             for k, (i, j) in enumerate(coords):
-                st = cur if k == 0 else side[k - 1]
-                if k:
+                st = cur if k == 0 else side[(k - 1) % n_side]
+                if k and k <= n_side:
                     st.wait_event(fork)
                 with torch.cuda.stream(st):
                     t = self._batched(fn, x[:, :, i:i + tile_h, j:j + tile_w].contiguous(), frame_batch).contiguous()
                 if k:
                     t.record_stream(cur)         # produced on a side stream, consumed (blend / cat) and freed on this one
                 tiles.append(t)
-            for st in side[:len(coords) - 1]:
+            for st in side[:n_side]:
                 cur.wait_stream(st)
         else:
             tiles = [self._batched(fn, x[:, :, i:i + tile_h, j:j + tile_w].contiguous(), frame_batch).contiguous() for i, j in coords]

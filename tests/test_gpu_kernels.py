@@ -1079,3 +1079,37 @@ def test_attention_w64_variant_passes_the_attention_tests():
                         "fixed_shift or packed_c_from or gamma_product"], cwd=root, env=dict(os.environ, ORV_ATTN_W64="1"),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_shift_free_attention_near_its_limit_with_strongly_negative_rows():
+    """the shift-free kernel takes P = exp2(s) for |s| <= 90 with no shift.  Rows whose scores ALL sit near -bound give P ~ 2^-85
+    (a normal bf16 / fp32 number), P . v products ~ 2^-92 and a row sum ~ S 2^-85: nothing may flush before the 1 / l rescale.  A bound of 88,
+    query rows built so that every score is -85 + small next to ordinary rows, against the online kernel (which subtracts the running max and
+    never sees such magnitudes) and the fp32 reference."""
+    from orv_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    B, S, H = 1, 700, 2
+    D = H * 64
+    qkv = torch.randn(B * S, 3 * D, generator=g) * 0.1
+    qkv[:, 2 * D:] = torch.randn(B * S, D, generator=g)                    # v: ordinary magnitudes
+    for h in range(H):
+        qkv[:, D + h * 64] = 8.0                                           # every key: component 0 = 8
+        qkv[::3, h * 64] = -10.625                                         # every third query: component 0 = -85 / 8  ->  score = -85 + O(0.1)
+    qkv = q(qkv).to(dev, BF)
+    qf, kf = qkv[:, :D].float().view(S, H, 64), qkv[:, D:2 * D].float().view(S, H, 64)
+    s_all = torch.einsum("qhd,khd->hqk", qf, kf)
+    bound = 88.0
+    assert s_all.abs().max().item() <= bound and s_all[:, ::3].max().item() < -80.0
+    out = torch.full((B * S, D), float("nan"), dtype=BF, device=dev)
+    lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+    ops.attention_fwd(qkv, None, out, B, S, H, 0, 1.0 / LOG2E, lse=lse, score_bound=bound)
+    out_online = torch.empty_like(out)
+    lse_online = torch.empty_like(lse)
+    ops.attention_fwd(qkv, None, out_online, B, S, H, 0, 1.0 / LOG2E, lse=lse_online)
+    # the kernel's scores are in log2 units (q pre-multiplied): P = 2^s = exp(s ln 2)
+    ref = torch.einsum("hqk,khd->qhd", torch.softmax(s_all * 0.6931471805599453, dim=-1), qkv[:, 2 * D:].float().view(S, H, 64)).reshape(S, D)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all()
+    close(out, ref)
+    close(out, out_online.float().cpu(), rtol=1.6e-2, afrac=4e-3)
+    assert (lse - lse_online).abs().max().item() <= 2e-3
