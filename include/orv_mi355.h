@@ -103,6 +103,12 @@ int orv_scatter_gated_rows(const void* y, int ldy, const int* idx, const float* 
 int orv_layernorm_modulate(const void* x, int ldx, orv_rowmap_t xmap, void* y, int ldy, const void* gamma,
                            const void* beta, const float* scale, const float* shift, long mod_b, long mod_g,
                            orv_groups_t grp, int batch, int D, float eps, void* stream);
+/* The same with y written in the packed P16 layout (orv_gemm_t: orv_packed_rows(batch * seq) x D bf16) - the A operand of the projections that
+ * follow a CogVideoXLayerNormZero (cogvideox_control.py:232-234, 439) on the d8 GEMM.  Full case only (gamma, beta, scale, shift given, no row
+ * map), D % 32 == 0, D <= 2048. */
+int orv_layernorm_modulate_packed(const void* x, int ldx, void* y, const void* gamma, const void* beta, const float* scale,
+                                  const float* shift, long mod_b, long mod_g, orv_groups_t grp, int batch, int D, float eps,
+                                  void* stream);
 
 /* All AdaLN modulation linears of one forward in a single launch (CogVideoXLayerNormZero "partially forward self.linear
  * twice" cogvideox_control.py:117-130, and AdaLayerNorm :172): for tab in [0, n_tab)

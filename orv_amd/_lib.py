@@ -52,6 +52,8 @@ SIGNATURES = {
     "orv_add_rows": (c_int, [c_void_p, c_int, RowMap, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "orv_layernorm_modulate": (c_int, [c_void_p, c_int, RowMap, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_long, c_long, Groups, c_int, c_int, c_float, c_void_p]),
+    "orv_layernorm_modulate_packed": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, Groups,
+                                              c_int, c_int, c_float, c_void_p]),
     "orv_modulation_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                       c_int, c_void_p]),
     "orv_qkv_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

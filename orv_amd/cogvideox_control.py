@@ -527,7 +527,7 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             nb = ops.attention_ws_bytes(B, S, H)
             # att and h carry orv_packed_rows(M) row slots: on the packed path (below) they hold the P16 layout, else rows [0, M) row-major
             Mp = ops.packed_rows(M)
-            self._ws = {key: dict(x=e(M, D), xn=e(M, D), qkv=e(M, 3 * D), att=e(Mp, D), h=e(Mp, 4 * D), vis=e(B * Nv, D),
+            self._ws = {key: dict(x=e(M, D), xn=e(Mp, D), qkv=e(M, 3 * D), att=e(Mp, D), h=e(Mp, 4 * D), vis=e(B * Nv, D),
                                   vis2=e(B * Nv, D), s_pad=s_pad,
                                   attn_ws=torch.empty(nb, dtype=torch.uint8, device=dev) if nb else None,
                                   packed=self._packed_plan(M, D))}
@@ -540,7 +540,7 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         free - FFN2's A is FFN1's GELU epilogue (cogvideox_control.py:439 -> :440), the out-projection's A is the attention output (:256-263) -
         and the d8 kernel must be the better choice for the shape: exactly where the row-major cost model picks the 256 x 192 t8 tile
         (same tile count; B = 1 and other single-round shapes keep their smaller row-major tiles).  ``ORV_GEMM_PACKED=0``: A/B switch."""
-        plan = {"ffn": False, "out": False}
+        plan = {"ffn": False, "out": False, "qkv": False, "ffn1": False}
         if os.environ.get("ORV_GEMM_PACKED", "1") == "0":
             return plan
         t8_192 = "gemm_t8_kernel<192, 2>"
@@ -556,6 +556,14 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             one_round = D % 128 == 0 and -(-M // 256) * (D // 128) <= _num_cus()
             if ops.gemm_kernel_name(M, D, D, 2) == t8_192 or one_round:
                 plan["out"] = True
+        # the LayerNorm outputs (A of q | k | v and of FFN1): the producer is a row-per-wave VALU kernel whose packed store scatters 16-byte
+        # pieces.  ORV_PACKED_QKV / ORV_PACKED_FFN1 = 1 switch them on (A/B; measured in profiles/r5_model_ab_packed_ln.txt)
+        if D <= 2048 and D % 192 == 0:
+            if os.environ.get("ORV_PACKED_QKV", _PACKED_QKV_DEFAULT) == "1" and ops.gemm_kernel_name(M, 3 * D, D, 4, a_packed=True) is not None:
+                plan["qkv"] = True
+            if (plan["ffn"] and os.environ.get("ORV_PACKED_FFN1", _PACKED_FFN1_DEFAULT) == "1"
+                    and ops.gemm_kernel_name(M, 4 * D, D, 1, a_packed=True, c_packed=True) is not None):
+                plan["ffn1"] = True
         return plan
         t8_192 = "gemm_t8_kernel<192, 2>"
         if (ops.gemm_kernel_name(M, D, 4 * D, 2) == t8_192 and ops.gemm_kernel_name(M, D, 4 * D, 2, a_packed=True) is not None
@@ -653,7 +661,7 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         return self._mv_ptr_tables[1:]
 
     @staticmethod
-    def _qkv_projection(at, xn, qkv, rope, B, S, heads, n_text, s_pad, scale, raw=None):
+    def _qkv_projection(at, xn, qkv, rope, B, S, heads, n_text, s_pad, scale, raw=None, a_packed=False):
         """to_q / to_k / to_v + norm_q / norm_k (+ RoPE) (:232-254): q', k', v into ``qkv``; the attention kernel reads all three
         in place (V through transposing LDS reads: no V^T copy).  Without RoPE the qk LayerNorm and the softmax pre-multiplier
         (scale * log2 e, one rounding) ride in the GEMM epilogue; with RoPE the projection is followed by ``orv_qkv_prep``.
@@ -664,10 +672,10 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         nq, nk = at.norm_q, at.norm_k
         if rope is None and _FUSE_QKNORM:
             ops.gemm(xn, wqkv, bqkv, qkv, M, 3 * D, D, epilogue=4, Y=raw,
-                     qknorm=(nq.weight, nq.bias, nk.weight, nk.bias, at.eps, scale * LOG2E, heads))
+                     qknorm=(nq.weight, nq.bias, nk.weight, nk.bias, at.eps, scale * LOG2E, heads), a_packed=a_packed)
         else:
             dst = qkv if raw is None else raw
-            ops.gemm(xn, wqkv, bqkv, dst, M, 3 * D, D)
+            ops.gemm(xn, wqkv, bqkv, dst, M, 3 * D, D, a_packed=a_packed)
             ops.qkv_prep(qkv, None, nq.weight, nq.bias, nk.weight, nk.bias, rope, B, S, heads, n_text, s_pad, at.eps,
                          q_premul=scale * LOG2E, src=raw)
 
@@ -827,8 +835,8 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             m1, m2 = mod[2 * i], mod[2 * i + 1]
             at = blk.attn1
             ops.layernorm_modulate(x, xn, blk.norm1.norm.weight, blk.norm1.norm.bias, m1[..., D:2 * D], m1[..., :D],
-                                   mb, mg, grp, B, D, c.norm_eps)
-            self._qkv_projection(at, xn, qkv, rope, B, S, heads, Nt, s_pad, scale)
+                                   mb, mg, grp, B, D, c.norm_eps, out_packed=packed["qkv"])
+            self._qkv_projection(at, xn, qkv, rope, B, S, heads, Nt, s_pad, scale, a_packed=packed["qkv"])
             bound = at.score_bound(scale)
             # packed path: the attention kernel writes its output, the FFN1 GELU epilogue the hidden state, in the P16 layout the d8 GEMM reads
             att_p = packed["out"] and ws["attn_ws"] is None and ops.attention_packed_ok(bound, 1.0 / LOG2E)
@@ -839,9 +847,9 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             ops.gemm(att, at.to_out[0].weight, at.to_out[0].bias, x, M, D, D, epilogue=2, R=x, ldr=D,
                      gate=m1[..., 2 * D:], gate_b=mb, gate_g=mg, grp=grp, a_packed=att_p)
             ops.layernorm_modulate(x, xn, blk.norm2.norm.weight, blk.norm2.norm.bias, m2[..., D:2 * D], m2[..., :D],
-                                   mb, mg, grp, B, D, c.norm_eps)
+                                   mb, mg, grp, B, D, c.norm_eps, out_packed=packed["ffn1"])
             f0, f2 = blk.ff.net[0].proj, blk.ff.net[2]
-            ops.gemm(xn, f0.weight, f0.bias, hbuf, M, f0.weight.shape[0], D, epilogue=1, c_packed=packed["ffn"])
+            ops.gemm(xn, f0.weight, f0.bias, hbuf, M, f0.weight.shape[0], D, epilogue=1, a_packed=packed["ffn1"], c_packed=packed["ffn"])
             ops.gemm(hbuf, f2.weight, f2.bias, x, M, D, f0.weight.shape[0], epilogue=2, R=x, ldr=D,
                      gate=m2[..., 2 * D:], gate_b=mb, gate_g=mg, grp=grp, a_packed=packed["ffn"])
 
@@ -877,6 +885,9 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
 # sampler pipeline (:1090-1489)
 # ------------------------------------------------------------------------------------------------------------------
 _FUSE_QKNORM = os.environ.get("ORV_FUSED_QKNORM", "1") != "0"      # A/B switch: 0 = projection + orv_qkv_prep
+
+
+_PACKED_QKV_DEFAULT, _PACKED_FFN1_DEFAULT = "0", "0"
 
 
 def _num_cus() -> int:

@@ -228,10 +228,12 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(const bf16_t* src, bf16_t
 // rows, then per_group rows per frame) FOLDED into two - y = xhat * [gamma (1 + scale)] + [beta (1 + scale) + shift], fp32: one rounding order
 // away from ln_mod_kernel's ((xhat gamma + beta)(1 + scale) + shift), far below the bf16 output step - and prefetches row r + 1 while row r is
 // normalised.
-template <int CH>
 #ifndef ORV_LNR_WAVES
 #define ORV_LNR_WAVES 3
 #endif
+// PACKED: y in the P16 layout (include/orv_mi355.h orv_gemm_t: the A operand of gemm_d8) - chunk c of row r is 16-byte slot (c & 3) * 16 + (r & 15)
+// of block (r >> 4, c >> 2).  A wave instruction then writes 64 scattered 16-byte pieces (four per KiB block) instead of 1 KiB of one row.
+template <int CH, bool PACKED = false>
 __global__ __launch_bounds__(256, ORV_LNR_WAVES) void ln_mod_rows_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t* __restrict__ y, long ldy,
                                                              const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
                                                              const float* __restrict__ scale, const float* __restrict__ shift, long mod_b,
@@ -314,16 +316,17 @@ __global__ __launch_bounds__(256, ORV_LNR_WAVES) void ln_mod_rows_kernel(const b
             for (int e = 0; e < 8; ++e) o[e] = fmaf((v[i][e] - mean) * rstd, gg[i][e], hh[i][e]);
             uint4 u;
             u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]); u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
-            *(uint4*)(yr + ce[i] * 8) = u;       // lanes past the row end re-store the last chunk's identical bytes
+            if (PACKED) *(uint4*)(y + ((((long)(row >> 4) * (D >> 5) + (ce[i] >> 2)) << 9) + ((((ce[i] & 3) << 4) + (row & 15)) << 3))) = u;
+            else *(uint4*)(yr + ce[i] * 8) = u;       // lanes past the row end re-store the last chunk's identical bytes
         }
     }
 }
 
 }  // namespace
 
-extern "C" int orv_layernorm_modulate(const void* x, int ldx, orv_rowmap_t xmap, void* y, int ldy, const void* gamma,
-                                      const void* beta, const float* scale, const float* shift, long mod_b, long mod_g,
-                                      orv_groups_t grp, int batch, int D, float eps, void* stream) {
+static int layernorm_modulate_impl(const void* x, int ldx, orv_rowmap_t xmap, void* y, int ldy, const void* gamma,
+                                   const void* beta, const float* scale, const float* shift, long mod_b, long mod_g,
+                                   orv_groups_t grp, int batch, int D, float eps, void* stream, bool packed) {
     ORV_REQUIRE(x && y, "orv_layernorm_modulate: null operand");
     ORV_REQUIRE(D % 8 == 0 && D <= 4096, "orv_layernorm_modulate: D=%d must be a multiple of 8 and <= 4096", D);
     ORV_REQUIRE(grp.seq > 0 && batch > 0, "orv_layernorm_modulate: empty problem");
@@ -338,14 +341,21 @@ extern "C" int orv_layernorm_modulate(const void* x, int ldx, orv_rowmap_t xmap,
     // the problem.  ORV_LN_ROWS=0: the one-row kernel everywhere (A/B); ORV_LN_ROWS=n: fixed R.
     static int rows_env = -2;
     if (rows_env == -2) { const char* e = getenv("ORV_LN_ROWS"); rows_env = e ? atoi(e) : -1; }
-    if (full && xmap.rows == 0 && rows_env != 0 && rows >= 2048 && ch <= 4) {
+    ORV_REQUIRE(!packed || (full && xmap.rows == 0 && ch <= 4 && D % 32 == 0 && ldy == D),
+                "orv_layernorm_modulate_packed: needs gamma, beta, scale, shift, no row map, D %% 32 == 0, D <= 2048 and ldy == D");
+    if (full && xmap.rows == 0 && (packed || (rows_env != 0 && rows >= 2048)) && ch <= 4) {
         const int slots = 256 * 4 * ORV_LNR_WAVES;
         const int R = rows_env > 0 ? rows_env : max(2, (rows + slots - 1) / slots);
         dim3 g2(((rows + R - 1) / R + 3) / 4);
 #define ORV_LNR_CASE(C)                                                                                                \
-        hipLaunchKernelGGL((ln_mod_rows_kernel<C>), g2, block, 0, st, (const bf16_t*)x, (long)ldx, (bf16_t*)y, (long)ldy, \
-                           (const bf16_t*)gamma, (const bf16_t*)beta, scale, shift, mod_b, mod_g, grp.seq, grp.n_text, \
-                           grp.per_group, rows, D, eps, R)
+        if (packed)                                                                                                    \
+            hipLaunchKernelGGL((ln_mod_rows_kernel<C, true>), g2, block, 0, st, (const bf16_t*)x, (long)ldx, (bf16_t*)y, (long)ldy, \
+                               (const bf16_t*)gamma, (const bf16_t*)beta, scale, shift, mod_b, mod_g, grp.seq, grp.n_text, \
+                               grp.per_group, rows, D, eps, R);                                                        \
+        else                                                                                                           \
+            hipLaunchKernelGGL((ln_mod_rows_kernel<C>), g2, block, 0, st, (const bf16_t*)x, (long)ldx, (bf16_t*)y, (long)ldy, \
+                               (const bf16_t*)gamma, (const bf16_t*)beta, scale, shift, mod_b, mod_g, grp.seq, grp.n_text, \
+                               grp.per_group, rows, D, eps, R)
         if (ch <= 1) { ORV_LNR_CASE(1); }
         else if (ch <= 2) { ORV_LNR_CASE(2); }
         else { ORV_LNR_CASE(4); }
@@ -368,6 +378,20 @@ extern "C" int orv_layernorm_modulate(const void* x, int ldx, orv_rowmap_t xmap,
     else { ORV_LN_CASE(8); }
 #undef ORV_LN_CASE
     return orv_check_launch("orv_layernorm_modulate");
+}
+
+extern "C" int orv_layernorm_modulate(const void* x, int ldx, orv_rowmap_t xmap, void* y, int ldy, const void* gamma,
+                                      const void* beta, const float* scale, const float* shift, long mod_b, long mod_g,
+                                      orv_groups_t grp, int batch, int D, float eps, void* stream) {
+    return layernorm_modulate_impl(x, ldx, xmap, y, ldy, gamma, beta, scale, shift, mod_b, mod_g, grp, batch, D, eps, stream, false);
+}
+// y in the packed P16 layout (orv_packed_rows(batch * seq) x D; the A operand of the d8 GEMM): the full case only (gamma, beta, scale, shift,
+// no row map), D % 32 == 0, D <= 2048
+extern "C" int orv_layernorm_modulate_packed(const void* x, int ldx, void* y, const void* gamma, const void* beta, const float* scale,
+                                             const float* shift, long mod_b, long mod_g, orv_groups_t grp, int batch, int D, float eps,
+                                             void* stream) {
+    orv_rowmap_t none{0, 0, 0};
+    return layernorm_modulate_impl(x, ldx, none, y, D, gamma, beta, scale, shift, mod_b, mod_g, grp, batch, D, eps, stream, true);
 }
 
 extern "C" int orv_qkv_prep_from(const void* src, void* qkv, void* vT, const void* gq, const void* bq, const void* gk,

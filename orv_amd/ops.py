@@ -138,8 +138,13 @@ def add_rows(a, amap: Optional[RowMap], b, out, col_off, M, D, lda=None, ldb=Non
 
 
 def layernorm_modulate(x, y, gamma, beta, scale, shift, mod_b, mod_g, grp: Groups, batch, D, eps, ldx=None, ldy=None,
-                       xmap: Optional[RowMap] = None):
+                       xmap: Optional[RowMap] = None, out_packed=False):
+    """``out_packed``: ``y`` is a packed P16 buffer [packed_rows(batch * seq), D] (``orv_layernorm_modulate_packed``)."""
     _need(x, BF16, "x"), _need(y, BF16, "y")
+    if out_packed:
+        check(lib().orv_layernorm_modulate_packed(_p(x), ldx or D, _p(y), _p(gamma), _p(beta), _p(scale), _p(shift), mod_b, mod_g, grp,
+                                                  batch, D, float(eps), _stream()), "orv_layernorm_modulate_packed")
+        return y
     check(lib().orv_layernorm_modulate(_p(x), ldx or D, xmap or RowMap(0, 0, 0), _p(y), ldy or D, _p(gamma), _p(beta),
                                        _p(scale), _p(shift), mod_b, mod_g, grp, batch, D, float(eps), _stream()),
           "orv_layernorm_modulate")
