@@ -83,7 +83,8 @@ __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][B
             if (p.c_rows > 0) orow[rb][j] = (long)(mc / p.c_rows) * p.c_bstride + p.c_off + mc % p.c_rows;
         }
     // row operands (residual / GELU-adjoint input) of one 64-column group: requested one group ahead
-    uint4 r8[D8_RSETS][2][2];                           // [set][rb][j]
+    constexpr int RS = (D8_RSETS == 0) ? (BN <= 192 ? NG : 1) : D8_RSETS;    // D8_RSETS = 0: every group's rows up front where the registers allow (BN <= 192)
+    uint4 r8[RS][2][2];                                 // [set][rb][j]
     auto load_rows = [&](int cg, uint4 (&dst)[2][2]) {
         const int col8 = col0 + 64 * cg + 8 * c;
 #pragma unroll
@@ -97,13 +98,19 @@ __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][B
                 dst[rb][j] = *(const uint4*)(p.R + rr * p.ldr + col8);
             }
     };
-    if (EPI == 2 || EPI == 3) load_rows(0, r8[0]);
+    if (EPI == 2 || EPI == 3) {
+        load_rows(0, r8[0]);
+        if (RS == NG && NG > 1) {
+#pragma unroll
+            for (int cg = 1; cg < NG; ++cg) load_rows(cg, r8[cg % RS]);
+        }
+    }
 
 #pragma unroll
     for (int cg = 0; cg < NG; ++cg) {
         const int col8 = col0 + 64 * cg + 8 * c;
-        if (D8_RSETS == 2 && (EPI == 2 || EPI == 3) && cg + 1 < NG) load_rows(cg + 1, r8[(cg + 1) & 1]);
-        if (D8_RSETS == 1 && (EPI == 2 || EPI == 3) && cg > 0) load_rows(cg, r8[0]);
+        if (RS == 2 && RS != NG && (EPI == 2 || EPI == 3) && cg + 1 < NG) load_rows(cg + 1, r8[(cg + 1) & 1]);
+        if (RS == 1 && (EPI == 2 || EPI == 3) && cg > 0) load_rows(cg, r8[0]);
         float b8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) b8[e] = 0.f;
@@ -186,7 +193,7 @@ __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][B
                 }
                 if (EPI == 2) {
                     float rv[8], gg[8];
-                    d8_unpack8(r8[cg & (D8_RSETS - 1)][rb][j], rv);
+                    d8_unpack8(r8[cg % RS][rb][j], rv);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) gg[e] = g8[e];
                     if (g_lane) {            // block straddles a frame / text boundary: this lane's row picks its own gate row
@@ -200,7 +207,7 @@ __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][B
                 }
                 if (EPI == 3) {
                     float rv[8];
-                    d8_unpack8(r8[cg & (D8_RSETS - 1)][rb][j], rv);
+                    d8_unpack8(r8[cg % RS][rb][j], rv);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) w[e] *= gelu_tanh_grad(rv[e]);
                 }
