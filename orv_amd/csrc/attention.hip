@@ -423,6 +423,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_v2_kernel(const AttnArgs p) {
 //     guide T13 ordering).
 //   * epilogue: O rows leave as 16-byte pieces (two 8-byte column groups exchanged between lane and lane ^ 32, guide T21).
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef ORV_ATTN_M16_DEFAULT
+#define ORV_ATTN_M16_DEFAULT 0
+#endif
 #ifndef ORV_ATTN_W64_DEFAULT
 #define ORV_ATTN_W64_DEFAULT 0
 #endif
@@ -1388,7 +1391,12 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_m16_kernel(const AttnArgs p) 
             // even group: x = own quad of block 2 dp, y = partner's quad of block 2 dp        -> d 32 dp + 4 g .. + 7
             // odd group:  x = partner's quad of block 2 dp + 1, y = own quad of block 2 dp + 1 -> d 32 dp + 16 + 4 (g - 1) .. + 7
             const int d0 = 32 * dp + ((g & 1) ? 16 + 4 * (g - 1) : 4 * g);
-            if (q < p.S) *(uint4*)(op + d0) = make_uint4(x0, x1, y0, y1);
+            if (q < p.S) {
+                if (p.out_packed) {     // P16 layout: 16-byte slot (d0 % 32 / 8) * 16 + m % 16 of block (m / 16, 2 h + dp)
+                    const long m_ = row0 + q;
+                    *(uint4*)((char*)p.out + (((m_ >> 4) * (p.ld_out >> 5) + 2 * h + dp) << 10) + (((((d0 & 31) >> 3) << 4) + (m_ & 15)) << 4)) = make_uint4(x0, x1, y0, y1);
+                } else *(uint4*)(op + d0) = make_uint4(x0, x1, y0, y1);
+            }
         }
 #if !defined(ORV_SEG_TRACE) && !defined(ORV_PP_TRACE)
         if (p.lse && g == 0 && q < p.S) p.lse[((long)b * p.H + h) * p.S + q] = __log2f(l_tot) * 0.6931471805599453f;
@@ -1464,7 +1472,7 @@ extern "C" int orv_attention_fwd_bounded(const void* qkv, int ld_qkv, void* out,
     static int use_pp = -1;
     if (use_pp < 0) { const char* e = getenv("ORV_ATTN_PP"); use_pp = (e && atoi(e) == 0) ? 0 : 1; }
     static int use_m16 = -1;         // ORV_ATTN_M16=1: the 16x16x32 form of the ping-pong kernel (A/B switch)
-    if (use_m16 < 0) { const char* e = getenv("ORV_ATTN_M16"); use_m16 = (e && atoi(e) != 0) ? 1 : 0; }
+    if (use_m16 < 0) { const char* e = getenv("ORV_ATTN_M16"); use_m16 = e ? (atoi(e) != 0) : ORV_ATTN_M16_DEFAULT; }
     if (use_pp && attn_use_w64() && ld_out % 8 == 0 && ((uintptr_t)out & 15) == 0)
         hipLaunchKernelGGL(attn_fwd_w64_kernel, dim3((grid.x + 1) / 2), dim3(512), 0, (hipStream_t)stream, a);
     else if (use_pp && use_m16 && ld_out % 8 == 0 && ((uintptr_t)out & 15) == 0)
@@ -1493,7 +1501,10 @@ extern "C" int orv_attention_fwd_packed(const void* qkv, int ld_qkv, void* out, 
     a.lse = lse; a.B = B; a.S = S; a.H = H; a.s_pad = 0;
     a.scale = scale; a.scale_log2 = scale_log2; a.shift = score_bound; a.guard_dev = nullptr; a.guard_limit = 0.f; a.ws_o = a.ws_l = nullptr; a.ws_cnt = nullptr; a.n_full = a.ks = 0;
     a.out_packed = 1;
+    static int use_m16p = -1;
+    if (use_m16p < 0) { const char* e = getenv("ORV_ATTN_M16"); use_m16p = e ? (atoi(e) != 0) : ORV_ATTN_M16_DEFAULT; }
     if (attn_use_w64()) hipLaunchKernelGGL(attn_fwd_w64_kernel, dim3((((S + 255) / 256) * H * B + 1) / 2), dim3(512), 0, (hipStream_t)stream, a);
+    else if (use_m16p) hipLaunchKernelGGL(attn_fwd_m16_kernel, dim3(((S + 255) / 256) * H * B), dim3(512), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((attn_fwd_pp_kernel<true>), dim3(((S + 255) / 256) * H * B), dim3(512), 0, (hipStream_t)stream, a);
     return orv_check_launch("orv_attention_fwd_packed");
 }
@@ -1549,7 +1560,7 @@ extern "C" int orv_attention_fwd_bounded_ws(const void* qkv, int ld_qkv, void* o
     static int use_static = -1, use_pp = -1, use_m16 = -1;
     if (use_static < 0) { const char* e = getenv("ORV_ATTN_STATIC"); use_static = (e && atoi(e) == 0) ? 0 : 1; }
     if (use_pp < 0) { const char* e = getenv("ORV_ATTN_PP"); use_pp = (e && atoi(e) == 0) ? 0 : 1; }
-    if (use_m16 < 0) { const char* e = getenv("ORV_ATTN_M16"); use_m16 = (e && atoi(e) != 0) ? 1 : 0; }
+    if (use_m16 < 0) { const char* e = getenv("ORV_ATTN_M16"); use_m16 = e ? (atoi(e) != 0) : ORV_ATTN_M16_DEFAULT; }
     const AttnSplit sp = (ws && B > 0 && S > 0 && H > 0) ? attn_split_plan(B, S, H) : AttnSplit{0, 0, 0};
     if (!sp.ks || !use_static || !use_pp || use_m16 || !fused || !(score_bound > 0.f) || score_bound > ORV_STATIC_LIMIT_PP ||
         ld_out % 8 != 0 || ((uintptr_t)out & 15) != 0 || ((uintptr_t)ws & 255) != 0 || ws_bytes < orv_attention_ws_bytes(B, S, H))

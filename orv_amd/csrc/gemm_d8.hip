@@ -56,10 +56,38 @@ __device__ __forceinline__ unsigned long long d8_uniform64(unsigned long long u)
 #ifndef D8_RSETS
 #define D8_RSETS 1
 #endif
+// RLDS (row-operand epilogues at BN <= 192, where 32 KiB of LDS are free): the residual rows of a 64-column group arrive by LDS-DMA in a
+// per-wave 4-KiB slab ([32 rows][128 B], full-line pieces) instead of by register loads whose latency the epilogue would wait for - group
+// 0's is issued three K-tiles before the K loop ends (d8_issue_rows from the kernel), group g + 1's as soon as group g's rows have been
+// read out of the slab.  No registers are held across the wait.
+__device__ __forceinline__ void d8_glds_v(const void* gsrc, const char* lds_dst) {
+    const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_dst);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(d) : "memory", "m0");
+}
+__device__ __forceinline__ void d8_issue_rows(const GemmArgs& p, const int row0, const int colg, const int lane, const char* slab) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int mc = min(row0 + 8 * j + (lane >> 3), p.M - 1);
+        long rr = mc;
+        if (p.r_mod > 0) rr = mc % p.r_mod;
+        else if (p.c_rows > 0) rr = (long)(mc / p.c_rows) * p.c_bstride + p.c_off + mc % p.c_rows;
+        d8_glds_v(p.R + rr * p.ldr + colg + 8 * (lane & 7), slab + j * 1024);
+    }
+}
+template <int BN, int EPI>
+constexpr bool d8_rlds() {
+#ifdef ORV_D8_RLDS       // opt-in build: measured level with the register loads (profiles/r5_gemm_d8_rlds.txt: FFN2 0.2907 vs 0.2903 ms, out-projection
+    return BN <= 192 && (EPI == 2 || EPI == 3);     // 0.0953 vs 0.0945) - the epilogue does not wait for its residual rows
+#else
+    return false;
+#endif
+}
+
 template <int BN, int EPI>
 __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][BN / 16], const int row0, const int col0, const int lane,
-                                            char* const scr) {
+                                            char* const scr, const char* const rslab = nullptr) {
     constexpr int NG = BN / 64;
+    constexpr bool RLDS = d8_rlds<BN, EPI>();
     const int g = lane >> 4, r16 = lane & 15;
     const int c = lane & 7, rr8 = lane >> 3;
     int woff[4];
@@ -98,9 +126,25 @@ __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][B
                 dst[rb][j] = *(const uint4*)(p.R + rr * p.ldr + col8);
             }
     };
-    if (EPI == 2 || EPI == 3) {
+    // RLDS: rows of group cg out of the slab (the DMA was issued by the kernel / by the previous group), then the next group's DMA
+    auto take_rows = [&](int cg, uint4 (&dst)[2][2]) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dst[rb][j] = *(const uint4*)(rslab + (rb * 16 + 8 * j + rr8) * 128 + c * 16);
+        if (cg + 1 < NG) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            d8_issue_rows(p, row0, col0 + 64 * (cg + 1), lane, rslab);
+        }
+    };
+    if (RLDS) {
+        take_rows(0, r8[0]);
+    } else if (EPI == 2 || EPI == 3) {
         load_rows(0, r8[0]);
-        if (RS == NG && NG > 1) {
+        if (RS == NG && NG > 1 && !RLDS) {
 #pragma unroll
             for (int cg = 1; cg < NG; ++cg) load_rows(cg, r8[cg % RS]);
         }
@@ -109,8 +153,9 @@ __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][B
 #pragma unroll
     for (int cg = 0; cg < NG; ++cg) {
         const int col8 = col0 + 64 * cg + 8 * c;
-        if (RS == 2 && RS != NG && (EPI == 2 || EPI == 3) && cg + 1 < NG) load_rows(cg + 1, r8[(cg + 1) & 1]);
-        if (RS == 1 && (EPI == 2 || EPI == 3) && cg > 0) load_rows(cg, r8[0]);
+        if (!RLDS && RS == 2 && RS != NG && (EPI == 2 || EPI == 3) && cg + 1 < NG) load_rows(cg + 1, r8[(cg + 1) & 1]);
+        if (RLDS) { if (cg > 0) take_rows(cg, r8[0]); }
+        else if (RS == 1 && (EPI == 2 || EPI == 3) && cg > 0) load_rows(cg, r8[0]);
         float b8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) b8[e] = 0.f;
@@ -193,7 +238,7 @@ __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][B
                 }
                 if (EPI == 2) {
                     float rv[8], gg[8];
-                    d8_unpack8(r8[cg % RS][rb][j], rv);
+                    d8_unpack8(r8[RLDS ? 0 : cg % RS][rb][j], rv);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) gg[e] = g8[e];
                     if (g_lane) {            // block straddles a frame / text boundary: this lane's row picks its own gate row
@@ -207,7 +252,7 @@ __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][B
                 }
                 if (EPI == 3) {
                     float rv[8];
-                    d8_unpack8(r8[cg % RS][rb][j], rv);
+                    d8_unpack8(r8[RLDS ? 0 : cg % RS][rb][j], rv);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) w[e] *= gelu_tanh_grad(rv[e]);
                 }
@@ -347,6 +392,10 @@ __global__ __launch_bounds__(512) void gemm_d8_kernel(const GemmArgs p) {
     // phase (4 CBP MFMAs) to land, reads and MFMAs alternate 1 : 2 instead of arriving in bursts, and no second fragment set is needed.
 #ifdef ORV_D8_ABL_NOREAD
 #define D8_READ1(T, KH, BOFF, PH) asm volatile("" : "+v"(fx[T][KH]));
+#elif defined(ORV_D8_ABL_READ2)   // experiment (right results): every fragment is read TWICE (the second copy is thrown away) - what do LDS reads cost in time / energy?
+#define D8_READ1(T, KH, BOFF, PH)                                                                                    \
+    { fx[T][KH] = *(const bf16x8*)(((KH) ? rd1 : rd0) + (BOFF) + ((PH) * CBP + (T)) * 2048);                         \
+      bf16x8 dummy_ = *(const volatile bf16x8*)(((KH) ? rd0 : rd1) + (BOFF) + ((PH) * CBP + (T)) * 2048); asm volatile("" :: "v"(dummy_)); }
 #else
 #define D8_READ1(T, KH, BOFF, PH) fx[T][KH] = *(const bf16x8*)(((KH) ? rd1 : rd0) + (BOFF) + ((PH) * CBP + (T)) * 2048);
 #endif
@@ -421,6 +470,11 @@ __global__ __launch_bounds__(512) void gemm_d8_kernel(const GemmArgs p) {
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         for (int kt = 0; kt < nk; kt += 3) {
+            if (d8_rlds<BN, EPI>() && kt + 3 >= nk) {      // the epilogue's first residual rows: in flight under the last three K-tiles
+                int tm_, tn_;
+                tile_of_index(p, tile, ntiles, tm_, tn_);
+                d8_issue_rows(p, tm_ * 256 + wave * 32, tn_ * BN, lane, smem + SCR + 8 * 4096 + wave * 4096);
+            }
             D8_KTILE(a0, a2)
             D8_KTILE(a1, a0)
             D8_KTILE(a2, a1)
@@ -428,7 +482,7 @@ __global__ __launch_bounds__(512) void gemm_d8_kernel(const GemmArgs p) {
         int tm, tn;
         tile_of_index(p, tile, ntiles, tm, tn);
         if ((EPI == 0 || EPI == 1) && p.c_packed) d8_epilogue_packed<BN, EPI>(p, acc, tm * 256 + wave * 32, tn * BN, lane);
-        else d8_epilogue<BN, EPI>(p, acc, tm * 256 + wave * 32, tn * BN, lane, smem + SCR + wave * 4096);
+        else d8_epilogue<BN, EPI>(p, acc, tm * 256 + wave * 32, tn * BN, lane, smem + SCR + wave * 4096, smem + SCR + 8 * 4096 + wave * 4096);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -441,7 +495,7 @@ __global__ __launch_bounds__(512) void gemm_d8_kernel(const GemmArgs p) {
 
 template <int BN, int EPI>
 int launch_d8_one(const GemmArgs& a, hipStream_t st) {
-    constexpr int smem = 4 * BN * 128 + 8 * 4096;     // four W buffers + the epilogue scratch (160 KiB at BN = 256)
+    constexpr int smem = 4 * BN * 128 + 8 * 4096 + (d8_rlds<BN, EPI>() ? 8 * 4096 : 0);     // four W buffers + the epilogue scratch (160 KiB at BN = 256) + the residual slabs
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)gemm_d8_kernel<BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);

@@ -25,7 +25,7 @@ for fill in ("random", "zero"):
     W = ((torch.randn(N, K, device=dev, generator=g) * 0.05) if fill == "random" else torch.zeros(N, K, device=dev)).to(torch.bfloat16)
     Ap = ops.pack_rows16(A, M, K)
     C = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
-    for kern in ("t8", "d8"):
+    for kern in (("d8",) if os.environ.get("PG_D8_ONLY") else ("t8", "d8")):
         lib().orv_gemm_force_tile(3 if kern == "t8" else 5, 256, 192)
         samples, stop = [], threading.Event()
 
