@@ -110,6 +110,26 @@ __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][B
             orow[rb][j] = mc;
             if (p.c_rows > 0) orow[rb][j] = (long)(mc / p.c_rows) * p.c_bstride + p.c_off + mc % p.c_rows;
         }
+    // gate rows (EPI 2) of the two 16-row blocks: wave-uniform when a block lies inside one (batch element, token group) - the index
+    // arithmetic (integer divisions on the scalar unit) runs once per tile, not once per 64-column group
+    const float* gate_row[2] = {nullptr, nullptr};
+    bool gate_lane[2] = {false, false};
+    if (EPI == 2 && p.gate) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const int mf = __builtin_amdgcn_readfirstlane(row0 + rb * 16), ml = min(mf + 15, p.M - 1);
+            long of = min(mf, p.M - 1), ol = ml;
+            if (p.c_rows > 0) {
+                of = (long)(of / p.c_rows) * p.c_bstride + p.c_off + of % p.c_rows;
+                ol = (long)(ml / p.c_rows) * p.c_bstride + p.c_off + ml % p.c_rows;
+            }
+            const int bf_ = (int)(of / p.seq), bl_ = (int)(ol / p.seq);
+            const int gf_ = orv_group_of((int)(of % p.seq), p.n_text, p.per_group);
+            const int gl_ = orv_group_of((int)(ol % p.seq), p.n_text, p.per_group);
+            if (bf_ == bl_ && gf_ == gl_) gate_row[rb] = p.gate + bf_ * p.gate_b + gf_ * p.gate_g;
+            else gate_lane[rb] = true;
+        }
+    }
     // row operands (residual / GELU-adjoint input) of one 64-column group: requested one group ahead
     constexpr int RS = (D8_RSETS == 0) ? (BN <= 192 ? NG : 1) : D8_RSETS;    // D8_RSETS = 0: every group's rows up front where the registers allow (BN <= 192)
     uint4 r8[RS][2][2];                                 // [set][rb][j]
@@ -190,26 +210,15 @@ __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][B
                 v[j][0] = lo[0]; v[j][1] = lo[1]; v[j][2] = lo[2]; v[j][3] = lo[3];
                 v[j][4] = hi[0]; v[j][5] = hi[1]; v[j][6] = hi[2]; v[j][7] = hi[3];
             }
-            // gate row of this 16-row block (EPI 2): wave-uniform when the block lies inside one (batch element, token group)
-            bool g_lane = false;
-            if (EPI == 2 && p.gate) {
-                const int mf = __builtin_amdgcn_readfirstlane(row0 + rb * 16), ml = min(mf + 15, p.M - 1);
-                long of = min(mf, p.M - 1), ol = ml;
-                if (p.c_rows > 0) {
-                    of = (long)(of / p.c_rows) * p.c_bstride + p.c_off + of % p.c_rows;
-                    ol = (long)(ml / p.c_rows) * p.c_bstride + p.c_off + ml % p.c_rows;
+            // gate row of this 16-row block (EPI 2): found once per tile (gate_row[] above), the values of this group's columns loaded here
+            const bool g_lane = (EPI == 2 && p.gate) ? gate_lane[rb] : false;
+            if (EPI == 2 && p.gate && !g_lane) {
+                const float* gr = gate_row[rb];
+                if (gr != g_cached) {
+                    g_cached = gr;
+                    const float4 a = *(const float4*)(gr + col8), b = *(const float4*)(gr + col8 + 4);
+                    g8[0] = a.x; g8[1] = a.y; g8[2] = a.z; g8[3] = a.w; g8[4] = b.x; g8[5] = b.y; g8[6] = b.z; g8[7] = b.w;
                 }
-                const int bf_ = (int)(of / p.seq), bl_ = (int)(ol / p.seq);
-                const int gf_ = orv_group_of((int)(of % p.seq), p.n_text, p.per_group);
-                const int gl_ = orv_group_of((int)(ol % p.seq), p.n_text, p.per_group);
-                if (bf_ == bl_ && gf_ == gl_) {
-                    const float* gr = p.gate + bf_ * p.gate_b + gf_ * p.gate_g;
-                    if (gr != g_cached) {
-                        g_cached = gr;
-                        const float4 a = *(const float4*)(gr + col8), b = *(const float4*)(gr + col8 + 4);
-                        g8[0] = a.x; g8[1] = a.y; g8[2] = a.z; g8[3] = a.w; g8[4] = b.x; g8[5] = b.y; g8[6] = b.z; g8[7] = b.w;
-                    }
-                } else g_lane = true;
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
