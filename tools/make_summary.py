@@ -47,3 +47,13 @@ table("== denoise (python bench.py --no-vae) ==", f"r{RN}_bench_novae_kernel_sta
 t = last_json(os.path.join(R, f"r{RN}_train_2b_line.json"))
 print(f"train: {t['ms_per_step']} ms/step, {t['value']} clips/s, peak {t['peak_hbm_gib']} GiB\n")
 table("== SFT step (python bench.py --mode train) ==", f"r{RN}_train_kernel_stats_summary.txt", "hbm_traffic_train.json", None)
+b1p = os.path.join(R, f"r{RN}_bench_b1_kernel_stats_summary.txt")
+if os.path.exists(b1p):
+    b1 = last_json(os.path.join(R, f"r{RN}_bench_line_b1.json"))
+    print(f"B = 1: {b1['ms_per_step']} ms/step, {b1['achieved_tflops_attn_ffn']} TFLOP/s attention+FFN = {b1['frac_mfma_peak_attn_ffn']} x peak\n")
+    table("== denoise, B = 1 (python bench.py --batch 1 --no-vae) ==", f"r{RN}_bench_b1_kernel_stats_summary.txt", "-", b1)
+vp = os.path.join(R, f"r{RN}_vae_kernel_stats_summary.txt")
+if os.path.exists(vp):
+    v = (d.get("vae_decode") or {})
+    print(f"VAE decode (tiled, as the reference configures it): {v.get('ms_per_clip')} ms per clip, {v.get('frames_per_s')} frames/s\n")
+    table("== VAE decode (tools/profile_vae.sh) ==", f"r{RN}_vae_kernel_stats_summary.txt", "-", None)

@@ -14,6 +14,8 @@ python bench.py --mode train --model 5b --no-cpu-baseline --steps 6 --warmup 2 2
 python bench.py --mode train --model 5b --no-cpu-baseline --steps 6 --warmup 2 --grad-ckpt 2>/dev/null | tail -1 > $O/train_5b_ckpt_line.json
 bash tools/profile_bench.sh r5nv --no-vae --no-legs --no-pmc > $O/profile_bench_nv.log 2>&1 < /dev/null
 cp gpurun_out/prof_r5nv/r5nv_kernel_stats_summary.txt $O/bench_novae_kernel_stats_summary.txt; grep '^{' gpurun_out/prof_r5nv/bench_stdout.log | tail -1 > $O/bench_line_under_rocprof.json
+bash tools/profile_bench.sh r5b1 --batch 1 --no-vae --no-legs --no-pmc > $O/profile_bench_b1.log 2>&1 < /dev/null
+cp gpurun_out/prof_r5b1/r5b1_kernel_stats_summary.txt $O/bench_b1_kernel_stats_summary.txt
 bash tools/profile_bench.sh r5tr --mode train --steps 4 --warmup 1 > $O/profile_train.log 2>&1 < /dev/null
 cp gpurun_out/prof_r5tr/r5tr_kernel_stats_summary.txt $O/train_kernel_stats_summary.txt
 bash tools/profile_vae.sh r5 1 3 > $O/profile_vae.log 2>&1 < /dev/null
