@@ -55,5 +55,5 @@ if os.path.exists(b1p):
 vp = os.path.join(R, f"r{RN}_vae_kernel_stats_summary.txt")
 if os.path.exists(vp):
     v = (d.get("vae_decode") or {})
-    print(f"VAE decode (tiled, as the reference configures it): {v.get('ms_per_clip')} ms per clip, {v.get('frames_per_s')} frames/s\n")
+    print(f"VAE decode (tiled, as the reference configures it): {v.get('ms_per_clip')} ms per clip ({v.get('ms_per_clip_untiled')} untiled); 50-step pipeline {v.get('frames_per_sec_50_steps_incl_decode')} frames/s with the decode, {v.get('frames_per_sec_50_steps_excl_decode')} without\n")
     table("== VAE decode (tools/profile_vae.sh) ==", f"r{RN}_vae_kernel_stats_summary.txt", "-", None)
