@@ -665,7 +665,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(const BwdArgs p)
 // Y_t = { P = exp2(S), dS = P dP, bf16 pack of both }.  Q' and dO tiles: three slots each; waves 0-3 stage Q' (+ the lse
 // vector) one tile ahead, waves 4-7 dO (+ the delta vector) two tiles ahead.
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[6 * TILE + 6 * 256];   // Q' slots 0-2 | dO slots 0-2 | lse x3 | delta x3
+    __shared__ __attribute__((aligned(16))) char smem[7 * TILE + 7 * 256];   // Q' slots 0-3 | dO slots 0-2 | lse x4 | delta x3
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wq = wave & 3;
@@ -697,15 +697,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p
         const int sr = wq * 16 + j * 8 + (lane >> 3), slot = lane & 7;
         loff[j] = (unsigned)((sr * (int)ldx + (slot ^ swz(sr)) * 8) * 2);
     }
-    char* const sdst = smem + grp * 3 * TILE + wq * 2048;
+    char* const sdst = smem + grp * 4 * TILE + wq * 2048;
     const char* const vbase = (const char*)((grp == 0 ? p.neg_lse2 : p.neg_delta) + hb * p.s_pad);
-    char* const vdst = smem + 6 * TILE + grp * 3 * 256;
+    char* const vdst = smem + 7 * TILE + grp * 4 * 256;
     auto stage = [&](int t) {
         if (t >= nt) return;
 #ifdef ORV_BW_ABL_NODMA
         if (t > 1) return;
 #endif
-        char* const d = sdst + (t % 3) * TILE;
+        const int slot_ = grp == 0 ? (t & 3) : t % 3;       // Q': four slots (staged two tiles ahead from the vector segment), dO: three
+        char* const d = sdst + slot_ * TILE;
         if (__builtin_expect(ragged && t == nt - 1, 0)) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {          // rows past S read a valid row (masked in the vector segment)
@@ -718,7 +719,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p
             glds16_sv(tb, loff[1], d + 1024);
         }
         // the tile's 64-float vector travels by LDS-DMA too (a register round trip would put a vmcnt(0) behind the tile loads)
-        if (wq == 0) glds4_sv(vbase + (long)t * 256, (unsigned)(lane * 4), vdst + (t % 3) * 256);
+        if (wq == 0) glds4_sv(vbase + (long)t * 256, (unsigned)(lane * 4), vdst + slot_ * 256);
     };
     f32x16 dk[2], dv[2], sS[2], dP[2];
 #pragma unroll
@@ -738,17 +739,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p
     // barrier, so X_t opens with MFMAs instead of an LDS round trip
     bf16x8 o0 = kf[0], o1 = kf[0], g0_ = kf[0], g1_ = kf[0];
     auto prefetch_g = [&](int t) {                                 // fragments of tile t for the gradient part of X_{t+1}
-        const char* sQp = smem + (t % 3) * TILE;
-        const char* sOp = smem + 3 * TILE + (t % 3) * TILE;
+        const char* sQp = smem + (t & 3) * TILE;
+        const char* sOp = smem + 4 * TILE + (t % 3) * TILE;
         o0 = tr_pair(sOp + t00, sOp + t01); o1 = tr_pair(sOp + t10, sOp + t11);
         g0_ = tr_pair(sQp + t00, sQp + t01); g1_ = tr_pair(sQp + t10, sQp + t11);
     };
     auto seg_x = [&](int t, auto stage_q) {
         __builtin_amdgcn_s_setprio(1);
-        const char* sQ = smem + (t % 3) * TILE + row_off;
-        const char* sO = smem + 3 * TILE + (t % 3) * TILE + row_off;
-        const float* sL = (const float*)(smem + 6 * TILE + (t % 3) * 256);
-        const float* sDl = (const float*)(smem + 6 * TILE + 3 * 256 + (t % 3) * 256);
+        const char* sQ = smem + (t & 3) * TILE + row_off;
+        const char* sO = smem + 4 * TILE + (t % 3) * TILE + row_off;
+        const float* sL = (const float*)(smem + 7 * TILE + (t & 3) * 256);
+        const float* sDl = (const float*)(smem + 7 * TILE + 4 * 256 + (t % 3) * 256);
         auto rd = [&](const char* base, int qb, int ks) {
 #ifdef ORV_BW_ABL_NOB128
             bf16x8 z; asm volatile("" : "=v"(z)); return z;
@@ -765,8 +766,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p
         };
         bf16x8 qa0, oa0, qa1, oa1, qb0, ob0, qb1, ob1, o2, o3, g2_, g3_;
         if (t > 0) {
-            const char* sQp = smem + ((t - 1) % 3) * TILE;               // Q' and dO of the previous tile, transposed reads
-            const char* sOp = smem + 3 * TILE + ((t - 1) % 3) * TILE;
+            const char* sQp = smem + ((t - 1) & 3) * TILE;               // Q' and dO of the previous tile, transposed reads
+            const char* sOp = smem + 4 * TILE + ((t - 1) % 3) * TILE;
             o2 = tr_pair(sOp + 2048 + t00, sOp + 2048 + t01); o3 = tr_pair(sOp + 2048 + t10, sOp + 2048 + t11);
             g2_ = tr_pair(sQp + 2048 + t00, sQp + 2048 + t01); g3_ = tr_pair(sQp + 2048 + t10, sQp + 2048 + t11);
         }
@@ -774,8 +775,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p
         stage_q();
         BW_FENCE()
         if (t > 0) {
-            const char* sQp = smem + ((t - 1) % 3) * TILE;
-            const char* sOp = smem + 3 * TILE + ((t - 1) % 3) * TILE;
+            const char* sQp = smem + ((t - 1) & 3) * TILE;
+            const char* sOp = smem + 4 * TILE + ((t - 1) % 3) * TILE;
             // per k-step: dv[0], dv[1] += dO^T[db] P ; dk[0], dk[1] += Q'^T[db] dS   (4 fragments, 4 MFMAs)
             dv[0] = BW_MFMA(o0, pf[0].v, dv[0]); dv[1] = BW_MFMA(o1, pf[0].v, dv[1]);
             dk[0] = BW_MFMA(g0_, dsf[0].v, dk[0]); dk[1] = BW_MFMA(g1_, dsf[0].v, dk[1]);
@@ -859,9 +860,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p
             }
     };
 
-    // prologue: Q'_0 (+ lse_0) by the first half; dO_0, dO_1 (+ delta) by the second half
+    // prologue: tiles 0 and 1 of both operands (Q' + lse by the first half, dO + delta by the second)
     stage(0);
-    if (grp == 1) stage(1);
+    stage(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     BW_BAR()
     const bool act = __builtin_amdgcn_readfirstlane((int)(k0 < p.S)) != 0;
@@ -870,12 +871,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p
         if (act) {
             for (int t = 0; t < nt; ++t) {
                 SEG_T(0)
-                seg_x(t, [&]() { stage(t + 1); });
+                seg_x(t, [&]() {});
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // Q'_{t+1} landed (issued in Y_{t-1} / the prologue)
                 SEG_T(1)
                 BW_BAR()
                 SEG_T(2)
+                stage(t + 2);                                    // Q'_{t+2} -> slot of Q'_{t-2} (last read in the partners' X_{t-1}, two intervals ago)
+                BW_FENCE()
                 seg_y(t);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 SEG_T(3)
                 BW_BAR()
                 SEG_T(4)
@@ -883,9 +886,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p
             seg_x(nt, [&]() {});
         } else {
             for (int t = 0; t < nt; ++t) {
-                stage(t + 1);
-                BW_BAR()
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                BW_BAR()
+                stage(t + 2);
                 BW_BAR()
             }
         }
