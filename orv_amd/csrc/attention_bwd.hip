@@ -441,9 +441,10 @@ __device__ __forceinline__ void store_row16(bf16_t* op, const f32x16 (&acc)[2], 
 
 // ===== pass A, ping-pong: dQ.  X_t = { dQ^T += K_{t-1}^T dS_{t-1}^T (8 MFMAs, transposing reads) ; S_t^T = K_t Q^T - lse,
 // dP_t^T = V_t dO^T - delta (16 MFMAs, ds_read_b128) } ; Y_t = { P = exp2(S), dS = P dP, bf16 pack }.
-// K: three slots (read as tile t and as tile t-1), staged by waves 0-3; V: two slots, staged two tiles ahead by waves 4-7.
+// K: four slots (read as tile t and as tile t-1), staged by waves 0-3; V: two slots, staged by waves 4-7; both two tiles ahead, from the
+// vector segment (an LDS-DMA issue inside the matrix segment cost the first half ~270 ns per tile: profiles/r5_attention_bwd_slots.txt).
 __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(const BwdArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[5 * TILE];          // K slots 0-2 | V slots 0-1
+    __shared__ __attribute__((aligned(16))) char smem[6 * TILE];          // K slots 0-3 | V slots 0-1
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wq = wave & 3;
@@ -477,13 +478,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(const BwdArgs p)
     };
     const bf16_t* const sbase0 = src_of(0, 0);
     const bf16_t* const sbase1 = src_of(1, 0);
-    char* const sdst = smem + (grp == 0 ? 0 : 3 * TILE) + wq * 2048;
+    char* const sdst = smem + (grp == 0 ? 0 : 4 * TILE) + wq * 2048;
     auto stage = [&](int t) {
         if (t >= nt) return;
 #ifdef ORV_BW_ABL_NODMA
         if (t > 1) return;
 #endif
-        char* const d = sdst + (grp == 0 ? t % 3 : t & 1) * TILE;
+        char* const d = sdst + (grp == 0 ? t & 3 : t & 1) * TILE;
         if (__builtin_expect(ragged && t == nt - 1, 0)) {
             glds16_asm(src_of(0, t), d);
             glds16_asm(src_of(1, t), d + 1024);
@@ -510,14 +511,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(const BwdArgs p)
     // they come from is resident since X_{t-1}) and held across the barrier, so X_t opens with MFMAs instead of an LDS round trip
     bf16x8 ga0 = qf[0], ga1 = qf[0], gb0 = qf[0], gb1 = qf[0];
     auto prefetch_g = [&](int t) {                                 // fragments of tile t for the gradient part of X_{t+1}
-        const char* sP = smem + (t % 3) * TILE;
+        const char* sP = smem + (t & 3) * TILE;
         ga0 = tr_pair(sP + t00, sP + t01); ga1 = tr_pair(sP + t10, sP + t11);
         gb0 = tr_pair(sP + 2048 + t00, sP + 2048 + t01); gb1 = tr_pair(sP + 2048 + t10, sP + 2048 + t11);
     };
     auto seg_x = [&](int t, auto stage_k) {
         __builtin_amdgcn_s_setprio(1);
-        const char* sK = smem + (t % 3) * TILE + row_off;
-        const char* sV = smem + 3 * TILE + (t & 1) * TILE + row_off;
+        const char* sK = smem + (t & 3) * TILE + row_off;
+        const char* sV = smem + 4 * TILE + (t & 1) * TILE + row_off;
         auto rd = [&](const char* base, int kb, int ks) {
 #ifdef ORV_BW_ABL_NOB128
             bf16x8 z; asm volatile("" : "=v"(z)); return z;
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(const BwdArgs p)
         stage_k();
         BW_FENCE()
         if (t > 0) {
-            const char* sP = smem + ((t - 1) % 3) * TILE;         // K of the previous tile, transposed reads
+            const char* sP = smem + ((t - 1) & 3) * TILE;         // K of the previous tile, transposed reads
             dq[0] = BW_MFMA(ga0, dsf[0].v, dq[0]); dq[1] = BW_MFMA(ga1, dsf[0].v, dq[1]);
             BW_FENCE()
             ga0 = tr_pair(sP + 4096 + t00, sP + 4096 + t01); ga1 = tr_pair(sP + 4096 + t10, sP + 4096 + t11);
@@ -595,9 +596,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(const BwdArgs p)
             for (int i = 0; i < 4; ++i) dsf[kk].u[i] = pack2bf(sT[kk >> 1][(kk & 1) * 8 + 2 * i], sT[kk >> 1][(kk & 1) * 8 + 2 * i + 1]);
     };
 
-    // prologue: K_0 (first half); V_0 and V_1 (second half)
+    // prologue: tiles 0 and 1 of both operands
     stage(0);
-    if (grp == 1) stage(1);
+    stage(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     BW_BAR()
     const bool act = __builtin_amdgcn_readfirstlane((int)(q0 < p.S)) != 0;
@@ -606,12 +607,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(const BwdArgs p)
         if (act) {
             for (int t = 0; t < nt; ++t) {
                 SEG_T(0)
-                seg_x(t, [&]() { stage(t + 1); });              // K_{t+1} -> slot of K_{t-2} (last read in the partners' X_{t-1})
+                seg_x(t, [&]() {});
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K_{t+1} landed (issued in Y_{t-1} / the prologue)
                 SEG_T(1)
                 BW_BAR()
                 SEG_T(2)
+                stage(t + 2);                                    // K_{t+2} -> slot of K_{t-2} (last read in the partners' X_{t-1}, two intervals ago)
+                BW_FENCE()
                 seg_y(t);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 SEG_T(3)
                 BW_BAR()
                 SEG_T(4)
@@ -619,9 +622,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(const BwdArgs p)
             seg_x(nt, [&]() {});
         } else {
             for (int t = 0; t < nt; ++t) {
-                stage(t + 1);
-                BW_BAR()
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                BW_BAR()
+                stage(t + 2);
                 BW_BAR()
             }
         }
