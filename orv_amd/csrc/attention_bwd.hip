@@ -509,11 +509,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(const BwdArgs p)
 
     // transposing-read fragments of the gradient GEMMs, k-steps 0 and 1: fetched at the top of the vector segment Y_{t-1} (the tile
     // they come from is resident since X_{t-1}) and held across the barrier, so X_t opens with MFMAs instead of an LDS round trip
-    bf16x8 ga0 = qf[0], ga1 = qf[0], gb0 = qf[0], gb1 = qf[0];
+    // ALL four k-steps (32 registers): one wave per SIMD gets one LDS instruction per ~25 clocks whatever its width (profiles/
+    // r5_attention_bwd_slots.txt), so the 16 transposing reads of a tile belong in the vector segment, where this wave's LDS port idles,
+    // and the matrix segment keeps the 16 ds_read_b128 of the score GEMMs only
+    bf16x8 ga0 = qf[0], ga1 = qf[0], gb0 = qf[0], gb1 = qf[0], gc0 = qf[0], gc1 = qf[0], gd0 = qf[0], gd1 = qf[0];
     auto prefetch_g = [&](int t) {                                 // fragments of tile t for the gradient part of X_{t+1}
         const char* sP = smem + (t & 3) * TILE;
         ga0 = tr_pair(sP + t00, sP + t01); ga1 = tr_pair(sP + t10, sP + t11);
         gb0 = tr_pair(sP + 2048 + t00, sP + 2048 + t01); gb1 = tr_pair(sP + 2048 + t10, sP + 2048 + t11);
+        gc0 = tr_pair(sP + 4096 + t00, sP + 4096 + t01); gc1 = tr_pair(sP + 4096 + t10, sP + 4096 + t11);
+        gd0 = tr_pair(sP + 6144 + t00, sP + 6144 + t01); gd1 = tr_pair(sP + 6144 + t10, sP + 6144 + t11);
     };
     auto seg_x = [&](int t, auto stage_k) {
         __builtin_amdgcn_s_setprio(1);
@@ -530,18 +535,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(const BwdArgs p)
         stage_k();
         BW_FENCE()
         if (t > 0) {
-            const char* sP = smem + ((t - 1) & 3) * TILE;         // K of the previous tile, transposed reads
             dq[0] = BW_MFMA(ga0, dsf[0].v, dq[0]); dq[1] = BW_MFMA(ga1, dsf[0].v, dq[1]);
-            BW_FENCE()
-            ga0 = tr_pair(sP + 4096 + t00, sP + 4096 + t01); ga1 = tr_pair(sP + 4096 + t10, sP + 4096 + t11);
-            BW_FENCE()
             dq[0] = BW_MFMA(gb0, dsf[1].v, dq[0]); dq[1] = BW_MFMA(gb1, dsf[1].v, dq[1]);
             BW_FENCE()
-            gb0 = tr_pair(sP + 6144 + t00, sP + 6144 + t01); gb1 = tr_pair(sP + 6144 + t10, sP + 6144 + t11);
             if (t < nt) { kb0 = rd(sK, 0, 2); vb0 = rd(sV, 0, 2); kb1 = rd(sK, 0, 3); vb1 = rd(sV, 0, 3); }
             BW_FENCE()
-            dq[0] = BW_MFMA(ga0, dsf[2].v, dq[0]); dq[1] = BW_MFMA(ga1, dsf[2].v, dq[1]);
-            dq[0] = BW_MFMA(gb0, dsf[3].v, dq[0]); dq[1] = BW_MFMA(gb1, dsf[3].v, dq[1]);
+            dq[0] = BW_MFMA(gc0, dsf[2].v, dq[0]); dq[1] = BW_MFMA(gc1, dsf[2].v, dq[1]);
+            dq[0] = BW_MFMA(gd0, dsf[3].v, dq[0]); dq[1] = BW_MFMA(gd1, dsf[3].v, dq[1]);
             BW_FENCE()
         } else {
             kb0 = rd(sK, 0, 2); vb0 = rd(sV, 0, 2); kb1 = rd(sK, 0, 3); vb1 = rd(sV, 0, 3);
