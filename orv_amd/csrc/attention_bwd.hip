@@ -346,9 +346,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const BwdArgs p) {
 //     are read with ds_read_b64_tr_b16 from the SAME row-major tile the score GEMMs read with ds_read_b128, one tile later
 //     (X_t = { gradient GEMMs of tile t-1 ; score GEMMs of tile t }), so orv_head_transpose and the qT / kT / doT buffers are
 //     gone.  One LDS image is conflict-free for both read kinds (swz below).
-//   * dual-use tiles live two segments longer: three 8-KiB slots (tile t in slot t % 3), staged one tile ahead by the first
-//     half (in its X_t, behind the transposing reads - see attention.hip on hipcc's vmcnt(0) in front of them) and two tiles ahead
-//     by the second half (in its Y_t).
+//   * dual-use tiles live two segments longer.  Round 5: the dual-use operand (K in the dQ pass, Q' in the dK / dV pass) has FOUR 8-KiB slots
+//     (tile t in slot t & 3) and BOTH halves stage tile t + 2 at the top of their vector segment Y_t and wait for tile t + 1 at the end of X_t
+//     (a whole segment after its issue) - an LDS-DMA issued from inside the matrix segment cost that half ~270 ns per tile
+//     (profiles/r5_attention_bwd_slots.txt); the other operand keeps its two (V) / three (dO) slots.
 // ===============================================================================================================
 // One LDS image serves both read kinds without bank conflicts: 16-byte chunk c of tile row r lives in slot c ^ f(r),
 //   f(r) = (bit 1 of r) << 2 | (bits 3..2 of r).
@@ -665,8 +666,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(const BwdArgs p)
 // ===== pass B, ping-pong: dK, dV (one lane = one key row; loop over query tiles).
 // X_t = { dV^T += dO_{t-1}^T P_{t-1}, dK^T += Q'_{t-1}^T dS_{t-1} (16 MFMAs, transposing reads) ; S_t = Q'_t K^T - lse, dP_t = dO_t V^T - delta
 // (16 MFMAs, ds_read_b128; -lse / -delta of the tile's 64 query rows enter through the accumulator init, from LDS) } ;
-// Y_t = { P = exp2(S), dS = P dP, bf16 pack of both }.  Q' and dO tiles: three slots each; waves 0-3 stage Q' (+ the lse
-// vector) one tile ahead, waves 4-7 dO (+ the delta vector) two tiles ahead.
+// Y_t = { P = exp2(S), dS = P dP, bf16 pack of both }.  Q' tiles (+ the lse vector): four slots, staged by waves 0-3; dO tiles (+ the delta
+// vector): three slots, staged by waves 4-7; both two tiles ahead, from the vector segment.
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[7 * TILE + 7 * 256];   // Q' slots 0-3 | dO slots 0-2 | lse x4 | delta x3
     const int tid = threadIdx.x, lane = tid & 63;
