@@ -937,14 +937,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p
 #undef BW_FENCE
 #undef BW_MFMA
 
-// sums over the 8 lanes of a row group (lane ^ 1, ^ 2, ^ 4) and over the 8 row groups of a wave (lane ^ 8, ^ 16, ^ 32) on the VALU alone (DPP +
-// the gfx950 half-swaps): the __shfl_xor forms are ds_bpermute round trips through the LDS crossbar, ~100 cycles each and dependent
-__device__ __forceinline__ float sum8(float v) {
-    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
-    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
-    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x141, 0xF, 0xF, true));    // row_half_mirror (quads are uniform)
-    return v;
-}
+// sum over the 8 row groups of a wave (lane ^ 8, ^ 16, ^ 32) on the VALU alone; the 8-lane sum is orv_sum8 (common.hpp)
 __device__ __forceinline__ float sum_rows8(float v) {
     v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x128, 0xF, 0xF, true));    // row_ror:8 = lane ^ 8
     { const unsigned u = __float_as_uint(v); const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false); v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
@@ -994,12 +987,12 @@ __global__ __launch_bounds__(256) void qkv_prep_bwd_kernel(const bf16_t* __restr
                     dz[e + 1] = c2 * cp[e + 1] - a * sp[e];
                 }
             }
-            sum = sum8(sum);
+            sum = orv_sum8(sum);
             const float mean = sum * (1.f / 64.f);
             float sq = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { x[e] -= mean; sq += x[e] * x[e]; }
-            sq = sum8(sq);
+            sq = orv_sum8(sq);
             const float rstd = rsqrtf(sq * (1.f / 64.f) + eps);
             float m1 = 0.f, m2 = 0.f;
 #pragma unroll
@@ -1011,7 +1004,7 @@ __global__ __launch_bounds__(256) void qkv_prep_bwd_kernel(const bf16_t* __restr
                 m1 += dz[e];
                 m2 += dz[e] * x[e];
             }
-            m1 = sum8(m1); m2 = sum8(m2);
+            m1 = orv_sum8(m1); m2 = orv_sum8(m2);
             m1 *= (1.f / 64.f); m2 *= (1.f / 64.f);
             if (ok) {
                 float o[8];

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const LnBwdArgs p) {
 #define ORV_BLOCK_SUM(PH, SLOT, V)                                                                   \
         {                                                                                            \
             _Pragma("unroll") for (int k = 0; k < LNB_R; ++k) {                                      \
-                const float w_ = wave_sum(V[k]);                                                     \
+                const float w_ = wave_sum_valu(V[k]);                                                     \
                 if (lane == 0) red[PH][SLOT][k][wave] = w_;                                          \
             }                                                                                        \
         }

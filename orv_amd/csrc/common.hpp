@@ -85,6 +85,14 @@ __device__ __forceinline__ float wave_sum_valu(float v) {
     { const unsigned u = __float_as_uint(v); const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false); v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
     return v;
 }
+// sum over the 8 lanes of an aligned group (lane ^ 1, ^ 2, ^ 4) on the VALU alone (DPP): the __shfl_xor form is three dependent ds_bpermute
+// round trips through the LDS crossbar, ~100 cycles each
+__device__ __forceinline__ float orv_sum8(float v) {
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x141, 0xF, 0xF, true));    // row_half_mirror (quads are uniform)
+    return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -149,12 +149,12 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(const bf16_t* src, bf16_t
                 v[2 * e + 1] = bf2f(w[e] >> 16);
                 sum += v[2 * e] + v[2 * e + 1];
             }
-            sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+            sum = orv_sum8(sum);
             const float mean = sum * (1.f / 64.f);
             float sq = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { v[e] -= mean; sq += v[e] * v[e]; }
-            sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+            sq = orv_sum8(sq);
             const float rstd = rsqrtf(sq * (1.f / 64.f) + eps);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = v[e] * rstd * gam[e] + bet[e];
