@@ -523,25 +523,32 @@ __global__ __launch_bounds__(256) void mod_bwd_wgrad_kernel(const ModBwdArgs p) 
 
 // input gradient: block = (64-wide k slice, tab, half); 256 threads = 64 k x 4 n-phases; the dtab slab of 128 n x rows is
 // staged in LDS as [n][32 rows]; every thread streams its W column once (128-byte rows across the 64 k lanes).
-__global__ __launch_bounds__(256) void mod_bwd_dgrad_kernel(const ModBwdArgs p) {
-    __shared__ __attribute__((aligned(16))) float dys[128][32];
-    __shared__ float red[3][32][64];
+// d cond[row, k] += sum_n dtab[row, n] W[n, k] over one quarter of the table's rows n.  thread -> FOUR consecutive k (one 8-byte load per weight
+// row; with one bf16 per load the whole grid had ~1 MB in flight and streamed the 354 MB of weights at 0.5 TB/s: 600 us per launch), 64 threads
+// cover 256 k, the four waves split the n rows (mod 4) and are summed through LDS; grid = (E / 256 x 4 n-quarters, tables, halves).
+// RM = rows per pass (accumulators per thread and k): 32, or 8 when the half has at most 8 rows (the text half: B rows).
+template <int RM>
+__device__ __forceinline__ void mod_bwd_dgrad_body(const ModBwdArgs& p, float (*dys)[32], float (*red)[32][64]) {
     const int tab = blockIdx.y, half = blockIdx.z;          // half 0 = video rows, 1 = text rows
     const int E = p.E, G = 1 + p.T;
     const int rows = half ? p.B : p.B * p.T;
-    const int kk = threadIdx.x & 63, ph = threadIdx.x >> 6, k = blockIdx.x * 64 + kk;
+    const int kblocks = (E + 255) / 256;
+    const int kb = blockIdx.x % kblocks, nq = blockIdx.x / kblocks;
+    const int kk = threadIdx.x & 63, ph = threadIdx.x >> 6, k = kb * 256 + kk * 4;
+    const int nchunk = ((p.width + 3) / 4 + 127) / 128 * 128;                 // rows n of this quarter: [nlo, nhi), a multiple of the 128-row tile
+    const int nlo = nq * nchunk, nhi = min(p.width, nlo + nchunk);
     const bf16_t* W = p.W[tab] + (long)(half ? p.width : 0) * E;
-    for (int r0 = 0; r0 < rows; r0 += 32) {                 // 32 rows per pass (one pass up to B*T = 32; W is re-streamed beyond)
-        const int rr = min(32, rows - r0);
-        float acc[32];
+    for (int r0 = 0; r0 < rows; r0 += RM) {                 // RM rows per pass (one pass up to B*T = 32; W is re-streamed beyond)
+        const int rr = min(RM, rows - r0);
+        float acc[RM][4];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) acc[j] = 0.f;
-        for (int n0 = 0; n0 < p.width; n0 += 128) {
+        for (int j = 0; j < RM; ++j) { acc[j][0] = 0.f; acc[j][1] = 0.f; acc[j][2] = 0.f; acc[j][3] = 0.f; }
+        for (int n0 = nlo; n0 < nhi; n0 += 128) {
             __syncthreads();
-            for (int i = threadIdx.x; i < 128 * 32; i += 256) {
+            for (int i = threadIdx.x; i < 128 * RM; i += 256) {
                 const int r = i >> 7, nl = i & 127;          // consecutive threads -> consecutive n (coalesced dtab rows)
                 float d = 0.f;
-                if (r < rr && n0 + nl < p.width) {
+                if (r < rr && n0 + nl < nhi) {
                     const int row = r0 + r;
                     const int b = half ? row : row / p.T, g = half ? 0 : 1 + row % p.T;
                     d = p.dtab[(((long)tab * p.B + b) * G + g) * p.width + n0 + nl];
@@ -550,44 +557,58 @@ __global__ __launch_bounds__(256) void mod_bwd_dgrad_kernel(const ModBwdArgs p) 
             }
             __syncthreads();
             if (k < E) {
-                const int nend = min(128, p.width - n0);
-                // eight weight loads in flight per thread (rows nl, nl + 4, ... of this k column; rows past the tile end re-read its last
-                // row with weight 0): one load per iteration made the loop one dependent L2 round trip per 32 FMAs (0.76 ms per launch);
-                // the accumulation order is unchanged
+                const int nend = min(128, nhi - n0);
+                // eight weight loads in flight per thread (rows nl, nl + 4, ... ; rows past the tile end re-read its last row with weight 0)
                 for (int nl0 = ph; nl0 < nend; nl0 += 32) {
-                    float w8[8];
+                    float w8[8][4];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int nl = nl0 + 4 * u;
-                        const float wv = bf2f(W[(long)(n0 + min(nl, nend - 1)) * E + k]);
-                        w8[u] = nl < nend ? wv : 0.f;
+                        const uint2 wv = *(const uint2*)(W + (long)(n0 + min(nl, nend - 1)) * E + k);
+                        const bool on = nl < nend;
+                        w8[u][0] = on ? bf2f(wv.x & 0xffff) : 0.f; w8[u][1] = on ? bf2f(wv.x >> 16) : 0.f;
+                        w8[u][2] = on ? bf2f(wv.y & 0xffff) : 0.f; w8[u][3] = on ? bf2f(wv.y >> 16) : 0.f;
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int nl = min(nl0 + 4 * u, 127);
-                        const float w = w8[u];
 #pragma unroll
-                        for (int j = 0; j < 32; j += 4) {
+                        for (int j = 0; j < RM; j += 4) {
                             const float4 d4 = *(const float4*)&dys[nl][j];
-                            acc[j] = fmaf(d4.x, w, acc[j]); acc[j + 1] = fmaf(d4.y, w, acc[j + 1]);
-                            acc[j + 2] = fmaf(d4.z, w, acc[j + 2]); acc[j + 3] = fmaf(d4.w, w, acc[j + 3]);
+                            const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) acc[j + jj][c] = fmaf(dd[jj], w8[u][c], acc[j + jj][c]);
                         }
                     }
                 }
             }
         }
-        __syncthreads();
-        if (ph > 0)
+        // sum of the four waves (they took the n rows mod 4), one 4-column group at a time through LDS
+        float* dx = half ? p.d_cond_t : p.d_cond_v;
 #pragma unroll
-            for (int j = 0; j < 32; ++j) red[ph - 1][j][kk] = acc[j];
-        __syncthreads();
-        if (ph == 0 && k < E) {
-            float* dx = half ? p.d_cond_t : p.d_cond_v;
+        for (int c = 0; c < 4; ++c) {
+            __syncthreads();
+            if (ph > 0)
 #pragma unroll
-            for (int j = 0; j < 32; ++j)
-                if (j < rr) atomicAdd(dx + (long)(r0 + j) * E + k, acc[j] + red[0][j][kk] + red[1][j][kk] + red[2][j][kk]);
+                for (int j = 0; j < RM; ++j) red[ph - 1][j][kk] = acc[j][c];
+            __syncthreads();
+            if (ph == 0 && k + c < E)
+#pragma unroll
+                for (int j = 0; j < RM; ++j)
+                    if (j < rr) atomicAdd(dx + (long)(r0 + j) * E + k + c, acc[j][c] + red[0][j][kk] + red[1][j][kk] + red[2][j][kk]);
         }
     }
+}
+__global__ __launch_bounds__(256) void mod_bwd_dgrad_kernel(const ModBwdArgs p) {
+    __shared__ __attribute__((aligned(16))) float dys[128][32];
+    __shared__ float red[3][32][64];
+    const int rows = blockIdx.z ? p.B : p.B * p.T;          // uniform over the workgroup
+    if (rows <= 8) mod_bwd_dgrad_body<8>(p, dys, red);
+    else if (rows <= 16) mod_bwd_dgrad_body<16>(p, dys, red);
+    else if (rows <= 24) mod_bwd_dgrad_body<24>(p, dys, red);           // B T = 20 at the training shape
+    else mod_bwd_dgrad_body<32>(p, dys, red);
 }
 
 // ---- fused AdamW on bf16 parameters / bf16 gradients with fp32 moments (torch.optim.AdamW semantics, decoupled decay):
@@ -812,7 +833,7 @@ extern "C" int orv_modulation_tables_bwd(const float* dtab, const void* cond_v, 
     hipStream_t st = (hipStream_t)stream;
     const long per_tab = (long)width * (1 + a.text) * (E / 8);
     hipLaunchKernelGGL(mod_bwd_wgrad_kernel, dim3((unsigned)((per_tab + 255) / 256), n_tab), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(mod_bwd_dgrad_kernel, dim3(E / 64, n_tab, 1 + a.text), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(mod_bwd_dgrad_kernel, dim3(((E + 255) / 256) * 4, n_tab, 1 + a.text), dim3(256), 0, st, a);
     return orv_check_launch("orv_modulation_tables_bwd");
 }
 
