@@ -887,6 +887,14 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
 _FUSE_QKNORM = os.environ.get("ORV_FUSED_QKNORM", "1") != "0"      # A/B switch: 0 = projection + orv_qkv_prep
 
 
+def _chains() -> int:
+    """ORV_CHAINS=n (default 1): GraphedTransformer cuts a batch into n chains on n streams (see ``GraphedTransformer._forward``)."""
+    try:
+        return max(1, int(os.environ.get("ORV_CHAINS", "1")))
+    except ValueError:
+        return 1
+
+
 _PACKED_QKV_DEFAULT, _PACKED_FFN1_DEFAULT = "0", "0"
 
 
@@ -976,17 +984,107 @@ class GraphedTransformer:
             self._pepoch = _state.param_epoch[0]
         return (len(ps), sum(p._version for p in ps), hash(tuple(p.data_ptr() for p in ps)), hash(tuple(map(id, ps))))
 
+    # ---- batch chains (experiment, ORV_CHAINS=n): the clips of a batch are independent until the sampler's update, so the batch can be cut
+    # into n chains that run the SAME forward on n streams inside the captured graph.  Every kernel of the path is persistent / fills the
+    # chip on its own, so two chains do not co-run in steady state - but the ramp and the tail of every launch (first loads of a cold
+    # pipeline, the last tile's epilogue, a last round that does not fill its slots) overlap with the neighbouring launch of the other
+    # chain instead of leaving the CUs idle behind the in-order barrier of a single stream.  Results are bit-identical to the uncut call
+    # (every kernel is deterministic and batch independent); the action-mask draw is made ONCE for the whole batch, before the fork, so the
+    # global RNG stream advances exactly as in the uncut call.
+    def _chain_parts(self, kw, n):
+        hs = kw["hidden_states"]
+        B = hs.shape[0]
+        if n <= 1 or B % n or B < n:
+            return None
+        b = B // n
+
+        def cut(v, i):
+            return v[i * b:(i + 1) * b] if (torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B) else v
+        parts = []
+        for i in range(n):
+            d = {}
+            for k, v in kw.items():
+                if k in ("hidden_states", "encoder_hidden_states", "timestep"):
+                    d[k] = cut(v, i)
+                elif k == "controls_or_guidances" and isinstance(v, dict):
+                    d[k] = {kk: cut(vv, i) for kk, vv in v.items()}
+                else:
+                    d[k] = v
+            parts.append(d)
+        return parts
+
+    def _forward(self, kw, st, concurrent):
+        """``self.tr(**kw)``, cut into ``ORV_CHAINS`` batch chains when that is enabled and the batch divides; ``concurrent``: the chains
+        run on side streams (inside a capture), else one after the other on the current stream (the eager warm-up call)."""
+        n = _chains()
+        parts = self._chain_parts(kw, n) if n > 1 else None
+        if parts is None:
+            out = self.tr(**kw)
+            st["ws"] = self.tr._ws
+            return out
+        tr = self.tr
+        B = kw["hidden_states"].shape[0]
+        b = B // n
+        dev = kw["hidden_states"].device
+        ae = getattr(tr, "action_embed", None)
+        ctl = kw.get("controls_or_guidances") or {}
+        full_mask = saved_mask = None
+        if ae is not None and ctl.get("actions", None) is not None:
+            saved_mask = ae.forced_mask
+            if saved_mask is not None:
+                if saved_mask.device != dev or saved_mask.dtype != torch.bool:      # once, like ActionEmbed.forward: no H2D copy per call
+                    saved_mask = ae.forced_mask = saved_mask.to(device=dev, dtype=torch.bool)
+                full_mask = saved_mask
+            else:
+                full_mask = torch.rand(B, device=dev) < 0.1          # the draw ActionEmbed.forward would make for the whole batch
+        chain_ws = st.setdefault("chain_ws", [dict() for _ in range(n)])
+        saved_ws = tr._ws
+        cur = torch.cuda.current_stream(dev)
+        side = []
+        if concurrent:
+            side = getattr(self, "_side", None)
+            if side is None or len(side) < n - 1 or side[0].device != dev:
+                side = self._side = [torch.cuda.Stream(device=dev) for _ in range(n - 1)]
+            fork = torch.cuda.Event()
+            fork.record(cur)
+        outs = []
+        try:
+            for i, pkw in enumerate(parts):
+                tr._ws = chain_ws[i]
+                if full_mask is not None:
+                    ae.forced_mask = full_mask[i * b:(i + 1) * b]
+                if concurrent and i:
+                    side[i - 1].wait_event(fork)
+                    with torch.cuda.stream(side[i - 1]):
+                        outs.append(tr(**pkw))
+                else:
+                    outs.append(tr(**pkw))
+                chain_ws[i] = tr._ws
+        finally:
+            tr._ws = saved_ws
+            if full_mask is not None:
+                ae.forced_mask = saved_mask
+        if concurrent:
+            for s in side[:n - 1]:
+                cur.wait_stream(s)
+        st["ws"] = chain_ws
+        cat = lambda j: (None if outs[0][j] is None else torch.cat([o[j] for o in outs], dim=0))
+        sample, mask, recon = cat(0), cat(1), cat(2)
+        if isinstance(outs[0], tuple):
+            return (sample, mask, recon) if len(outs[0]) == 3 else (sample,) + tuple(outs[0][1:])
+        return Transformer3DModelTrajOutput(sample=sample, is_action_mask=mask, actions_recon=recon)
+
     def __call__(self, hidden_states, encoder_hidden_states, timestep, **kw):
         kw = dict(kw, hidden_states=hidden_states, encoder_hidden_states=encoder_hidden_states, timestep=timestep)
         leaves, desc = self._flatten(kw)
-        key = (desc, _state.weights_epoch[0], self._weights_version(), self.tr.training)
+        key = (desc, _state.weights_epoch[0], self._weights_version(), self.tr.training, _chains())
         st = self._state.get(key)
         if st is None:                       # eager warm-up call
-            self._state[key] = {"calls": 1}
+            st = self._state[key] = {"calls": 1}
             while len(self._state) > self.max_entries:
                 self._state.popitem(last=False)
             with torch.no_grad():
-                return self.tr(**kw)
+                return self._forward(kw, st, concurrent=False)
         self._state.move_to_end(key)
         if "graph" not in st:
             st["static"] = [t.clone() for t in leaves]
@@ -994,10 +1092,8 @@ class GraphedTransformer:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.no_grad(), torch.cuda.graph(g):
-                st["out"] = self.tr(**skw)
-            st["graph"] = g
-            st["ws"] = self.tr._ws      # the captured launches point into this workspace: keep it alive even if the model
-            #                             later swaps in another one for a different shape
+                st["out"] = self._forward(skw, st, concurrent=True)      # st["ws"]: the captured launches point into these workspaces -
+            st["graph"] = g                                              # kept alive even if the model later swaps in another one
         else:
             for dst, src in zip(st["static"], leaves):
                 if dst.data_ptr() != src.data_ptr():

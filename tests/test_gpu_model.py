@@ -234,6 +234,42 @@ def test_hip_graph_replay_is_bit_identical():
     assert torch.equal(res[0], res[1])
 
 
+@pytest.mark.parametrize("forced", [True, False])
+def test_batch_chains_in_the_graph_are_bit_identical(monkeypatch, forced):
+    """ORV_CHAINS=2: the batch cut into two chains on two streams inside the captured graph gives exactly the latents of the
+    uncut eager call; with the mask left to the RNG (``forced`` False) the draw is made once for the whole batch, so the same
+    seed gives the same masks - and the same latents - as the uncut call."""
+    from orv_amd import schedulers
+    from orv_amd.cogvideox_control import CogVideoXImageToVideoPipelineTraj
+    dev = torch.device("cuda:0")
+    cfg, extra, ins, w, outs = load_golden("pipe_ddim")
+    m = build(cfg, w, dev)
+    b0 = ins["image"].shape[0]
+    rep = 2 if b0 % 2 else 1                                  # an even batch
+    b = b0 * rep
+    m.action_embed.forced_mask = torch.tensor([False, True] * (b // 2)) if forced else None
+    m.action_embed.mask = True                                # the mask is applied: the draw matters
+    g = torch.Generator().manual_seed(11)
+    image_lat = torch.randn(b, 16, 1, 8, 12, generator=g).to(dev, BF)
+    lat0 = torch.randn(b, 3, 16, 8, 12, generator=g).to(dev, BF)
+    prompt = ins["prompt_embeds"].repeat(rep, 1, 1).to(dev, BF)
+    actions = torch.cat([ins["actions"] * (1 + 0.5 * i) for i in range(rep)], dim=0).to(dev)
+    res = []
+    # forced masks: uncut EAGER vs chained graph; RNG masks: uncut graph vs chained graph (the same capture-time RNG bookkeeping on both sides)
+    for chains, graph in (("1", not forced), ("2", True)):
+        monkeypatch.setenv("ORV_CHAINS", chains)
+        torch.manual_seed(1234)
+        sched = schedulers.CogVideoXDDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012,
+                                                  beta_schedule="scaled_linear", prediction_type="v_prediction",
+                                                  rescale_betas_zero_snr=True, snr_shift_scale=3.0, timestep_spacing="trailing")
+        pipe = CogVideoXImageToVideoPipelineTraj(transformer=m, scheduler=sched).enable_hip_graph(graph)
+        out = pipe(image=image_lat, height=64, width=96, num_frames=9, num_inference_steps=5, guidance_scale=1.0,
+                   latents=lat0.clone(), prompt_embeds=prompt, output_type="latent", controls_or_guidances={"actions": actions})
+        res.append(out.frames.clone())
+    assert torch.isfinite(res[0].float()).all()
+    assert torch.equal(res[0], res[1])
+
+
 def test_hip_graph_second_call_with_other_controls_and_weights():
     """A second pipeline call with DIFFERENT actions / prompt tensors (fresh allocations) and a call after an in-place
     weight change must not replay stale pointers: graphed == eager every time, and the graph cache stays bounded."""
