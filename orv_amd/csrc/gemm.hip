@@ -1274,6 +1274,15 @@ struct GemmCand { int ring, bm, bn; float rate; int min_rounds; };
 #define ORV_D8_RATE_128 1.20f
 #endif
 #define D8_RATE_128 ORV_D8_RATE_128
+// relative rates of the 192-row t8 tiles (gemm_t8r192_kernel): a tile does 3 / 4 of the MFMAs of its 256-row sibling on 7 / 8 of the LDS-DMA bytes
+#ifndef ORV_T8R192_RATE_256
+#define ORV_T8R192_RATE_256 1.20f
+#endif
+#ifndef ORV_T8R192_RATE_192
+#define ORV_T8R192_RATE_192 1.12f
+#endif
+#define T8R192_RATE_256 ORV_T8R192_RATE_256
+#define T8R192_RATE_192 ORV_T8R192_RATE_192
 // C[M, N] (+)= A[K, M]^T . W[K, N]: the TN form of gemm_t8.hip (weight gradients: A = dY [tokens, out], W = X [tokens, in]; reference:
 // torch autograd of nn.Linear inside accelerator.backward, train_cogvideox_control_to_video_sft.py:1093).  bf16 in, fp32 accumulate, bf16 out;
 // accumulate != 0: C += the product (gradient accumulation).  N % 192 == 0 or N % 256 == 0, M % 8 == 0; any K (rows past K are zeros).
@@ -1322,6 +1331,9 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
     static const GemmCand cands[] = {
         // ring = 3: the 16x16x32 8-phase kernel of gemm_t8.hip (persistent, BK = 64; needs an even number of K-tiles)
         {3, 256, 256, 1.29f, 0}, {3, 256, 192, 1.21f, 0},
+        // the same kernel on 192-row tiles (gemm_t8r192_kernel, round 5): M = 3226 (one clip) is 17 row tiles, M = 6452 is 34 - 510 / 255 / 170 tiles
+        // for N = 7680 / 3840 / 1920 where 256 rows give 390 / 195 / 130; at M = 12904 the 256-row tiles stay cheaper (rates: T8R192_RATE_*)
+        {3, 192, 256, T8R192_RATE_256, 0}, {3, 192, 192, T8R192_RATE_192, 0},
         // ring = 4: four-wave 256 x 256 experiment of gemm_t8.hip - forced only (rate 0.01 never wins)
         {4, 256, 256, 0.01f, 0},
         // ring = 5: gemm_d8.hip (round 5) - A straight to registers two K-tiles ahead, W through four LDS buffers; needs K % 192 == 0
@@ -1347,6 +1359,8 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
     if (no_phased < 0) { const char* e = getenv("ORV_GEMM_PHASED"); no_phased = (e && atoi(e) == 0) ? 1 : 0; }
     static int no_t8 = -1;       // ORV_GEMM_T8=0: A/B switch for the t8 kernel
     if (no_t8 < 0) { const char* e = getenv("ORV_GEMM_T8"); no_t8 = (e && atoi(e) == 0) ? 1 : 0; }
+    static int no_r192 = -1;     // ORV_GEMM_R192=0: A/B switch for the 192-row t8 tiles
+    if (no_r192 < 0) { const char* e = getenv("ORV_GEMM_R192"); no_r192 = (e && atoi(e) == 0) ? 1 : 0; }
     static int no_d8 = -1;       // ORV_GEMM_D8=0: A/B switch for the d8 kernel
     if (no_d8 < 0) { const char* e = getenv("ORV_GEMM_D8"); no_d8 = (e && atoi(e) == 0) ? 1 : 0; }
     static int no384 = -1;   // ORV_GEMM_BN384=0: A/B switch for the 384-wide variant
@@ -1358,6 +1372,9 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
         if (N % c.bn) continue;
         if (c.ring == 2 && (K % 128 != 0 || no_phased)) continue;
         if (c.ring == 3 && (K % 128 != 0 || no_t8 || wide || (epilogue == 4 && c.bn != 256))) continue;
+        if (c.ring == 3 && c.bm == 192 && (no_r192 || epilogue == 3)) continue;
+        // packed C has orv_packed_rows(M) = ceil(M / 256) * 256 row slots and the packed store is not masked: the 192-row tiling must fit them
+        if (c.ring == 3 && c.bm == 192 && cpacked && (long)((M + 191) / 192) * 192 > (long)((M + 255) / 256) * 256) continue;
         if (c.ring == 4 && (K % 128 != 0 || wide || epilogue > 2 || force_ring != 4)) continue;
         // ring 5 reads A in the packed P16 layout and nothing else does: the caller's a_packed decides the family
         if ((c.ring == 5) != packed) continue;
@@ -1365,7 +1382,7 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
         if (cpacked && !packed && !(c.ring == 3 && c.bn == 256 && epilogue == 1)) continue;
         if (c.ring == 5 && (K % 192 != 0 || no_d8)) continue;
         // epilogue 4 normalises whole 64-wide heads inside a wave (BN / 2 columns) that must not straddle q | k | v
-        if (epilogue == 4 && c.ring != 5 && (c.bm == 192 || (c.bn / 2) % 64 != 0 || (heads * 64) % (c.bn / 2) != 0)) continue;
+        if (epilogue == 4 && c.ring != 5 && ((c.bm == 192 && c.ring != 3) || (c.bn / 2) % 64 != 0 || (heads * 64) % (c.bn / 2) != 0)) continue;
         if (force_bm && (c.ring != force_ring || c.bm != force_bm || c.bn != force_bn)) continue;
         if (!force_bm && force_ring == 0 && c.ring) continue;
         const long tiles = (long)((M + c.bm - 1) / c.bm) * (N / c.bn);
@@ -1405,7 +1422,8 @@ static bool plan_gemm(int M, int N, int K, int epilogue, int heads, const GemmCa
     return first != nullptr;
 }
 static void cand_name(const GemmCand* c, int epilogue, char* buf, int len) {
-    if (c->ring == 3) snprintf(buf, len, "gemm_t8_kernel<%d, %d>", c->bn, epilogue);
+    if (c->ring == 3 && c->bm == 192) snprintf(buf, len, "gemm_t8r192_kernel<%d, %d>", c->bn, epilogue);
+    else if (c->ring == 3) snprintf(buf, len, "gemm_t8_kernel<%d, %d>", c->bn, epilogue);
     else if (c->ring == 5) snprintf(buf, len, "gemm_d8_kernel<%d, %d>", c->bn, epilogue);
     else if (c->ring == 2) snprintf(buf, len, "gemm_ph_kernel<%d, %d>", c->bn, epilogue);
     else if (c->ring) snprintf(buf, len, "gemm_pp_kernel<%d, %d, %d>", c->bn, c->bn == 384 ? 4 : 5, epilogue);
@@ -1445,7 +1463,7 @@ static int gemm_dispatch(GemmArgs a, const GemmCand* best, int epilogue, hipStre
         if (gm_env < 0) { const char* e = getenv("ORV_GEMM_GM"); gm_env = e ? atoi(e) : 0; }
         a.gm = gm_env > 0 ? gm_env : (a.K >= 4096 && a.tiles_n <= 16 ? 8 : 0);
     }
-    if (best->ring == 3) return launch_t8(a, best->bn, epilogue, st);
+    if (best->ring == 3) return launch_t8(a, best->bn, epilogue, st, best->bm);
     if (best->ring == 4) return launch_t4(a, epilogue, st);
     if (best->ring == 5) return launch_d8(a, best->bn, epilogue, st);
     if (best->ring == 2) {

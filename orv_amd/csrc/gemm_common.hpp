@@ -67,8 +67,9 @@ __device__ __forceinline__ void tile_of_index(const GemmArgs& p, int b, int nb, 
 __device__ __forceinline__ void tile_of_block(const GemmArgs& p, int& tm, int& tn) { tile_of_index(p, blockIdx.x, gridDim.x, tm, tn); }
 
 
-// gemm_t8.hip: launches gemm_t8_kernel<BN, EPI> (BN = 256 or 192); a.tiles_m / a.tiles_n must be set for BM = 256, BN
-int launch_t8(const GemmArgs& a, int bn, int epi, hipStream_t st);
+// gemm_t8.hip: launches gemm_t8_kernel<BN, EPI> (bm = 256) or gemm_t8r192_kernel<BN, EPI> (bm = 192), BN = 256 or 192; a.tiles_m / a.tiles_n
+// must be set for bm, BN
+int launch_t8(const GemmArgs& a, int bn, int epi, hipStream_t st, int bm = 256);
 // gemm_t8.hip: TN form C[M, N] (+)= A[K, M]^T . W[K, N] (both operands row-major over the contraction index), BN = 256 or 192
 int launch_t8_tn(const GemmArgs& a, int bn, int accumulate, hipStream_t st);
 // gemm_t8.hip: the four-wave 256 x 256 experiment (ORV_GEMM_TILE=4,256,256)

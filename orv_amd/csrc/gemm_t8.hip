@@ -51,8 +51,8 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
 //   BN = 256: block blk = 2 P + t (pair P = 0, 1):  column 32 P + 8 g + 4 t + e      -> 8-column pieces at 32 P + 8 g
 //   BN = 192: blocks 0, 1 (pair 0):                 column 8 g + 4 blk + e           -> one 8-column piece at 8 g
 //             block 2:                              column 32 + 4 g + e              -> one 4-column piece
-template <int BN, int EPI>
-__device__ __forceinline__ void t8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][4][BN / 64], const int mbase, const int nbase, const int lane) {
+template <int BN, int EPI, int MB = 4>      // MB: 16-row blocks per m half of a wave (4: 256-row tiles, 3: 192-row tiles)
+__device__ __forceinline__ void t8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][MB][BN / 64], const int mbase, const int nbase, const int lane) {
     constexpr int NP = BN == 256 ? 2 : 1;            // 8-column pieces per row
     constexpr bool TAIL = BN == 192;                 // plus one 4-column piece
     const int g = lane >> 4, r16 = lane & 15;
@@ -103,8 +103,8 @@ __device__ __forceinline__ void t8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][4
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const int m = mbase + mh * 64 + mb * 16 + r16;
+            for (int mb = 0; mb < MB; ++mb) {
+                const int m = mbase + mh * (16 * MB) + mb * 16 + r16;
                 const bool valid = m < p.M;              // the four lanes of a row agree
                 const long orow = min(m, p.M - 1);
                 float v[NP][8];
@@ -151,13 +151,13 @@ __device__ __forceinline__ void t8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][4
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh) {
             // row operands of the four 16-row blocks of this half are requested together
-            long orow[4], rr[4];
-            bool valid[4];
-            uint4 r8[4][NP];
-            uint2 r4[4];
+            long orow[MB], rr[MB];
+            bool valid[MB];
+            uint4 r8[MB][NP];
+            uint2 r4[MB];
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const int m = mbase + mh * 64 + mb * 16 + r16;
+            for (int mb = 0; mb < MB; ++mb) {
+                const int m = mbase + mh * (16 * MB) + mb * 16 + r16;
                 valid[mb] = m < p.M;
                 const int mc = min(m, p.M - 1);
                 orow[mb] = mc;
@@ -170,11 +170,11 @@ __device__ __forceinline__ void t8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][4
                 }
             }
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
+            for (int mb = 0; mb < MB; ++mb) {
                 bool g_lane = false;             // block straddles a frame / text boundary: per-lane gate rows
                 const float* grow = nullptr;
                 if (EPI == 2 && p.gate) {
-                    const int mf = __builtin_amdgcn_readfirstlane(mbase + mh * 64 + mb * 16), ml = min(mf + 15, p.M - 1);
+                    const int mf = __builtin_amdgcn_readfirstlane(mbase + mh * (16 * MB) + mb * 16), ml = min(mf + 15, p.M - 1);
                     long of = min(mf, p.M - 1), ol = ml;
                     if (p.c_rows > 0) {
                         of = (long)(of / p.c_rows) * p.c_bstride + p.c_off + of % p.c_rows;
@@ -235,7 +235,7 @@ __device__ __forceinline__ void t8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][4
                         // packed P16 output (orv_gemm_t.c_packed: the hidden state of FeedForward, cogvideox_control.py:439 -> :440, as the A
                         // operand of gemm_d8): lane (r16, g) holds columns 32 P + 8 g + (0..7) of row r16 = slot 16 g + r16 of packed block
                         // (row block, column block) - one lane-linear, contiguous 1-KiB store; the buffer has tiles_m * 256 row slots (no mask)
-                        if (st_ok) *(uint4*)((char*)p.C + ((((long)((mbase + mh * 64 + mb * 16) >> 4)) * (p.ldc >> 5) + ((nbase + 32 * P) >> 5)) << 10) + lane * 16) = pack8(v);
+                        if (st_ok) *(uint4*)((char*)p.C + ((((long)((mbase + mh * (16 * MB) + mb * 16) >> 4)) * (p.ldc >> 5) + ((nbase + 32 * P) >> 5)) << 10) + lane * 16) = pack8(v);
                     } else
                     if (valid[mb] && st_ok) *(uint4*)(crow + col8[P]) = pack8(v);
                 }
@@ -287,8 +287,8 @@ __device__ __forceinline__ float sum8(float v) {             // sum over the 8 l
     return v;
 }
 
-template <int BN, int EPI>
-__device__ __forceinline__ void t8_epilogue_lds(const GemmArgs& p, f32x4 (&acc)[2][4][BN / 64], const int mbase, const int nbase, const int lane,
+template <int BN, int EPI, int MB = 4>
+__device__ __forceinline__ void t8_epilogue_lds(const GemmArgs& p, f32x4 (&acc)[2][MB][BN / 64], const int mbase, const int nbase, const int lane,
                                                 char* const scr) {
     constexpr int NBW = BN / 64;                     // 16-column accumulator blocks per wave
     constexpr int NC = BN / 32;                      // 8-column chunks per row of the wave (8 or 6)
@@ -339,8 +339,8 @@ __device__ __forceinline__ void t8_epilogue_lds(const GemmArgs& p, f32x4 (&acc)[
     // Row operands (residual / GELU-adjoint input): a rolling prefetch four 16-row blocks deep - blocks 0-3 are requested here, block
     // b + 4 right before block b is processed, into the registers block b - 4... (b & 3) held - so the second half's loads fly while
     // the first half is worked on: one exposed load latency per tile instead of one per half, no extra registers.
-    uint4 r8[4][2];
-    auto load_rows = [&](int blk8, uint4 (&dst)[2]) {       // blk8 = mh * 4 + mb
+    uint4 r8[MB][2];
+    auto load_rows = [&](int blk8, uint4 (&dst)[2]) {       // blk8 = mh * MB + mb
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int mc = min(mbase + blk8 * 16 + 8 * j + rr8, p.M - 1);
@@ -352,24 +352,24 @@ __device__ __forceinline__ void t8_epilogue_lds(const GemmArgs& p, f32x4 (&acc)[
     };
     if (EPI == 2 || EPI == 3) {
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) load_rows(mb, r8[mb]);
+        for (int mb = 0; mb < MB; ++mb) load_rows(mb, r8[mb]);
     }
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh) {
-        long orow[4][2];
-        bool valid[4][2];
+        long orow[MB][2];
+        bool valid[MB][2];
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int m = mbase + mh * 64 + mb * 16 + 8 * j + rr8;
+                const int m = mbase + mh * (16 * MB) + mb * 16 + 8 * j + rr8;
                 valid[mb][j] = m < p.M && lane_on;
                 const int mc = min(m, p.M - 1);
                 orow[mb][j] = mc;
                 if (p.c_rows > 0) orow[mb][j] = (long)(mc / p.c_rows) * p.c_bstride + p.c_off + mc % p.c_rows;
             }
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
+        for (int mb = 0; mb < MB; ++mb) {
             // accumulators -> scratch (fp32, natural column order), back as rows
 #pragma unroll
             for (int blk = 0; blk < NBW; ++blk) *(f32x4*)(scr + woff[blk]) = acc[mh][mb][blk];
@@ -383,7 +383,7 @@ __device__ __forceinline__ void t8_epilogue_lds(const GemmArgs& p, f32x4 (&acc)[
             // gate row of this 16-row block (EPI 2): wave-uniform when the block lies inside one (batch element, token group)
             bool g_lane = false;
             if (EPI == 2 && p.gate) {
-                const int mf = __builtin_amdgcn_readfirstlane(mbase + mh * 64 + mb * 16), ml = min(mf + 15, p.M - 1);
+                const int mf = __builtin_amdgcn_readfirstlane(mbase + mh * (16 * MB) + mb * 16), ml = min(mf + 15, p.M - 1);
                 long of = min(mf, p.M - 1), ol = ml;
                 if (p.c_rows > 0) {
                     of = (long)(of / p.c_rows) * p.c_bstride + p.c_off + of % p.c_rows;
@@ -448,7 +448,7 @@ __device__ __forceinline__ void t8_epilogue_lds(const GemmArgs& p, f32x4 (&acc)[
                 }
                 if (valid[mb][j] && st_ok) *(uint4*)crow = pack8(w);
             }
-            if ((EPI == 2 || EPI == 3) && mh == 0) load_rows(4 + mb, r8[mb]);       // this block's registers take block + 4
+            if ((EPI == 2 || EPI == 3) && mh == 0) load_rows(MB + mb, r8[mb]);       // this block's registers take block + 4
         }
     }
 }
@@ -477,482 +477,19 @@ __device__ __forceinline__ bf16x8 t8_tr2(t8_lds_char* a) {
     return u.v;
 }
 #endif
+// MB = 16-row blocks per m half of a wave: 4 = the 256-row tile (gemm_t8_kernel), 3 = a 192-row tile (gemm_t8r192_kernel, round 5: M = 3226, one
+// clip, is 17 row tiles of 192 - 510 / 255 tiles for N = 7680 / 3840 instead of 390 / 195 tiles of 256 rows on 256 CUs - and M = 6452 is 34).
+// Same streams, phases, LDS regions (an A half keeps its 16-KiB region and uses 12) and epilogues; a wave owns 96 x BN / 4, the A
+// half-tiles are 96 rows = 12 pieces, so waves 6 and 7 issue no A pieces (a_on) and wait for their W pieces only (T8_VMCNT).
 template <int BN, int EPI>
 __global__ __launch_bounds__(512) void gemm_t8_kernel(const GemmArgs p) {
-    constexpr int NBW = BN / 64;                      // 16-column blocks per wave
-    constexpr int HALF = 16384;                       // A0 | A1 | B region 0 | B region 1
-    constexpr int BUF = BN == 256 ? 65536 : 57344;    // BN = 192: the second B region (block 2 of every wave) is 64 rows = 8 KiB
-    constexpr int SCR = 2 * BUF;                      // epilogue transpose scratch: 8 waves x 4 KiB behind the two K-tile buffers
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int nk = p.K / BK;                          // even (chooser-checked)
-
-    // ---- DMA side.  One wave instruction fills one 1-KiB piece of LDS; the image is lane-linear (lane l writes physical bytes [16 l, 16 l + 16)),
-    // so WHICH 16 global bytes a lane fetches decides the layout.  Two layouts, chosen per instantiation (FL):
-    //   st_16x32 (the template's): a piece = 16 rows x 32 k; lane l holds logical byte 16 (l ^ ((l >> 5) << 1)): row = that >> 2, 16-byte k-chunk
-    //     = that & 3; the two k halves of a 16-row block are two instructions 64 B apart in memory.
-    //   full-line (round 4): a piece = 8 rows x 64 k = 8 whole 128-byte lines (lanes 8 r .. 8 r + 7 fetch row r), so the texture path handles 8
-    //     full lines per instruction instead of 16 half lines: the LDS-DMA stream ALONE is 13-18 % faster (profiles/r4_gemm_t8_load_side.txt).
-    //     Lane l holds physical chunk l & 7 of row r = l >> 3 and fetches logical chunk (l & 7) ^ (r & 6); with that XOR the 16 lanes of every
-    //     ds_read_b128 group (row i of a 16-row block = piece i >> 3, row i & 7; k chunk (4 kh + g) ^ (i & 6)) cover the 16 bank slots once.  A
-    //     block's two pieces are two instructions 8 rows apart.  In the model (same box, interleaved): FFN1 0.3008 -> 0.2958 ms, FFN2 0.3030 ->
-    //     0.2970, out-projection level, q | k | v 0.2326 -> 0.2350 - hence per epilogue: GELU and gated-residual instantiations only.
-    // Both: every instruction has its own 32-bit per-lane byte offset (row clamp to M - 1 included, recomputed per output tile) against a
-    // wave-uniform base that carries the K position (global_load_lds saddr form: no vector address arithmetic in the K loop).  Needs
-    // M * lda * 2 and N * ldw * 2 < 4 GiB (the chooser checks).
-#if defined(ORV_T8_FULLLINE_ALL)
-    constexpr bool FL = true;
-#elif defined(ORV_T8_FULLLINE_NONE)
-    constexpr bool FL = false;
-#else
-    constexpr bool FL = EPI == 1 || EPI == 2;
-#endif
-    const int lsw = FL ? lane : lane ^ ((lane >> 5) << 1);
-    const int srow = FL ? lane >> 3 : lsw >> 2;
-    const int schunk = FL ? (lane & 7) ^ (srow & 6) : lsw & 3;
-    const int q = wave * 16 + srow;                   // row of a 128-row half-tile this lane feeds with its first instruction (FL: second = + 8)
-    const int arow0 = (q >> 6) * 128 + (q & 63);      // + h * 64: tile row held by row q of A half h
-    int brow0, brow1;                                 // tile column held by row q of B region 0 / by this lane's row of region 1
-    {
-        const int wc_ = q >> 5, nb_ = (q >> 4) & 1, r = q & 15;
-        if (BN == 256) {
-            brow0 = wc_ * 64 + 8 * (r >> 2) + 4 * nb_ + (r & 3);      // FL second instruction (r + 8): + 16
-            brow1 = brow0 + 32;
-        } else {
-            brow0 = wc_ * 48 + 8 * (r >> 2) + 4 * nb_ + (r & 3);
-            // region 1: 64 rows.  st_16x32: wave w fills (row block w >> 1, k half w & 1); FL: rows 8 (w & 1) .. + 7 of block w >> 1
-            brow1 = (wave >> 1) * 48 + 32 + (FL ? (wave & 1) * 8 : 0) + srow;
-        }
-    }
-    const int koff1 = (BN == 256 || FL) ? schunk * 8 : (wave & 1) * 32 + schunk * 8;
-    char* const dst2 = smem + wave * 2048;            // two-instruction streams: + S * BUF + region * HALF (+ 1024: second instruction)
-    char* const dst1 = smem + 3 * HALF + wave * 1024; // BN = 192 region 1: + S * BUF
-    unsigned oA0[2], oA1[2], oB0[2], oB1[2];          // byte offsets from p.A / p.W of the two instructions of a stream
-    int kA0 = 0, kA1 = 0, kB0 = 0, kB1 = 0;
-    int tA0 = blockIdx.x, tA1 = blockIdx.x, tB0 = blockIdx.x, tB1 = blockIdx.x;
-#define T8_SETUP_A(OFF, H, TILE)                                                                                     \
-    {                                                                                                                \
-        int tm_, tn_;                                                                                                \
-        tile_of_index(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                                                 \
-        if (p.dbg == 77) tm_ = 0;   /* ORV_GEMM_DBG=77 (timing experiment, wrong results): every workgroup streams the panels of tile (0, 0) */ \
-        const int row_ = tm_ * 256 + arow0 + (H) * 64;                                                               \
-        OFF[0] = (unsigned)(((long)min(row_, p.M - 1) * p.lda + schunk * 8) * 2);                                    \
-        OFF[1] = FL ? (unsigned)(((long)min(row_ + 8, p.M - 1) * p.lda + schunk * 8) * 2) : OFF[0] + 64;             \
-    }
-#define T8_SETUP_B(OFF, H, TILE)                                                                                     \
-    {                                                                                                                \
-        int tm_, tn_;                                                                                                \
-        tile_of_index(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                                                 \
-        if (p.dbg == 77) tn_ = 0;                                                                                    \
-        const int row_ = tn_ * BN + ((H) == 0 ? brow0 : brow1);                                                      \
-        OFF[0] = (unsigned)(((long)row_ * p.ldw + ((H) == 0 ? schunk * 8 : koff1)) * 2);                             \
-        OFF[1] = FL ? (unsigned)(((long)(row_ + 16) * p.ldw + schunk * 8) * 2) : OFF[0] + 64;                        \
-    }
-    // advance a stream by one K-tile; past its tile's last K-tile it moves to the workgroup's next tile (past the last tile: the
-    // final tile again - uniform instruction counts, data never read)
-#define T8_NEXT_A(OFF, KC, TC, H)                                                                                    \
-    if (__builtin_expect(++KC == nk, 0)) { KC = 0; TC += gridDim.x; T8_SETUP_A(OFF, H, TC) }
-#define T8_NEXT_B(OFF, KC, TC, H)                                                                                    \
-    if (__builtin_expect(++KC == nk, 0)) { KC = 0; TC += gridDim.x; T8_SETUP_B(OFF, H, TC) }
-#ifdef ORV_T8_ABL_NODMA      // ablation builds (tools/t8_loop_abl.sh, wrong results): what does the K loop cost without its LDS-DMA / without its fragment reads?
-#define T8_GLDS(BASE, KC, OFF, DST) asm volatile("" :: "v"(OFF), "s"(DST))
-#else
-#ifdef ORV_T8_TRPROBE
-#define T8_GLDS(BASE, KC, OFF, DST) t8_glds_asm((const char*)(BASE) + (long)(KC) * (BK * 2), OFF, DST)
-#else
-#define T8_GLDS(BASE, KC, OFF, DST) glds16((const char*)(BASE) + (long)(KC) * (BK * 2) + (OFF), DST)
-#endif
-#endif
-#define T8_ISSUE_A0(S) { T8_GLDS(p.A, kA0, oA0[0], dst2 + (S) * BUF); T8_GLDS(p.A, kA0, oA0[1], dst2 + (S) * BUF + 1024); T8_NEXT_A(oA0, kA0, tA0, 0) }
-#define T8_ISSUE_A1(S) { T8_GLDS(p.A, kA1, oA1[0], dst2 + (S) * BUF + HALF); T8_GLDS(p.A, kA1, oA1[1], dst2 + (S) * BUF + HALF + 1024); T8_NEXT_A(oA1, kA1, tA1, 1) }
-#define T8_ISSUE_B0(S) { T8_GLDS(p.W, kB0, oB0[0], dst2 + (S) * BUF + 2 * HALF); T8_GLDS(p.W, kB0, oB0[1], dst2 + (S) * BUF + 2 * HALF + 1024); T8_NEXT_B(oB0, kB0, tB0, 0) }
-#define T8_ISSUE_B1(S)                                                                                               \
-    {                                                                                                                \
-        if constexpr (BN == 256) { T8_GLDS(p.W, kB1, oB1[0], dst2 + (S) * BUF + 3 * HALF); T8_GLDS(p.W, kB1, oB1[1], dst2 + (S) * BUF + 3 * HALF + 1024); } \
-        else { T8_GLDS(p.W, kB1, oB1[0], dst1 + (S) * BUF); }                                                        \
-        T8_NEXT_B(oB1, kB1, tB1, 1)                                                                                  \
-    }
-#define pA0 oA0
-#define pA1 oA1
-#define pB0 oB0
-#define pB1 oB1
-    T8_SETUP_A(pA0, 0, tA0)
-    T8_SETUP_A(pA1, 1, tA1)
-    T8_SETUP_B(pB0, 0, tB0)
-    T8_SETUP_B(pB1, 1, tB1)
-
-    // ---- fragment reads: logical byte (l & 15) * 64 + (l >> 4) * 16 of a subtile, bit 5 flipped for rows 8-15
-    // ---- fragment reads.  st_16x32: logical byte (l & 15) * 64 + (l >> 4) * 16 of a piece, bit 5 flipped for rows 8-15, k half 1 = + 1024 (an
-    // immediate).  FL: row i = l & 15 of a block = piece i >> 3, row i & 7, k chunk (4 kh + g) ^ (i & 6): k half 1 = the same address with
-    // bit 6 flipped (a second base register).
-    const int fro = FL ? ((lane & 15) >> 3) * 1024 + (lane & 7) * 128 + (((lane >> 4) ^ (lane & 6)) << 4)
-                       : ((lane & 15) * 64 + (lane >> 4) * 16) ^ (((lane >> 3) & 1) << 5);
-    const int fro1 = FL ? fro ^ 64 : fro + 1024;
-    const char* const rdA = smem + (wr * 4) * 2048 + fro;             // + S * BUF + mh * HALF + mb * 2048
-    const char* const rdA_1 = smem + (wr * 4) * 2048 + fro1;
-    const char* const rdB = smem + 2 * HALF + (wc * 2) * 2048 + fro;  // region 0 (two blocks per wave): + S * BUF + t * 2048
-    const char* const rdB_1 = smem + 2 * HALF + (wc * 2) * 2048 + fro1;
-    const char* const rdB1 = BN == 256 ? rdB + HALF : smem + 3 * HALF + wc * 2048 + fro;
-    const char* const rdB1_1 = BN == 256 ? rdB_1 + HALF : smem + 3 * HALF + wc * 2048 + fro1;
-#define T8_KH(P, KH) (FL ? ((KH) ? P##_1 : P) : P + (KH) * 1024)
-
-#ifdef ORV_T8_TRPROBE
-    t8_lds_char* trb[4];
-    t8_lds_char* trb1[4];
-    {
-        t8_lds_char* const smem3 = (t8_lds_char*)smem;
-        const int i16 = lane & 15, g4 = lane >> 4, f = ((i16 >> 3) & 1) | ((g4 & 1) << 1);
-        const int lb = g4 * 2048 + (i16 >> 2) * 128 + (i16 & 3) * 8, lb1 = g4 * 1024 + (i16 >> 2) * 128 + (i16 & 3) * 8;
-#pragma unroll
-        for (int sg = 0; sg < 4; ++sg) { trb[sg] = smem3 + (lb | ((sg ^ f) << 5)); trb1[sg] = smem3 + (lb1 | ((sg ^ f) << 5)); }
-    }
-#endif
-    f32x4 acc[2][4][NBW];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int c = 0; c < NBW; ++c) acc[a][b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 fa[2][4][2], fb[NBW][2];
-
-#ifdef ORV_T8_ABL_NOREAD
-#define T8_READ_A(MH, S)                                                                                             \
-    _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                                 \
-        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) asm volatile("" : "+v"(fa[MH][mb][kh]));
-#elif defined(ORV_T8_ABL_NOA1)
-#define T8_READ_A(MH, S)                                                                                             \
-    _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                                 \
-        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
-            fa[MH][mb][kh] = (MH) ? fa[0][mb][kh] : *(const bf16x8*)(T8_KH(rdA, kh) + (S) * BUF + (MH) * HALF + mb * 2048);
-#elif defined(ORV_T8_TRPROBE)
-#define T8_READ_A(MH, S)                                                                                             \
-    _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                                 \
-        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
-            fa[MH][mb][kh] = t8_tr2(trb[mb] + (S) * BUF + (MH) * HALF + wr * 1024 + kh * 8192);
-#else
-#define T8_READ_A(MH, S)                                                                                             \
-    _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                                 \
-        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
-            fa[MH][mb][kh] = *(const bf16x8*)(T8_KH(rdA, kh) + (S) * BUF + (MH) * HALF + mb * 2048);
-#endif
-#ifdef ORV_T8_ABL_NOREAD
-#define T8_READ_B01(S)                                                                                               \
-    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                    \
-        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) asm volatile("" : "+v"(fb[t][kh]));
-#elif defined(ORV_T8_TRPROBE)
-#define T8_READ_B01(S)                                                                                               \
-    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                    \
-        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
-            fb[t][kh] = t8_tr2(trb[2 * (wc & 1) + t] + (S) * BUF + 2 * HALF + (wc >> 1) * 1024 + kh * 8192);
-#else
-#define T8_READ_B01(S)                                                                                               \
-    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                    \
-        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
-            fb[t][kh] = *(const bf16x8*)(T8_KH(rdB, kh) + (S) * BUF + t * 2048);
-#endif
-#if defined(ORV_T8_ABL_NOREAD)
-#define T8_READ_B23(S)                                                                                               \
-    _Pragma("unroll") for (int t = 0; t < NBW - 2; ++t)                                                              \
-        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) asm volatile("" : "+v"(fb[2 + t][kh]));
-#elif defined(ORV_T8_ABL_NOB23)      // ablation builds (tools/t8_lds_abl.sh, wrong results): how much do the fragment reads cost?
-#define T8_READ_B23(S)                                                                                               \
-    _Pragma("unroll") for (int t = 0; t < NBW - 2; ++t)                                                              \
-        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
-            fb[2 + t][kh] = fb[t][kh];
-#elif defined(ORV_T8_TRPROBE)
-#define T8_READ_B23(S)                                                                                               \
-    _Pragma("unroll") for (int t = 0; t < NBW - 2; ++t)                                                              \
-        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
-            fb[2 + t][kh] = BN == 256 ? t8_tr2(trb[2 * (wc & 1) + t] + (S) * BUF + 3 * HALF + (wc >> 1) * 1024 + kh * 8192)                  \
-                                      : t8_tr2(trb1[wc] + (S) * BUF + 3 * HALF + kh * 4096);
-#else
-#define T8_READ_B23(S)                                                                                               \
-    _Pragma("unroll") for (int t = 0; t < NBW - 2; ++t)                                                              \
-        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
-            fb[2 + t][kh] = *(const bf16x8*)(T8_KH(rdB1, kh) + (S) * BUF + t * 2048);
-#endif
-    // (m half MH) x (blocks B0 .. B0 + NBK - 1), both k halves
-#ifdef ORV_T8_ABL_NOMFMA
-#define T8_MFMA(MH, B0, NBK)                                                                                         \
-    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                                 \
-        _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                             \
-            _Pragma("unroll") for (int t = 0; t < (NBK); ++t) asm volatile("" : "+v"(acc[MH][mb][(B0) + t]) : "v"(fb[(B0) + t][kh]), "v"(fa[MH][mb][kh]));
-#else
-#define T8_MFMA(MH, B0, NBK)                                                                                         \
-    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                                 \
-        _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                             \
-            _Pragma("unroll") for (int t = 0; t < (NBK); ++t)                                                        \
-                acc[MH][mb][(B0) + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[(B0) + t][kh], fa[MH][mb][kh], acc[MH][mb][(B0) + t], 0, 0, 0);
-#endif
-#define T8_BAR()                                                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                               \
-    __builtin_amdgcn_s_barrier();                                                                                    \
-    __builtin_amdgcn_sched_barrier(0);
-#define T8_LGKM0()                                                                                                   \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
-    __builtin_amdgcn_sched_barrier(0);
-#define T8_PRIO1() __builtin_amdgcn_s_setprio(1);
-#define T8_PRIO0() __builtin_amdgcn_s_setprio(0);
-
-#define T8_KTILE_256(S)                                                                                              \
-    {                                                                                                                \
-        T8_READ_B01(S)                                                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        T8_READ_A(0, S)                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        T8_ISSUE_B1((S) ^ 1)                                                                                         \
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                                           \
-        T8_BAR() T8_LGKM0() T8_PRIO1() T8_MFMA(0, 0, 2) T8_PRIO0() T8_BAR()                                          \
-        T8_READ_A(1, S)                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        T8_ISSUE_B0(S)                                                                                               \
-        T8_BAR() T8_LGKM0() T8_PRIO1() T8_MFMA(1, 0, 2) T8_PRIO0() T8_BAR()                                          \
-        T8_READ_B23(S)                                                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        T8_ISSUE_A0(S)                                                                                               \
-        T8_BAR() T8_LGKM0() T8_PRIO1() T8_MFMA(1, 2, 2) T8_PRIO0() T8_BAR()                                          \
-        T8_ISSUE_A1(S)                                                                                               \
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                             \
-        T8_BAR() T8_PRIO1() T8_MFMA(0, 2, 2) T8_PRIO0() T8_BAR()                                                     \
-    }
-    // BN = 192: P1 (m0, n01) | P2 (m0, n2) + (m1, n2) | P3 (m1, n01); streams: region 1 + A1 of the NEXT K-tile in P1, region 0
-    // of K-tile + 2 in P2 (its reads were retired by the lgkmcnt(8) before P1's first barrier), A0 of K-tile + 2 in P3
-#define T8_KTILE_192(S)                                                                                              \
-    {                                                                                                                \
-        T8_READ_B01(S)                                                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        T8_READ_A(0, S)                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        T8_ISSUE_B1((S) ^ 1)                                                                                         \
-        T8_ISSUE_A1((S) ^ 1)                                                                                         \
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                                           \
-        T8_BAR() T8_LGKM0() T8_PRIO1() T8_MFMA(0, 0, 2) T8_PRIO0() T8_BAR()                                          \
-        T8_READ_B23(S)                                                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        T8_READ_A(1, S)                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        T8_ISSUE_B0(S)                                                                                               \
-        T8_BAR() T8_LGKM0() T8_PRIO1() T8_MFMA(0, 2, 1) T8_MFMA(1, 2, 1) T8_PRIO0() T8_BAR()                         \
-        T8_ISSUE_A0(S)                                                                                               \
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                             \
-        T8_BAR() T8_PRIO1() T8_MFMA(1, 0, 2) T8_PRIO0() T8_BAR()                                                     \
-    }
-
-    // ---- experiment (-DORV_T8_SCHED2, tools/t8_sched_ab.sh): TWO phases of 32 (24) MFMAs per K-tile instead of four (three) of 16: half as
-    // many barriers per MFMA, load segments of 20 + 4 (14 + 8) fragment reads that are closer to the MFMA segments in length.  The
-    // fragment reads are retired BEFORE a phase's first barrier (the DMA that restages a region is issued one phase after its last
-    // reader passed that barrier), one counted vmcnt per phase.
-    //   BN = 256: P1 reads A0 A1 B01, issues B1 (region 1) of K-tile + 1, MFMA (m0 m1) x n01 | P2 reads B23, issues A0 A1 B0 of K-tile + 2,
-    //             MFMA (m0 m1) x n23; vmcnt(8) in both.
-    //   BN = 192: P1 reads A0 B012, issues A1 of K-tile + 1, MFMA m0 x n012 | P2 reads A1, issues A0 B0 B1 of K-tile + 2, MFMA m1 x n012;
-    //             vmcnt(7) in both.
-#define T8_LGKM0_PRE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#define T8_KTILE2_256(S)                                                                                             \
-    {                                                                                                                \
-        T8_READ_B01(S)                                                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        T8_READ_A(0, S)                                                                                              \
-        T8_READ_A(1, S)                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        T8_ISSUE_B1((S) ^ 1)                                                                                         \
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                             \
-        T8_LGKM0_PRE()                                                                                               \
-        T8_BAR() T8_PRIO1() T8_MFMA(0, 0, 2) T8_MFMA(1, 0, 2) T8_PRIO0() T8_BAR()                                    \
-        T8_READ_B23(S)                                                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        T8_ISSUE_A0(S)                                                                                               \
-        T8_ISSUE_A1(S)                                                                                               \
-        T8_ISSUE_B0(S)                                                                                               \
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                             \
-        T8_LGKM0_PRE()                                                                                               \
-        T8_BAR() T8_PRIO1() T8_MFMA(0, 2, 2) T8_MFMA(1, 2, 2) T8_PRIO0() T8_BAR()                                    \
-    }
-#define T8_KTILE2_192(S)                                                                                             \
-    {                                                                                                                \
-        T8_READ_B01(S)                                                                                               \
-        T8_READ_B23(S)                                                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        T8_READ_A(0, S)                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        T8_ISSUE_A1((S) ^ 1)                                                                                         \
-        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                                                             \
-        T8_LGKM0_PRE()                                                                                               \
-        T8_BAR() T8_PRIO1() T8_MFMA(0, 0, 3) T8_PRIO0() T8_BAR()                                                     \
-        T8_READ_A(1, S)                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        T8_ISSUE_A0(S)                                                                                               \
-        T8_ISSUE_B0(S)                                                                                               \
-        T8_ISSUE_B1(S)                                                                                               \
-        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                                                             \
-        T8_LGKM0_PRE()                                                                                               \
-        T8_BAR() T8_PRIO1() T8_MFMA(1, 0, 3) T8_PRIO0() T8_BAR()                                                     \
-    }
-
-    // ---- SCHED3 (-DORV_T8_SCHED3, BN = 256; tools/t8_sched3_ab.sh): the four phases with BALANCED load segments.  Ablation of the shipped loop
-    // (profiles/r4_gemm_loop_ablation.txt): MFMAs + barriers alone 0.518 ms, LDS-DMA + fragment reads + barriers alone 0.544 ms, together 0.777 ms
-    // (8192^3) - the two sides are equal and overlap badly, because the fragment reads are 12 / 8 / 4 / 0 per phase: P1's load segment (12 reads + 2
-    // DMA instructions = 320 LDS cycles) outlasts its partner's 256 MFMA cycles while P4's (128) idles.  Here B01 (dead after P2) and the first block
-    // of A1 (dead after P3) of the NEXT K-tile are read in P4: reads 8 / 6 / 4 / 6, DMA 2 / 2 / 2 / 2 (B0, A0, A1, B1 of K-tile + 2: every stream two
-    // K-tiles ahead), all four load segments <= 256 LDS cycles.  Fragment reads are retired BEFORE a phase's first barrier, so a region is restaged
-    // one interval after its last reader; one vmcnt(6) per K-tile in P3 (retires K-tile + 1 completely: P4 reads it).  The tile's first K-tile
-    // reads B01 / A1 head itself in P1 (T8C_KTILE_FIRST) and issues its P1 DMA in P2 (the second half reads B01 one interval later).
-#define T8_READ_A1_HEAD(S)                                                                                           \
-    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                                 \
-        fa[1][0][kh] = *(const bf16x8*)(T8_KH(rdA, kh) + (S) * BUF + HALF);
-#define T8_READ_A1_REST(S)                                                                                           \
-    _Pragma("unroll") for (int mb = 1; mb < 4; ++mb)                                                                 \
-        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
-            fa[1][mb][kh] = *(const bf16x8*)(T8_KH(rdA, kh) + (S) * BUF + HALF + mb * 2048);
-#define T8C_PRE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#define T8C_TAIL(S)                                                                                                  \
-        T8_READ_B23(S)                                                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        T8_ISSUE_A1(S)                                                                                               \
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                             \
-        T8C_PRE()                                                                                                    \
-        T8_BAR() T8_PRIO1() T8_MFMA(1, 2, 2) T8_PRIO0() T8_BAR()                                                     \
-        T8_READ_B01((S) ^ 1)                                                                                         \
-        T8_READ_A1_HEAD((S) ^ 1)                                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        T8_ISSUE_B1(S)                                                                                               \
-        T8C_PRE()                                                                                                    \
-        T8_BAR() T8_PRIO1() T8_MFMA(0, 2, 2) T8_PRIO0() T8_BAR()
-#define T8C_KTILE(S)                                                                                                 \
-    {                                                                                                                \
-        T8_READ_A(0, S)                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        T8_ISSUE_B0(S)                                                                                               \
-        T8C_PRE()                                                                                                    \
-        T8_BAR() T8_PRIO1() T8_MFMA(0, 0, 2) T8_PRIO0() T8_BAR()                                                     \
-        T8_READ_A1_REST(S)                                                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        T8_ISSUE_A0(S)                                                                                               \
-        T8C_PRE()                                                                                                    \
-        T8_BAR() T8_PRIO1() T8_MFMA(1, 0, 2) T8_PRIO0() T8_BAR()                                                     \
-        T8C_TAIL(S)                                                                                                  \
-    }
-#define T8C_KTILE_FIRST(S)                                                                                           \
-    {                                                                                                                \
-        T8_READ_B01(S)                                                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        T8_READ_A(0, S)                                                                                              \
-        T8_READ_A1_HEAD(S)                                                                                           \
-        T8C_PRE()                                                                                                    \
-        T8_BAR() T8_PRIO1() T8_MFMA(0, 0, 2) T8_PRIO0() T8_BAR()                                                     \
-        T8_READ_A1_REST(S)                                                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        T8_ISSUE_B0(S)                                                                                               \
-        T8_ISSUE_A0(S)                                                                                               \
-        T8C_PRE()                                                                                                    \
-        T8_BAR() T8_PRIO1() T8_MFMA(1, 0, 2) T8_PRIO0() T8_BAR()                                                     \
-        T8C_TAIL(S)                                                                                                  \
-    }
-
-    // prologue: K-tile 0 complete into buffer 0, then the pieces of K-tile 1 the steady state would have issued by now
-    if constexpr (BN == 256) {
-#ifdef ORV_T8_SCHED3
-        T8_ISSUE_A0(0) T8_ISSUE_B0(0) T8_ISSUE_A1(0) T8_ISSUE_B1(0)
-        T8_ISSUE_B0(1) T8_ISSUE_A0(1) T8_ISSUE_A1(1) T8_ISSUE_B1(1)
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-#else
-        T8_ISSUE_A0(0) T8_ISSUE_B0(0) T8_ISSUE_A1(0) T8_ISSUE_B1(0)
-        T8_ISSUE_B0(1) T8_ISSUE_A0(1) T8_ISSUE_A1(1)
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-#endif
-    } else {
-#ifdef ORV_T8_SCHED2
-        T8_ISSUE_A0(0) T8_ISSUE_B0(0) T8_ISSUE_A1(0) T8_ISSUE_B1(0)
-        T8_ISSUE_A0(1) T8_ISSUE_B0(1) T8_ISSUE_B1(1)
-        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-#else
-        T8_ISSUE_A0(0) T8_ISSUE_B0(0) T8_ISSUE_A1(0) T8_ISSUE_B1(0)
-        T8_ISSUE_B0(1) T8_ISSUE_A0(1)
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-#endif
-    }
-    if (p.stagger_groups > 1) {
-        // the prologue's DMA is in flight; this workgroup's group waits its share of the stagger before the first K-tile
-        const int grp_ = (blockIdx.x >> 3) % p.stagger_groups;
-        const unsigned long long t0_ = wall_clock64(), dt_ = (unsigned long long)grp_ * (unsigned)p.stagger_ticks;
-        while (wall_clock64() - t0_ < dt_) __builtin_amdgcn_s_sleep(16);
-    }
-    T8_BAR()
-
-#ifdef ORV_T8_TRACE   // tools/trace_t8.cpp (EPI 0 / 1 builds only: R doubles as the trace buffer): wall-clock stamps (10 ns) of waves 0 and 4 of
-    // workgroups 0, 8 and 100: [loop start, after K-tiles 0-1, after K-tiles 2-3, loop end, epilogue start, epilogue end (stores issued),
-    // (ORV_T8_TRACE == 2: + after s_waitcnt vmcnt(0), i.e. the stores have drained)] for their first 8 tiles
-    int trace_i = 0;
-    const int trace_w = blockIdx.x == 0 ? 0 : (blockIdx.x == 8 ? 1 : (blockIdx.x == 100 ? 2 : -1));
-#define T8_STAMP(SLOT)                                                                                               \
-    if (trace_w >= 0 && (wave & 3) == 0 && lane == 0 && trace_i < 8)                                                 \
-        ((unsigned long long*)p.R)[((trace_w * 2 + wr) * 8 + trace_i) * 8 + (SLOT)] = wall_clock64();
-#else
-#define T8_STAMP(SLOT)
-#endif
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        if (wr == 1) { T8_BAR() }             // the second half of the workgroup runs one barrier behind ...
-        T8_STAMP(0)
-#ifdef ORV_T8_SCHED3
-        if constexpr (BN == 256) { T8C_KTILE_FIRST(0) T8C_KTILE(1) }
-#endif
-        for (int kt = (BN == 256 && T8_SCHED3_ON) ? 2 : 0; kt < nk; kt += 2) {
-#ifdef ORV_T8_SCHED3
-            if constexpr (BN == 256) { T8C_KTILE(0) T8C_KTILE(1) }
-            else { T8_KTILE_192(0) T8_KTILE_192(1) }
-#elif defined(ORV_T8_SCHED2)
-            if constexpr (BN == 256) { T8_KTILE2_256(0) T8_KTILE2_256(1) }
-            else { T8_KTILE2_192(0) T8_KTILE2_192(1) }
-#else
-            if constexpr (BN == 256) { T8_KTILE_256(0) T8_KTILE_256(1) }
-            else { T8_KTILE_192(0) T8_KTILE_192(1) }
-#endif
-#ifdef ORV_T8_TRACE
-            if (kt == 0) { T8_STAMP(1) }
-            if (kt == 2) { T8_STAMP(2) }
-#endif
-        }
-        T8_STAMP(3)
-        if (wr == 0) { T8_BAR() }             // ... and both halves run their epilogues side by side
-        T8_STAMP(4)
-        int tm, tn;
-        tile_of_index(p, tile, ntiles, tm, tn);
-#ifdef ORV_T8_ABL_NOEPI      // ablation build: no epilogue at all (the accumulators stay live through the never-taken call)
-        if (p.M < 0)
-#endif
-        // which epilogue: the LDS-transposed one wins where row operands are LOADED (gated residual: FFN2 -4.5 %, out-projection
-        // -2...4 %) and is level or better for the plain one; the GELU epilogue is bound by its two transcendentals per element and
-        // pays the LDS round trip on top (+1...2 %), the qk-LayerNorm epilogue pays it and the 8-lane DPP reductions (+2.6 % on the
-        // QKV pair in the model): those two keep the register-layout form
-        // (profiles/r4_gemm_epilogue_ablation.txt).  -DORV_T8_EPI_DIRECT / -DORV_T8_EPI_LDS force one form (A/B builds).
-#if defined(ORV_T8_EPI_DIRECT)
-        constexpr bool lds_epi = false;
-#elif defined(ORV_T8_EPI_LDS)
-        constexpr bool lds_epi = true;
-#else
-        constexpr bool lds_epi = EPI != 1 && EPI != 4;
-#endif
-        if constexpr (lds_epi) t8_epilogue_lds<BN, EPI>(p, acc, tm * 256 + wr * 128, tn * BN + wc * (BN / 4), lane, smem + SCR + wave * 4096);
-        else t8_epilogue<BN, EPI>(p, acc, tm * 256 + wr * 128, tn * BN + wc * (BN / 4), lane);
-        T8_STAMP(5)
-#ifdef ORV_T8_TRACE
-#if ORV_T8_TRACE == 2
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        T8_STAMP(6)
-#endif
-        ++trace_i;
-#endif
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int c = 0; c < NBW; ++c) acc[a][b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    constexpr int MB = 4;
+#include "gemm_t8_body.inc"
+}
+template <int BN, int EPI>
+__global__ __launch_bounds__(512) void gemm_t8r192_kernel(const GemmArgs p) {
+    constexpr int MB = 3;
+#include "gemm_t8_body.inc"
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1210,6 +747,8 @@ __device__ __forceinline__ bf16x8 tn_tr2(tn_lds_char* a) {
 template <int BN, int ACC>
 __global__ __launch_bounds__(512) void gemm_t8_tn_kernel(const GemmArgs p) {
     constexpr int NBW = BN / 64;
+    constexpr int MB = 4;                  // the reused K-tile macros of t8_body: 256-row tiles, every wave feeds both operands
+    constexpr bool a_on = true;
     constexpr int HALF = 16384;
     constexpr int BUF = BN == 256 ? 65536 : 57344;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1364,17 +903,19 @@ int launch_tn_one(const GemmArgs& a, hipStream_t st) {
     return orv_check_launch("orv_gemm_tn_bf16");
 }
 
-template <int BN, int EPI>
+template <int BN, int EPI, int BM = 256>
 int launch_one(const GemmArgs& a, hipStream_t st) {
     constexpr int smem = 2 * (BN == 256 ? 65536 : 57344) + 8 * 4096;      // two K-tile buffers + the epilogue scratch (160 KiB at BN = 256)
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_t8_kernel<BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if constexpr (BM == 256) (void)hipFuncSetAttribute((const void*)gemm_t8_kernel<BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        else (void)hipFuncSetAttribute((const void*)gemm_t8r192_kernel<BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
     int grid = min(a.tiles_m * a.tiles_n, orv_num_cus());
     if (a.grid_cap > 0) grid = min(grid, a.grid_cap);
-    hipLaunchKernelGGL((gemm_t8_kernel<BN, EPI>), dim3(grid), dim3(512), smem, st, a);
+    if constexpr (BM == 256) hipLaunchKernelGGL((gemm_t8_kernel<BN, EPI>), dim3(grid), dim3(512), smem, st, a);
+    else hipLaunchKernelGGL((gemm_t8r192_kernel<BN, EPI>), dim3(grid), dim3(512), smem, st, a);
     return orv_check_launch("orv_gemm_bf16");
 }
 
@@ -1396,13 +937,31 @@ int launch_t4(const GemmArgs& a, int epi, hipStream_t st) {
     orv_set_error("orv_gemm_bf16: no t4 kernel for epilogue %d", epi);
     return ORV_EINVAL;
 }
-int launch_t8(const GemmArgs& a, int bn, int epi, hipStream_t st) {
+int launch_t8(const GemmArgs& a, int bn, int epi, hipStream_t st, int bm) {
     if ((long)a.M * a.lda * 2 >= (1L << 32) || (long)a.N * a.ldw * 2 >= (1L << 32)) {
         orv_set_error("orv_gemm_bf16: the t8 kernel addresses A / W with 32-bit byte offsets (M=%d lda=%ld N=%d ldw=%ld)", a.M, a.lda, a.N, a.ldw);
         return ORV_EINVAL;
     }
     if (a.a_packed || (a.c_packed && (bn != 256 || epi != 1 || a.ldc != a.N || a.c_rows > 0 || a.Y))) {
         orv_set_error("orv_gemm_bf16: the t8 kernel reads row-major A and writes packed C only as BN = 256, epilogue 1, ldc == N, no row map / Y");
+        return ORV_EINVAL;
+    }
+    if (bm == 192) {      // the 192-row tile: the epilogues of the inference forward (single-clip and two-clip shapes)
+        if (bn == 256) {
+            switch (epi) {
+                case 0: return launch_one<256, 0, 192>(a, st);
+                case 1: return launch_one<256, 1, 192>(a, st);
+                case 2: return launch_one<256, 2, 192>(a, st);
+                case 4: return launch_one<256, 4, 192>(a, st);
+            }
+        } else if (bn == 192) {
+            switch (epi) {
+                case 0: return launch_one<192, 0, 192>(a, st);
+                case 1: return launch_one<192, 1, 192>(a, st);
+                case 2: return launch_one<192, 2, 192>(a, st);
+            }
+        }
+        orv_set_error("orv_gemm_bf16: no 192-row t8 kernel for BN=%d epilogue %d", bn, epi);
         return ORV_EINVAL;
     }
     if (bn == 256) {

@@ -650,6 +650,90 @@ def test_t8_gemm_matches_simple_kernel_on_every_epilogue_feature(bn):
         assert ((c1.float() - c0.float()).abs() <= 2e-2 * c0.float().abs() + 6e-2).all()
 
 
+@pytest.mark.parametrize("bn", [256, 192])
+def test_t8_192_row_tile_is_bit_identical_to_the_256_row_tile(bn):
+    """gemm_t8r192_kernel (the t8 kernel on 192-row tiles: a wave owns 96 x BN / 4, waves 6 / 7 stage no A pieces) against gemm_t8_kernel
+    pinned in the same process: the same K order per output element, so every epilogue it has - bias, GELU (+ the Y side output, + the
+    packed P16 store at BN = 256), gated residual with per-token-group gates that straddle 16-row blocks, row scatter, r_mod residual,
+    the fused qk LayerNorm (BN = 256) - must agree BIT FOR BIT, on ragged M, single-tile, one-clip (17 row tiles) and multi-round grids."""
+    from orv_amd import ops
+    from orv_amd._lib import lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(50 + bn)
+
+    def run(tile, fn):
+        lib().orv_gemm_force_tile(*tile)
+        try:
+            return fn()
+        finally:
+            lib().orv_gemm_force_tile(0, 0, 0)
+
+    def same(a, b, what):
+        assert torch.isfinite(a.float()).all(), what
+        assert torch.equal(a, b), (what, (a.float() - b.float()).abs().max().item())
+
+    N = bn * 3
+    for M, K in [(100, 128), (191, 256), (193, 128), (3226, 384), (3226 * 2, 256), (40000, 128)]:
+        A = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
+        W = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(torch.bfloat16)
+        bias = torch.randn(N, device=dev, generator=g).to(torch.bfloat16)
+        R = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16)
+        for epi in (0, 1, 2):
+            def fn():
+                C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+                Y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+                ops.gemm(A, W, bias, C, M, N, K, epilogue=epi, Y=Y, **(dict(R=R, ldr=N) if epi == 2 else {}))
+                return C, Y
+            (c1, y1), (c0, y0) = run((3, 192, bn), fn), run((3, 256, bn), fn)
+            same(c1, c0, (bn, M, K, epi, "C")), same(y1, y0, (bn, M, K, epi, "Y"))
+        if bn == 256 and (M + 191) // 192 * 192 <= ops.packed_rows(M):
+            def fn_packed():                                  # GELU epilogue into the packed P16 layout (FFN1 -> FFN2), unpacked for the comparison
+                Cp = torch.zeros(ops.packed_rows(M), N, dtype=torch.bfloat16, device=dev)
+                ops.gemm(A, W, bias, Cp, M, N, K, epilogue=1, c_packed=True)
+                return ops.unpack_rows16(Cp, M, N)
+            same(run((3, 192, bn), fn_packed), run((3, 256, bn), fn_packed), (bn, M, K, "packed C"))
+    seq, n_text, per_group, Bn = 500, 19, 37, 3
+    Mv = (seq - n_text) * Bn
+    K = 128
+    A = torch.randn(Mv, K, device=dev, generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev, generator=g).to(torch.bfloat16)
+    n_groups = 1 + (seq - n_text + per_group - 1) // per_group
+    gate = torch.randn(Bn, n_groups, N, device=dev, generator=g)
+    base = torch.randn(Bn * seq, N, device=dev, generator=g).to(torch.bfloat16)
+
+    def fn_gate():
+        C = base.clone()
+        ops.gemm(A, W, bias, C, Mv, N, K, epilogue=2, R=C, ldr=N, gate=gate, gate_b=n_groups * N, gate_g=N,
+                 grp=ops.Groups(seq, n_text, per_group), cmap=ops.RowMap(seq - n_text, seq, n_text))
+        return C
+    same(run((3, 192, bn), fn_gate), run((3, 256, bn), fn_gate), (bn, "gate + cmap"))
+    Rm = torch.randn(97, N, device=dev, generator=g).to(torch.bfloat16)
+
+    def fn_rmod():
+        C = torch.full((Mv, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.gemm(A, W, bias, C, Mv, N, K, epilogue=2, R=Rm, ldr=N, r_mod=97)
+        return C
+    same(run((3, 192, bn), fn_rmod), run((3, 256, bn), fn_rmod), (bn, "r_mod"))
+    if bn == 256:
+        heads = 4
+        Nq = 2 * heads * 64                                   # q | k: what the split projection hands to this kernel
+        for M in (3226, 777):
+            K = 256
+            A = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
+            W = (torch.randn(Nq, K, device=dev, generator=g) / K ** 0.5).to(torch.bfloat16)
+            bias = torch.randn(Nq, device=dev, generator=g).to(torch.bfloat16)
+            aff = [torch.randn(64, device=dev, generator=g).to(torch.bfloat16) for _ in range(4)]
+
+            def fn_qk():
+                C = torch.full((M, Nq), float("nan"), dtype=torch.bfloat16, device=dev)
+                Y = torch.full((M, Nq), float("nan"), dtype=torch.bfloat16, device=dev)
+                ops.gemm(A, W, bias, C, M, Nq, K, epilogue=4, Y=Y, qknorm=(aff[0], aff[1], aff[2], aff[3], 1e-6, 0.18, heads))
+                return C, Y
+            (c1, y1), (c0, y0) = run((3, 192, 256), fn_qk), run((3, 256, 256), fn_qk)
+            same(c1, c0, ("qknorm C", M)), same(y1, y0, ("qknorm Y", M))
+
+
 @pytest.mark.parametrize("B,S,H,nt,use_rope", [(2, 200, 2, 8, False), (1, 3226, 3, 226, False), (2, 333, 2, 13, True), (1, 17, 1, 0, False)])
 def test_attention_fixed_shift_softmax_with_a_score_bound(B, S, H, nt, use_rope):
     """orv_attention_fwd_bounded: ORV's qk LayerNorm bounds every score by (8 max|gamma_q| + ||beta_q||)(8 max|gamma_k| + ||beta_k||)
