@@ -557,20 +557,17 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             if ops.gemm_kernel_name(M, D, D, 2) == t8_192 or one_round:
                 plan["out"] = True
         # the LayerNorm outputs (A of q | k | v and of FFN1): the producer is a row-per-wave VALU kernel whose packed store scatters 16-byte
-        # pieces.  ORV_PACKED_QKV / ORV_PACKED_FFN1 = 1 switch them on (A/B; measured in profiles/r5_model_ab_packed_ln.txt)
+        # pieces - a loss at B = 4 and B = 2 (profiles/r5_model_ab_packed_ln.txt, r5_packed_qkv_b1.txt: +2.7 % / +1.2 % per step).  At ONE clip the
+        # q | k and v launches are single, latency-bound rounds (255 tiles each) and ONE d8 launch for q | k | v is shorter than the pair
+        # (0.0871 -> 0.0792 ms, step -1.3 %): "auto" takes the packed path exactly there.  ORV_PACKED_QKV / ORV_PACKED_FFN1 = 0 / 1 force them.
         if D <= 2048 and D % 192 == 0:
-            if os.environ.get("ORV_PACKED_QKV", _PACKED_QKV_DEFAULT) == "1" and ops.gemm_kernel_name(M, 3 * D, D, 4, a_packed=True) is not None:
+            want = os.environ.get("ORV_PACKED_QKV", _PACKED_QKV_DEFAULT)
+            single_round = -(-M // 192) * (2 * D // 256) <= _num_cus()
+            if (want == "1" or (want == "auto" and single_round)) and ops.gemm_kernel_name(M, 3 * D, D, 4, a_packed=True) is not None:
                 plan["qkv"] = True
             if (plan["ffn"] and os.environ.get("ORV_PACKED_FFN1", _PACKED_FFN1_DEFAULT) == "1"
                     and ops.gemm_kernel_name(M, 4 * D, D, 1, a_packed=True, c_packed=True) is not None):
                 plan["ffn1"] = True
-        return plan
-        t8_192 = "gemm_t8_kernel<192, 2>"
-        if (ops.gemm_kernel_name(M, D, 4 * D, 2) == t8_192 and ops.gemm_kernel_name(M, D, 4 * D, 2, a_packed=True) is not None
-                and ops.gemm_kernel_name(M, 4 * D, D, 1, c_packed=True) is not None):
-            plan["ffn"] = True
-        if ops.gemm_kernel_name(M, D, D, 2) == t8_192 and ops.gemm_kernel_name(M, D, D, 2, a_packed=True) is not None:
-            plan["out"] = True
         return plan
 
     def _view_pos_table(self, pos, n_view, T, P, dev):
@@ -895,7 +892,7 @@ def _chains() -> int:
         return 1
 
 
-_PACKED_QKV_DEFAULT, _PACKED_FFN1_DEFAULT = "0", "0"
+_PACKED_QKV_DEFAULT, _PACKED_FFN1_DEFAULT = "auto", "0"
 
 
 def _num_cus() -> int:

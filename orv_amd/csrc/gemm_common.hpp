@@ -67,6 +67,14 @@ __device__ __forceinline__ void tile_of_index(const GemmArgs& p, int b, int nb, 
 __device__ __forceinline__ void tile_of_block(const GemmArgs& p, int& tm, int& tn) { tile_of_index(p, blockIdx.x, gridDim.x, tm, tn); }
 
 
+// Fused qk LayerNorm (epilogue 4) of gemm_t8 / gemm_d8: the two roundings that the vectoriser would otherwise place differently per kernel (it
+// fused every second square of one kernel's chain and none of the other's) are written out, so that the kernels agree BIT FOR BIT - a one-clip
+// call (q | k | v on gemm_d8) and a four-clip call (the gemm_t8 pair) must give the same clip (tests: d8 == t8, full-depth batch consistency).
+__device__ __forceinline__ float qkln_sq(float x, float sq) { return __builtin_fmaf(x, x, sq); }
+__device__ __forceinline__ float qkln_affine(float x, float rstd, float ga, float be, float post) {
+    return __builtin_fmaf(x * rstd, ga, be) * post;
+}
+
 // gemm_t8.hip: launches gemm_t8_kernel<BN, EPI> (bm = 256) or gemm_t8r192_kernel<BN, EPI> (bm = 192), BN = 256 or 192; a.tiles_m / a.tiles_n
 // must be set for bm, BN
 int launch_t8(const GemmArgs& a, int bn, int epi, hipStream_t st, int bm = 256);

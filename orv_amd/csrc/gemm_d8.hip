@@ -36,11 +36,16 @@ __device__ __forceinline__ void d8_unpack8(const uint4 u, float (&f)[8]) {
 __device__ __forceinline__ uint4 d8_pack8(const float (&f)[8]) {
     return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
 }
-__device__ __forceinline__ float d8_sum8(float v) {          // sum over the 8 lanes lane & ~7 .. lane | 7
+__device__ __forceinline__ float d8_sum_quad(float v) {      // (v(l) + v(l ^ 1)) + (v(l ^ 2) + v(l ^ 3)) in every lane of a quad
     v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
     v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
-    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x141, 0xF, 0xF, true));    // row_half_mirror
     return v;
+}
+__device__ __forceinline__ float d8_shl4(float v) {          // v(lane + 4) within a row of 16 lanes (row_shl:4)
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x104, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float d8_shr4(float v) {          // v(lane - 4) within a row of 16 lanes (row_shr:4)
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x114, 0xF, 0xF, true));
 }
 __device__ __forceinline__ unsigned long long d8_uniform64(unsigned long long u) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
@@ -229,16 +234,32 @@ __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][B
                 if (p.Y && valid[rb][j]) *(uint4*)(p.Y + orow[rb][j] * p.ldy + col8) = d8_pack8(w);
                 if constexpr (EPI == 4) {
                     if (region < 2) {
+                        // The statistics are summed in gemm_t8_kernel's ORDER, so that the two kernels agree bit for bit here as well (a one-clip call takes
+                        // this kernel for q | k | v, a four-clip call the t8 pair: B = 4 stays bit-identical to four B = 1 calls).  t8's lane g of a row holds
+                        // columns 8 g .. 8 g + 7 and 32 + 8 g .. + 7 and chains its 16 values in that order, then adds lane g ^ 1, then g ^ 2.  Here lane c
+                        // holds chunk c: lanes c < 4 fetch chunk c + 4 of their row (row_shl:4), chain like t8's lane g = c, combine inside the quad, and
+                        // hand the result to lanes c >= 4 (row_shr:4).
+                        float hi[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) hi[e] = d8_shl4(w[e]);
                         float s = 0.f;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) s += w[e];
-                        const float mean = d8_sum8(s) * (1.f / 64.f);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) s += hi[e];
+                        s = d8_sum_quad(s);
+                        const float s_up = d8_shr4(s);       // every lane executes the cross-lane moves (a DPP inside a divergent arm reads disabled lanes)
+                        const float mean = (c < 4 ? s : s_up) * (1.f / 64.f);
                         float sq = 0.f;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) { w[e] -= mean; sq += w[e] * w[e]; }
-                        const float rstd = rsqrtf(d8_sum8(sq) * (1.f / 64.f) + p.qn_eps);
+                        for (int e = 0; e < 8; ++e) { w[e] -= mean; sq = qkln_sq(w[e], sq); }
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) w[e] = (w[e] * rstd * ga[e] + be[e]) * post;
+                        for (int e = 0; e < 8; ++e) { hi[e] -= mean; sq = qkln_sq(hi[e], sq); }
+                        sq = d8_sum_quad(sq);
+                        const float sq_up = d8_shr4(sq);
+                        const float rstd = rsqrtf((c < 4 ? sq : sq_up) * (1.f / 64.f) + p.qn_eps);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) w[e] = qkln_affine(w[e], rstd, ga[e], be[e], post);
                     }
                 }
                 if (EPI == 1) {

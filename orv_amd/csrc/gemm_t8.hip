@@ -123,12 +123,12 @@ __device__ __forceinline__ void t8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][M
 #pragma unroll
                     for (int P = 0; P < NP; ++P)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) { v[P][e] -= mean; sq += v[P][e] * v[P][e]; }
+                        for (int e = 0; e < 8; ++e) { v[P][e] -= mean; sq = qkln_sq(v[P][e], sq); }      // explicit fma chain: gemm_common.hpp
                     const float rstd = rsqrtf(sum_xor32(sum_xor16(sq)) * (1.f / 64.f) + p.qn_eps);
 #pragma unroll
                     for (int P = 0; P < NP; ++P)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[P][e] = (v[P][e] * rstd * ga[P][e] + be[P][e]) * post;
+                        for (int e = 0; e < 8; ++e) v[P][e] = qkln_affine(v[P][e], rstd, ga[P][e], be[P][e], post);
                 }
                 if (valid && st_ok) {
 #pragma unroll
@@ -416,10 +416,10 @@ __device__ __forceinline__ void t8_epilogue_lds(const GemmArgs& p, f32x4 (&acc)[
                         const float mean = sum8(s) * (1.f / 64.f);
                         float sq = 0.f;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) { w[e] -= mean; sq += w[e] * w[e]; }
+                        for (int e = 0; e < 8; ++e) { w[e] -= mean; sq = qkln_sq(w[e], sq); }
                         const float rstd = rsqrtf(sum8(sq) * (1.f / 64.f) + p.qn_eps);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) w[e] = (w[e] * rstd * ga[e] + be[e]) * post;
+                        for (int e = 0; e < 8; ++e) w[e] = qkln_affine(w[e], rstd, ga[e], be[e], post);
                     }
                 }
                 if (EPI == 1) {

@@ -1100,6 +1100,19 @@ def test_d8_gemm_on_packed_a_is_bit_identical_to_t8(bn):
     assert torch.isfinite(c1.float()).all() and torch.isfinite(y1.float()).all()
     assert ((y1.float() - y0.float()).abs() <= 1.0e-2 * y0.float().abs() + 1.5e-2).all()
     assert ((c1.float() - c0.float()).abs() <= 2e-2 * c0.float().abs() + 6e-2).all()
+    # q | k against gemm_t8_kernel<256, 4> pinned (on 256 and on 192 rows): the d8 epilogue sums the LayerNorm statistics in t8's order -
+    # BIT-identical, so that a one-clip call (q | k | v on d8) and a four-clip call (the t8 pair) give the same clip
+    qk = 2 * heads * 64
+    Cr = torch.full((M, qk), float("nan"), dtype=BF, device=dev)
+    Yr = torch.full((M, qk), float("nan"), dtype=BF, device=dev)
+    for bm in (256, 192):
+        lib().orv_gemm_force_tile(3, bm, 256)
+        try:
+            ops.gemm(A, W[:qk].contiguous(), bias[:qk].contiguous(), Cr, M, qk, K, epilogue=4, Y=Yr,
+                     qknorm=(aff[0], aff[1], aff[2], aff[3], 1e-6, 0.18, heads))
+        finally:
+            lib().orv_gemm_force_tile(0, 0, 0)
+        assert torch.equal(y1[:, :qk], Yr) and torch.equal(c1[:, :qk], Cr), bm
 
 
 def test_packed_c_from_the_gelu_epilogues_and_the_attention_kernel():
@@ -1116,10 +1129,10 @@ def test_packed_c_from_the_gelu_epilogues_and_the_attention_kernel():
         C = torch.empty(M, N, dtype=BF, device=dev)
         ops.gemm(A, W, bias, C, M, N, K, epilogue=1)
         name = ops.gemm_kernel_name(M, N, K, 1, c_packed=True)
-        assert name == "gemm_t8_kernel<256, 1>", name
+        assert name in ("gemm_t8_kernel<256, 1>", "gemm_t8r192_kernel<256, 1>"), name      # 192-row tiles where their count fits the CUs better
         Cp = torch.full((ops.packed_rows(M), N), float("nan"), dtype=BF, device=dev)
         ops.gemm(A, W, bias, Cp, M, N, K, epilogue=1, c_packed=True)
-        # the row-major call may have taken another kernel (cost model); compare against the t8 kernel pinned
+        # the row-major call may have taken another kernel (cost model); compare against the 256-row t8 kernel pinned
         from orv_amd._lib import lib
         lib().orv_gemm_force_tile(3, 256, 256)
         try:

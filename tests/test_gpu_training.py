@@ -671,6 +671,8 @@ def test_reference_config_widths_land_on_mfma_tiles():
         for (N, K, epi) in [(3 * D, D, 4), (D, D, 2), (4 * D, D, 1), (D, 4 * D, 2)]:
             name = ops.gemm_kernel_name(12904, N, K, epi)
             print(f"[tile] D={D} N={N} K={K} epi={epi}: {name}")
-            assert name and ("gemm_t8_kernel" in name or "gemm_ph_kernel" in name or "gemm_pp_kernel" in name or "gemm_kernel<" in name), name
+            assert name and ("gemm_t8_kernel" in name or "gemm_t8r192_kernel" in name or "gemm_ph_kernel" in name or "gemm_pp_kernel" in name
+                             or "gemm_kernel<" in name), name
             if D == 1792 and N % 256 == 0:
-                assert "gemm_t8_kernel<256" in name, name            # 1792 = 7 x 256, 7168 = 28 x 256: the t8 kernel's 256-wide tile
+                # 1792 = 7 x 256, 7168 = 28 x 256: the t8 kernel's 256-wide tile (on 256 or 192 rows, whichever count fits the CUs better)
+                assert "gemm_t8_kernel<256" in name or "gemm_t8r192_kernel<256" in name, name
