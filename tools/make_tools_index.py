@@ -5,7 +5,7 @@ CUR = {'refresh_r5.sh', 'make_summary.py', 'make_tools_index.py', 'profile_bench
        'bench_line_brief.py', 'gpu_suite.sh', 'full_check.sh', 'make_leaf_kat.py', 'make_vae_naive.py', 'kbench_gemm.cpp', 'kbench_attn.cpp', 'model_ab.sh',
        'time_attn_bwd.py', 'bwd_ab.sh', 'bwd_abl.sh', 'bwd_abl_run.sh', 'attn_bwd_seg_trace.py', 'probe_lds_bcast.cpp', 'attn_fwd_ab.sh', 'power_gemm.py',
        'power_gemm.sh', 'power_attn.py', 'd8_ab.sh', 'd8_abl.sh', 'd8_zero.sh', 'd8_variants.sh', 'd8_b1.sh', 'd8_prev_ab.sh', 'd8_rs_ab.sh', 'd8_rlds_ab.sh',
-       'w64_ab.sh', 'b1_ab.sh', 'ln_packed_ab.sh', 'probe_frag_loads.cpp', 'power_abl.sh', 'vae_bench.py', 'train_memory.py'}
+       'w64_ab.sh', 'b1_ab.sh', 'chains_ab.sh', 'r192_ab.sh', 'r192_tiles.py', 'pqkv_ab.sh', 'ln_rows_b1.sh', 'hipblaslt_compare.py', 'lib_ab.sh', 'ln_packed_ab.sh', 'probe_frag_loads.cpp', 'power_abl.sh', 'vae_bench.py', 'train_memory.py'}
 def first(p):
     try: L = open(p, errors='ignore').read().splitlines()
     except Exception: return ''
