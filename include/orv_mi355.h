@@ -191,6 +191,9 @@ int orv_gemm_kernel_name_packed(int M, int N, int K, int epilogue, int a_packed,
  * 1 ring, 2 phased, 3 t8; tile bm x bn) for all later orv_gemm_bf16 calls of this process; bm = 0 returns to the cost model.
  * Same effect as the environment variable ORV_GEMM_TILE="ring,bm,bn" read at the first call. */
 int orv_gemm_force_tile(int ring, int bm, int bn);
+/* Number of orv_gemm_force_tile calls so far: a host-side plan derived from orv_gemm_kernel_name(_packed) (which GEMMs of a block take packed
+ * operands) is valid for the epoch it was made in and is re-derived when this moves. */
+int orv_gemm_force_epoch(void);
 /* C[M, N] (+)= A[K, M]^T . W[K, N] - both operands row-major over the CONTRACTION index (K rows): the weight gradient dW = dY^T X of a linear
  * layer straight from the row-major dY [tokens, out] and X [tokens, in], without transposed copies (torch autograd of nn.Linear inside
  * `accelerator.backward(loss)`, train_cogvideox_control_to_video_sft.py:1093; the linears of cogvideox_control.py:232-234, 263, 439-440).

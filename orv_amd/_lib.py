@@ -63,6 +63,7 @@ SIGNATURES = {
     "orv_gemm_kernel_name": (c_int, [c_int, c_int, c_int, c_int, ctypes.c_char_p, c_int]),
     "orv_gemm_kernel_name_packed": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, ctypes.c_char_p, c_int]),
     "orv_gemm_force_tile": (c_int, [c_int, c_int, c_int]),
+    "orv_gemm_force_epoch": (c_int, []),
     "orv_gemm_tn_bf16": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p]),
     "orv_gemm_bf16": (c_int, [POINTER(Gemm), c_void_p]),
     "orv_packed_rows": (c_long, [c_long]),

@@ -18,16 +18,22 @@ _param_hook = []
 
 
 def watch_parameter_registration() -> None:
-    """Install (once per process) torch's global parameter-registration hook that bumps ``param_epoch``."""
+    """Install (once per process) torch's global parameter- AND module-registration hooks that bump ``param_epoch``:
+    ``m.weight = nn.Parameter(...)`` goes through ``register_parameter``; attaching a pre-built submodule (``blk.ff = other``,
+    replacing ``transformer_blocks``) goes through ``register_module`` / ``Module.__setattr__``.  Edits that bypass both
+    (``del m.weight``, writes into ``_parameters`` / ``_modules``, ``ModuleList`` truncation via ``del``) are caught by the structural
+    fingerprint ``GraphedTransformer._weights_version`` keeps next to the epoch."""
     if _param_hook:
         return
-    from torch.nn.modules.module import register_module_parameter_registration_hook
+    from torch.nn.modules.module import (register_module_module_registration_hook,
+                                         register_module_parameter_registration_hook)
 
-    def _bump(module, name, param):
+    def _bump(module, name, value):
         param_epoch[0] += 1
         return None
 
     _param_hook.append(register_module_parameter_registration_hook(_bump))
+    _param_hook.append(register_module_module_registration_hook(_bump))
 
 
 # Gradient destinations registered by the fused optimizer (id(parameter) -> its segment of the flat bf16 gradient buffer, viewed in

@@ -529,26 +529,33 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             Mp = ops.packed_rows(M)
             self._ws = {key: dict(x=e(M, D), xn=e(Mp, D), qkv=e(M, 3 * D), att=e(Mp, D), h=e(Mp, 4 * D), vis=e(B * Nv, D),
                                   vis2=e(B * Nv, D), s_pad=s_pad,
-                                  attn_ws=torch.empty(nb, dtype=torch.uint8, device=dev) if nb else None,
-                                  packed=self._packed_plan(M, D))}
-        return self._ws[key]
+                                  attn_ws=torch.empty(nb, dtype=torch.uint8, device=dev) if nb else None)}
+        ws = self._ws[key]
+        # the packed-operand plan is derived from the library's tile chooser: valid for the orv_gemm_force_tile epoch it was made in
+        # (a tile pinned later left a stale plan asking the d8 kernel for a shape the pin excludes)
+        ep = ops.lib().orv_gemm_force_epoch()
+        if ws.get("packed_epoch") != ep:
+            FF = self.transformer_blocks[0].ff.net[0].proj.weight.shape[0] if len(self.transformer_blocks) else 4 * D
+            ws["packed"], ws["packed_epoch"] = self._packed_plan(B * S, D, FF), ep
+        return ws
 
     @staticmethod
-    def _packed_plan(M, D):
+    def _packed_plan(M, D, FF=None):
         """Which GEMMs of a block take their A operand in the packed P16 layout (round 5, csrc/gemm_d8.hip: A straight to registers, twice
         the bytes in flight of the LDS-staged kernel; bit-identical results).  The producer must be an MFMA kernel that writes the layout for
         free - FFN2's A is FFN1's GELU epilogue (cogvideox_control.py:439 -> :440), the out-projection's A is the attention output (:256-263) -
         and the d8 kernel must be the better choice for the shape: exactly where the row-major cost model picks the 256 x 192 t8 tile
         (same tile count; B = 1 and other single-round shapes keep their smaller row-major tiles).  ``ORV_GEMM_PACKED=0``: A/B switch."""
         plan = {"ffn": False, "out": False, "qkv": False, "ffn1": False}
+        FF = FF or 4 * D                      # FeedForward inner dimension as built (``ff.net[0].proj.weight.shape[0]``)
         if os.environ.get("ORV_GEMM_PACKED", "1") == "0":
             return plan
         t8_192 = "gemm_t8_kernel<192, 2>"
         # FeedForward pair: wherever FFN1 can write the packed hidden state (the t8 kernel's 256-wide GELU epilogue) and a d8 tile takes
         # FFN2 - measured better at B = 4 (256 x 192 tiles: -0.7 % in the model), B = 2 and B = 1 (256 x 128 tiles against the single-round
         # simple kernels: 0.203 -> 0.180 ms and 0.118 -> 0.093 ms standalone, profiles/r5_gemm_d8_b1.txt)
-        if (ops.gemm_kernel_name(M, D, 4 * D, 2, a_packed=True) is not None
-                and ops.gemm_kernel_name(M, 4 * D, D, 1, c_packed=True) is not None):
+        if (ops.gemm_kernel_name(M, D, FF, 2, a_packed=True) is not None
+                and ops.gemm_kernel_name(M, FF, D, 1, c_packed=True) is not None):
             plan["ffn"] = True
         # out-projection (K = D: 30 K-tiles, epilogue-heavy): where the row-major model picks the 256 x 192 t8 tile (B = 4: -6 %) and where the
         # 256 x 128 d8 tiles fit ONE round of the CUs (B = 1: 0.037 -> 0.033 ms); in between (B = 2: 390 tiles) the row-major kernel wins
@@ -566,7 +573,7 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             if (want == "1" or (want == "auto" and single_round)) and ops.gemm_kernel_name(M, 3 * D, D, 4, a_packed=True) is not None:
                 plan["qkv"] = True
             if (plan["ffn"] and os.environ.get("ORV_PACKED_FFN1", _PACKED_FFN1_DEFAULT) == "1"
-                    and ops.gemm_kernel_name(M, 4 * D, D, 1, a_packed=True, c_packed=True) is not None):
+                    and ops.gemm_kernel_name(M, FF, D, 1, a_packed=True, c_packed=True) is not None):
                 plan["ffn1"] = True
         return plan
 
@@ -613,7 +620,9 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         if not hidden_states.is_cuda:
             raise RuntimeError("orv_amd runs on MI355X only: move the model and its inputs to the GPU (no CPU fallback)")
         if self.dtype != BF16:
-            raise RuntimeError(f"orv_amd kernels are bf16: call model.to(torch.bfloat16) (got {self.dtype})")
+            raise RuntimeError(f"orv_amd kernels are bf16: call model.to(torch.bfloat16) (got {self.dtype}).  The reference's "
+                               "`--dtype float16` (inference_control_to_video.py:198-203) is not provided - its default and every shipped "
+                               "config is bfloat16; run with `--dtype bfloat16`")
         if num_views > 1 and not c.multiview:
             raise ValueError("num_views > 1 needs a multiview=True model (pos_embedding_v / mv_blocks, :592-606)")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
@@ -976,10 +985,21 @@ class GraphedTransformer:
         old weights).  The per-call cost is one pass over the cached list - no module walk on the B = 1 path the graph exists
         to speed up; every data_ptr enters the key (a sampled subset missed moves of the unsampled ones)."""
         ps = getattr(self, "_plist", None)
+        self._vcalls = getattr(self, "_vcalls", 0) + 1
+        if ps is not None and self._pepoch == _state.param_epoch[0]:
+            # structural fingerprint (ADVICE r5): edits that bypass register_parameter / register_module - ``del m.weight``, ``del blocks[k:]``,
+            # writes into ``_parameters`` / ``_modules`` - change the live counts of the cached module list; a full re-walk every 64th call
+            # catches what keeps the counts (a same-size swap inside ``_modules``).  ~600 dict lengths per call, no generator walk.
+            fp = (sum(len(m._parameters) for m in self._mlist), sum(len(m._modules) for m in self._mlist))
+            if fp != self._mfp or (self._vcalls & 63) == 0 and [id(m) for m in self.tr.modules()] != self._mids:
+                ps = None
         if ps is None or self._pepoch != _state.param_epoch[0]:
+            self._mlist = list(self.tr.modules())
+            self._mids = [id(m) for m in self._mlist]
+            self._mfp = (sum(len(m._parameters) for m in self._mlist), sum(len(m._modules) for m in self._mlist))
             ps = self._plist = list(self.tr.parameters())
             self._pepoch = _state.param_epoch[0]
-        return (len(ps), sum(p._version for p in ps), hash(tuple(p.data_ptr() for p in ps)), hash(tuple(map(id, ps))))
+        return (len(ps), len(self._mlist), sum(p._version for p in ps), hash(tuple(p.data_ptr() for p in ps)), hash(tuple(map(id, ps))))
 
     # ---- batch chains (experiment, ORV_CHAINS=n): the clips of a batch are independent until the sampler's update, so the batch can be cut
     # into n chains that run the SAME forward on n streams inside the captured graph.  Every kernel of the path is persistent / fills the
@@ -1083,13 +1103,32 @@ class GraphedTransformer:
             with torch.no_grad():
                 return self._forward(kw, st, concurrent=False)
         self._state.move_to_end(key)
+        if st.get("eager_only"):             # a capture of this key failed before: plain launches from now on
+            with torch.no_grad():
+                return self._forward(kw, st, concurrent=False)
         if "graph" not in st:
             st["static"] = [t.clone() for t in leaves]
             skw = self._rebuild(kw, st["static"])
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(g):
-                st["out"] = self._forward(skw, st, concurrent=True)      # st["ws"]: the captured launches point into these workspaces -
+            try:
+                # thread_local: another thread's CUDA calls (a DataLoader pin_memory thread during in-training validation,
+                # base_train.yaml pin_memory / 8 workers) must not invalidate this capture
+                with torch.no_grad(), torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    st["out"] = self._forward(skw, st, concurrent=True)  # st["ws"]: the captured launches point into these workspaces -
+            except _NotCapturable:
+                raise
+            except Exception as e:           # out of memory in the private pool, a syncing op, a foreign capture-unsafe call
+                for k in ("static", "out", "ws", "chain_ws"):
+                    st.pop(k, None)
+                st["eager_only"] = True
+                import warnings
+                warnings.warn(f"orv_amd: HIP-graph capture of the transformer forward failed ({type(e).__name__}: {e}); this call "
+                              "shape runs with eager launches from now on (set ORV_HIP_GRAPH=0 or pipe.enable_hip_graph(False) to "
+                              "skip the attempt)", RuntimeWarning)
+                torch.cuda.synchronize()
+                with torch.no_grad():
+                    return self._forward(kw, st, concurrent=False)
             st["graph"] = g                                              # kept alive even if the model later swaps in another one
         else:
             for dst, src in zip(st["static"], leaves):

@@ -1313,8 +1313,10 @@ extern "C" int orv_gemm_tn_bf16(const void* A, long lda, const void* W, long ldw
 }
 
 // ORV_GEMM_TILE="ring,bm,bn" / orv_gemm_force_tile() pin one candidate (sweeps, same-process A/B, the per-instantiation tests)
-static int g_force_ring = -1, g_force_bm = 0, g_force_bn = 0;
+static int g_force_ring = -1, g_force_bm = 0, g_force_bn = 0, g_force_epoch = 0;
+extern "C" int orv_gemm_force_epoch(void) { return g_force_epoch; }
 extern "C" int orv_gemm_force_tile(int ring, int bm, int bn) {
+    ++g_force_epoch;
     if (g_force_ring < 0) g_force_ring = 2;
     if (bm > 0) { g_force_ring = ring; g_force_bm = bm; g_force_bn = bn; }
     else { g_force_ring = 2; g_force_bm = 0; g_force_bn = 0; }

@@ -343,9 +343,12 @@ static int layernorm_modulate_impl(const void* x, int ldx, orv_rowmap_t xmap, vo
     if (rows_env == -2) { const char* e = getenv("ORV_LN_ROWS"); rows_env = e ? atoi(e) : -1; }
     ORV_REQUIRE(!packed || (full && xmap.rows == 0 && ch <= 4 && D % 32 == 0 && ldy == D),
                 "orv_layernorm_modulate_packed: needs gamma, beta, scale, shift, no row map, D %% 32 == 0, D <= 2048 and ldy == D");
-    if (full && xmap.rows == 0 && (packed || (rows_env != 0 && rows >= 2048)) && ch <= 4) {
+    // Every full, map-free launch with D <= 2048 takes the rows kernel, whatever the row count (below 2048 rows the one-row kernel
+    // rounded ((xhat gamma + beta)(1 + scale) + shift) in another order than the folded form, so a clip could differ in the last bit between
+    // a batch size on the packed path and one on the row-major path).
+    if (full && xmap.rows == 0 && (packed || rows_env != 0) && ch <= 4) {
         const int slots = 256 * 4 * ORV_LNR_WAVES;
-        const int R = rows_env > 0 ? rows_env : max(2, (rows + slots - 1) / slots);
+        const int R = rows_env > 0 ? rows_env : max(rows >= 2048 ? 2 : 1, (rows + slots - 1) / slots);
         dim3 g2(((rows + R - 1) / R + 3) / 4);
 #define ORV_LNR_CASE(C)                                                                                                \
         if (packed)                                                                                                    \

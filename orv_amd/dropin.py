@@ -33,6 +33,11 @@ import types
 from typing import Dict, List
 
 _installed: Dict[str, types.ModuleType] = {}
+_MISSING = object()
+# what install() displaced, so that uninstall() can put it back: name -> (previous sys.modules entry or _MISSING, previous
+# attribute of the parent package or _MISSING); and (object, attribute name, previous value) for attributes patched in place
+_previous: Dict[str, tuple] = {}
+_patched: list = []
 
 
 def _have(name: str) -> bool:
@@ -73,6 +78,8 @@ def _ensure_parent(name: str) -> types.ModuleType:
 def _alias(name: str, module: types.ModuleType) -> None:
     parent, _, leaf = name.rpartition(".")
     pkg = _ensure_parent(parent)
+    if name not in _previous:              # first install only: a repeated install() must not record its own aliases as "previous"
+        _previous[name] = (sys.modules.get(name, _MISSING), getattr(pkg, leaf, _MISSING))
     sys.modules[name] = module
     setattr(pkg, leaf, module)
     _installed[name] = module
@@ -129,8 +136,12 @@ def install(verbose: bool = False) -> List[str]:
                 print = log
             ou.CONSOLE = _Plain()
         _alias("orv.utils", ou)
+    if not getattr(ou, "__orv_amd_standin__", False) and not any(o is ou for o, _, _ in _patched):
+        _patched.append((ou, "prepare_rotary_positional_embeddings", getattr(ou, "prepare_rotary_positional_embeddings", _MISSING)))
     ou.prepare_rotary_positional_embeddings = utils.prepare_rotary_positional_embeddings
-    _installed.setdefault("orv.utils", ou)
+    if "orv.utils" not in _installed:
+        _installed["orv.utils"] = ou
+        _previous.setdefault("orv.utils", (ou if not getattr(ou, "__orv_amd_standin__", False) else _MISSING, _MISSING))
 
     # orv.dataset.dataset: only when the reference's is not there
     if not _have("orv.dataset.dataset"):
@@ -165,17 +176,33 @@ def install(verbose: bool = False) -> List[str]:
 
 
 def uninstall() -> None:
-    """Remove what ``install()`` registered (tests)."""
+    """Undo ``install()``: aliases and stand-ins leave ``sys.modules`` / their parent packages, whatever they displaced (a real
+    ``diffusers.schedulers.scheduling_*_cogvideox``, the reference's own ``orv.utils.prepare_rotary_positional_embeddings``) comes back."""
+    for obj, attr, prev in _patched:
+        if prev is _MISSING:
+            if hasattr(obj, attr):
+                delattr(obj, attr)
+        else:
+            setattr(obj, attr, prev)
+    _patched.clear()
     for k, m in list(_installed.items()):
+        prev_mod, prev_attr = _previous.get(k, (_MISSING, _MISSING))
         if sys.modules.get(k) is m:
-            del sys.modules[k]
+            if prev_mod is _MISSING:
+                del sys.modules[k]
+            else:
+                sys.modules[k] = prev_mod
         parent, _, leaf = k.rpartition(".")
         if parent in sys.modules and getattr(sys.modules[parent], leaf, None) is m:
-            try:
-                delattr(sys.modules[parent], leaf)
-            except AttributeError:
-                pass
+            if prev_attr is _MISSING:
+                try:
+                    delattr(sys.modules[parent], leaf)
+                except AttributeError:
+                    pass
+            else:
+                setattr(sys.modules[parent], leaf, prev_attr)
     _installed.clear()
+    _previous.clear()
 
 
 def _export_to_video(video_frames, output_video_path: str = None, fps: int = 10, **_):

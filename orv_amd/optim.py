@@ -231,3 +231,102 @@ class FusedAdamW:
                 self._flat["seg_step"].copy_(sd["seg_step"])
             else:                           # checkpoints written before per-parameter counts existed
                 self._flat["seg_step"].fill_(self.step_count)
+
+
+# ---- learning-rate schedules of the train tail (train_cogvideox_control_to_video_sft.py:740-747, :1107; base_train.yaml:160-164) ----
+# The reference calls ``diffusers.optimization.get_scheduler(name, optimizer=, num_warmup_steps=, num_training_steps=, num_cycles=, power=)``
+# and ``lr_scheduler.step()`` after every optimizer step.  diffusers is not installable here: the multipliers below restate its published
+# ``get_*_schedule*`` lambdas (LEAF, unpinned like oracle/leaf.py; hand-derived known answers in tests/test_lr_schedule.py).  Each returns
+# lr(step) / lr_base for the number of ``step()`` calls made so far.
+def _lr_lambda(name: str, num_warmup_steps: int, num_training_steps: Optional[int], num_cycles, power: float, lr_init: float):
+    import math
+    W = int(num_warmup_steps or 0)
+    T = num_training_steps
+    name = getattr(name, "value", name)
+    if name not in ("constant", "constant_with_warmup") and T is None:
+        raise ValueError(f"{name} requires `num_training_steps`, please provide that argument.")       # diffusers' message
+    warm = lambda s: float(s) / float(max(1, W))
+    if name == "constant":
+        return lambda s: 1.0
+    if name == "constant_with_warmup":
+        return lambda s: warm(s) if s < W else 1.0
+    if name == "linear":
+        return lambda s: warm(s) if s < W else max(0.0, float(T - s) / float(max(1, T - W)))
+    if name == "cosine":
+        nc = 0.5 if num_cycles is None else float(num_cycles)      # NB the reference passes lr_num_cycles (1) for every schedule name
+
+        def cosine(s):
+            if s < W:
+                return warm(s)
+            prog = float(s - W) / float(max(1, T - W))
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * nc * 2.0 * prog)))
+        return cosine
+    if name == "cosine_with_restarts":                             # base_train.yaml:161 - the schedule every shipped config trains with
+        nc = 1 if num_cycles is None else num_cycles
+
+        def restarts(s):
+            if s < W:
+                return warm(s)
+            prog = float(s - W) / float(max(1, T - W))
+            if prog >= 1.0:
+                return 0.0
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * ((float(nc) * prog) % 1.0))))
+        return restarts
+    if name == "polynomial":
+        lr_end = 1e-7
+        if not lr_init > lr_end:
+            raise ValueError(f"lr_end ({lr_end}) must be smaller than initial lr ({lr_init})")
+
+        def poly(s):
+            if s < W:
+                return warm(s)
+            if s > T:
+                return lr_end / lr_init
+            pct = 1 - (s - W) / (T - W)
+            return ((lr_init - lr_end) * pct ** power + lr_end) / lr_init
+        return poly
+    raise ValueError(f"unknown lr scheduler {name!r} (constant, constant_with_warmup, linear, cosine, cosine_with_restarts, polynomial)")
+
+
+class LambdaSchedule:
+    """``torch.optim.lr_scheduler.LambdaLR`` semantics on anything with ``param_groups`` (``FusedAdamW`` is not a ``torch.optim.Optimizer``):
+    lr = base_lr x lambda(number of ``step()`` calls), applied at construction for step 0 - so with a warm-up the first optimizer
+    step runs at lr 0, exactly as the reference's loop does (train...sft.py:1100-1107: ``optimizer.step()`` then ``lr_scheduler.step()``)."""
+
+    def __init__(self, optimizer, lr_lambda, last_epoch: int = -1):
+        self.optimizer, self.lr_lambda = optimizer, lr_lambda
+        for g in optimizer.param_groups:
+            g.setdefault("initial_lr", g["lr"])
+        self.base_lrs = [g["initial_lr"] for g in optimizer.param_groups]
+        self.last_epoch = last_epoch
+        self.step()
+
+    def step(self):
+        self.last_epoch += 1
+        self._last_lr = [b * self.lr_lambda(self.last_epoch) for b in self.base_lrs]
+        for g, lr in zip(self.optimizer.param_groups, self._last_lr):
+            g["lr"] = lr
+
+    def get_last_lr(self):
+        return list(self._last_lr)
+
+    def state_dict(self):
+        return {"last_epoch": self.last_epoch, "base_lrs": list(self.base_lrs), "_last_lr": list(self._last_lr)}
+
+    def load_state_dict(self, sd):
+        self.last_epoch, self.base_lrs = int(sd["last_epoch"]), list(sd["base_lrs"])
+        self._last_lr = [b * self.lr_lambda(self.last_epoch) for b in self.base_lrs]
+        for g, lr in zip(self.optimizer.param_groups, self._last_lr):
+            g["lr"] = lr
+
+
+def get_scheduler(name, optimizer, step_rules=None, num_warmup_steps: Optional[int] = None, num_training_steps: Optional[int] = None,
+                  num_cycles: int = 1, power: float = 1.0, last_epoch: int = -1) -> LambdaSchedule:
+    """Drop-in for ``diffusers.optimization.get_scheduler`` as the train script calls it (:740-747) - same argument names and defaults;
+    ``piecewise_constant`` (``step_rules``) is not used by any shipped config and is refused."""
+    if step_rules is not None or getattr(name, "value", name) == "piecewise_constant":
+        raise ValueError("piecewise_constant / step_rules is not provided (no ORV config uses it)")
+    if getattr(name, "value", name) != "constant" and num_warmup_steps is None:
+        raise ValueError(f"{name} requires `num_warmup_steps`, please provide that argument.")
+    lr0 = optimizer.param_groups[0].get("initial_lr", optimizer.param_groups[0]["lr"])
+    return LambdaSchedule(optimizer, _lr_lambda(name, num_warmup_steps or 0, num_training_steps, num_cycles, power, lr0), last_epoch)

@@ -140,7 +140,7 @@ def sft_loss(transformer, scheduler, b: Batch, noise: torch.Tensor, timesteps: t
 
 def sft_step(transformer, scheduler, optimizer, b: Batch, generator: Optional[torch.Generator] = None,
              use_rope: bool = False, is_ofs_embed: bool = False, data_parallel: bool = False,
-             gradient_accumulation_steps: int = 1, micro_step: int = 0):
+             gradient_accumulation_steps: int = 1, micro_step: int = 0, lr_scheduler=None):
     """One micro-batch of the loop body (:863-1107).  ``optimizer`` is ``orv_amd.optim.FusedAdamW`` (global-norm clip inside,
     on device).  With ``data_parallel`` the flat bf16 gradient buffer is averaged over the RCCL group.
 
@@ -151,7 +151,11 @@ def sft_step(transformer, scheduler, optimizer, b: Batch, generator: Optional[to
     window (``(micro_step + 1) % N == 0``).  The backward-overlapped exchange needs the gradients of one backward to be
     final when a block closes, so it is used only without accumulation; with accumulation the accumulated buffer is
     exchanged once after the last backward (same bytes, one step later start).  The learning-rate scaling is the caller's,
-    as in the reference (:496-501 scales lr by accumulation x batch x processes when ``scale_lr``).  Returns
+    as in the reference (:496-501 scales lr by accumulation x batch x processes when ``scale_lr``); ``lr_scheduler``
+    (``orv_amd.optim.get_scheduler``: the reference's ``diffusers.optimization.get_scheduler`` call at :740-747, ``cosine_with_restarts``
+    in every shipped config) is stepped once per call, behind the optimizer, as ``lr_scheduler.step()`` at :1107 is - accelerate's wrapper
+    then skips it on non-synchronising micro-batches and steps it ``num_processes`` times on synchronising ones, which is why the script
+    multiplies the warm-up / total counts by ``num_processes``: here it advances by ``world`` on synchronising micro-batches.  Returns
     ``(loss, parts)``; ``parts["grad_norm"]`` is present on synchronising micro-batches only."""
     dev = b.video_latents.device
     noise = torch.randn(b.video_latents.shape, device=dev, dtype=torch.float32, generator=generator).to(b.video_latents.dtype)
@@ -173,4 +177,8 @@ def sft_step(transformer, scheduler, optimizer, b: Batch, generator: Optional[to
     if sync:
         parts["grad_norm"] = optimizer.step(average_over=world)       # (finishes) the exchange, averages, clips, updates
         optimizer.zero_grad()
+        if lr_scheduler is not None:                                  # :1107 through accelerate's AcceleratedScheduler (split_batches False)
+            for _ in range(world):
+                lr_scheduler.step()
+            parts["lr"] = lr_scheduler.get_last_lr()[0]
     return loss.detach(), parts

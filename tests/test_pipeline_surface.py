@@ -297,3 +297,69 @@ print("INSTALL-OK", len(names))
 '''
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "INSTALL-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_uninstall_restores_what_install_displaced():
+    """with a real ``diffusers.schedulers.scheduling_*_cogvideox`` / ``orv.utils`` in the environment, ``uninstall()`` must put
+    the originals back (modules, parent attributes and the RoPE helper patched in place) - fake "real" modules stand in for them here."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, types
+def mod(name, pkg=False, **attrs):
+    m = types.ModuleType(name)
+    if pkg: m.__path__ = []
+    for k, v in attrs.items(): setattr(m, k, v)
+    sys.modules[name] = m
+    if "." in name:
+        parent, _, leaf = name.rpartition(".")
+        setattr(sys.modules[parent], leaf, m)
+    return m
+mod("diffusers", pkg=True); mod("diffusers.schedulers", pkg=True)
+real_dpm = mod("diffusers.schedulers.scheduling_dpm_cogvideox", CogVideoXDPMScheduler="REAL-DPM")
+real_ddim = mod("diffusers.schedulers.scheduling_ddim_cogvideox", CogVideoXDDIMScheduler="REAL-DDIM")
+mod("orv", pkg=True)
+real_rope = lambda *a, **k: "REAL-ROPE"
+real_utils = mod("orv.utils", CONSOLE="REAL-CONSOLE", prepare_rotary_positional_embeddings=real_rope)
+import orv_amd, orv_amd.dropin as d, orv_amd.utils as ut
+orv_amd.install(); orv_amd.install()
+assert sys.modules["diffusers.schedulers.scheduling_dpm_cogvideox"] is not real_dpm
+assert sys.modules["orv.utils"] is real_utils and real_utils.prepare_rotary_positional_embeddings is ut.prepare_rotary_positional_embeddings
+assert real_utils.CONSOLE == "REAL-CONSOLE"
+d.uninstall()
+assert sys.modules["diffusers.schedulers.scheduling_dpm_cogvideox"] is real_dpm
+assert sys.modules["diffusers.schedulers"].scheduling_dpm_cogvideox is real_dpm
+assert sys.modules["diffusers.schedulers.scheduling_ddim_cogvideox"] is real_ddim
+assert sys.modules["orv.utils"] is real_utils and real_utils.prepare_rotary_positional_embeddings is real_rope
+assert "orv.models.cogvideox_control" not in sys.modules and not hasattr(sys.modules["orv"], "models")
+print("UNINSTALL-OK")
+'''
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "UNINSTALL-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_graph_cache_key_sees_structural_edits():
+    """ADVICE r5: ``GraphedTransformer._weights_version`` must move for edits that bypass ``register_parameter`` - a pre-built submodule
+    attached (``blk.ff = other``), blocks truncated, ``del m.weight``, a write into ``_parameters`` - or a stale graph is replayed."""
+    import torch
+    from torch import nn
+    from orv_amd.cogvideox_control import CogVideoXTransformer3DModelTraj, GraphedTransformer, FeedForward
+    cfg = dict(num_attention_heads=2, attention_head_dim=64, in_channels=8, out_channels=4, num_layers=3, text_embed_dim=32,
+               time_embed_dim=32, sample_width=12, sample_height=8, sample_frames=9, max_text_seq_length=8)
+    m = CogVideoXTransformer3DModelTraj(**cfg)
+    g = GraphedTransformer(m)
+    v0 = g._weights_version()
+    assert g._weights_version() == v0
+    m.transformer_blocks[0].ff = FeedForward(m.inner_dim)                        # pre-built submodule: Module.__setattr__ -> register_module hook
+    v1 = g._weights_version()
+    assert v1 != v0
+    del m.transformer_blocks[2:]                                                 # ModuleList.__delitem__ rewrites _modules directly
+    v2 = g._weights_version()
+    assert v2 != v1 and v2[0] < v1[0]
+    del m.transformer_blocks[0].ff.net[2].bias                                   # Module.__delattr__
+    v3 = g._weights_version()
+    assert v3 != v2 and v3[0] == v2[0] - 1
+    m.transformer_blocks[0].ff.net[2]._parameters["bias"] = nn.Parameter(torch.zeros(m.inner_dim))     # behind every hook
+    v4 = g._weights_version()
+    assert v4 != v3 and v4[0] == v2[0]
+    assert g._weights_version() == v4
