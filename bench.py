@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -521,6 +522,7 @@ def main():
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
     seen = ranks_seen(world, dev)
+    softmax_census = model.softmax_kernel_census(rope=False)      # which softmax form the timed weights selected, layer by layer
     vae_leg = None
     if not args.no_vae and args.layers == 30:
         vae_leg = vae_decode_leg(lat, dev, wall, args.steps, world, B, barrier)
@@ -560,7 +562,7 @@ def main():
         from orv_amd import cogvideox_control as cc
         keep_sb = cc.Attention.score_bound
         try:
-            cc.Attention.score_bound = lambda self, scale: None
+            cc.Attention.score_bound = lambda self, scale, rope=True: None
             so = make_step(default_forward(model), B, image_latents, prompt, controls)
             legs["attn_online"] = {"workload": "configs[1] at B = %d with the online-softmax attention kernel in every block (no score bound), 10 steps" % B,
                                    "ms_per_step": round(timed_steps(so, latents, 3, 10), 3),
@@ -568,6 +570,31 @@ def main():
             del so
         finally:
             cc.Attention.score_bound = keep_sb
+        # attn_mixed: trained-LIKE qk-LayerNorm gains (no checkpoint is reachable here): per layer max|gamma_q gamma_k| drawn log-uniformly in
+        # [1, 16] so that the layers' bounds straddle the fixed-shift limit; the parameters are restored afterwards
+        try:
+            gmix = torch.Generator().manual_seed(46)
+            saved = []
+            with torch.no_grad():
+                for blk in model.transformer_blocks:
+                    at_ = blk.attn1
+                    saved.append((at_.norm_q.weight.detach().clone(), at_.norm_k.weight.detach().clone()))
+                    tgt = float(torch.exp(torch.rand(1, generator=gmix) * math.log(16.0)))
+                    pert = 1.0 + 0.15 * torch.randn(2, 64, generator=gmix)
+                    at_.norm_q.weight.copy_((pert[0].abs() * math.sqrt(tgt)).to(dev, torch.bfloat16))
+                    at_.norm_k.weight.copy_((pert[1].abs() * math.sqrt(tgt)).to(dev, torch.bfloat16))
+            census = model.softmax_kernel_census(rope=False)
+            sm = make_step(default_forward(model), B, image_latents, prompt, controls)
+            legs["attn_mixed"] = {"workload": "configs[1] at B = %d with trained-like qk-LayerNorm gains (per-layer max|gamma_q gamma_k| log-uniform in [1, 16]), 10 steps" % B,
+                                  "ms_per_step": round(timed_steps(sm, latents, 3, 10), 3), **census}
+            del sm
+        except Exception as e:
+            legs["attn_mixed"] = {"error": repr(e)[:300]}
+        finally:
+            with torch.no_grad():
+                for blk, (wq_, wk_) in zip(model.transformer_blocks, saved):
+                    blk.attn1.norm_q.weight.copy_(wq_)
+                    blk.attn1.norm_k.weight.copy_(wk_)
         # cond: BASELINE configs[3] (config/traj_image_condfull_2b_finetune.yaml: visual_guidance, control_keys depth + label;
         # cogvideox_control.py:828-858) - a second 2B model with the guidance fuse, depth / label maps through the same patch-embed
         try:
@@ -585,7 +612,7 @@ def main():
         except Exception as e:      # a leg must never take the headline line down
             legs["cond"] = {"error": repr(e)[:300]}
         # train: configs[2] on this GPU (the fused optimizer moves the parameters into its flat buffers: after the inference legs)
-        legs["train"] = train_mode(args, model, latents, image_latents, prompt, actions, sched, dev, rank, world, leg=(3, 5))
+        legs["train"] = train_mode(args, model, latents, image_latents, prompt, actions, sched, dev, rank, world, leg=(3, 12))      # 12 timed steps: resolves a 2 % change
         # train_5b_ckpt: configs[4] (CogVideoX1.5-5B, DROID 256x384x29f, p_t = 2, RoPE, ofs, activation checkpointing), 1 + 2 steps
         try:
             import copy
@@ -697,8 +724,11 @@ def main():
             "kernel_timeline": f"HIP events on the launch stream over a separate eager loop of {n_tl} steps after the timed region",
             "lib": {"path": os.path.relpath(LIB_PATH, ROOT), "orv_version": int(lib().orv_version())},
             "pmc_source": pmc_source,
+            "attention_softmax": {**softmax_census, "note": "random-init qk-LayerNorm (gamma 1): every layer takes the fixed-shift kernel; "
+                                  "a checkpoint layer whose bound exceeds the limit runs the online kernel (leg attn_online = all of them, "
+                                  "leg attn_mixed = trained-like gains straddling the limit)"},
             "vae_decode": vae_leg,
-            "b1": legs.get("b1"), "attn_online": legs.get("attn_online"), "cond": legs.get("cond"), "train": legs.get("train"),
+            "b1": legs.get("b1"), "attn_online": legs.get("attn_online"), "attn_mixed": legs.get("attn_mixed"), "cond": legs.get("cond"), "train": legs.get("train"),
             "train_5b_ckpt": legs.get("train_5b_ckpt"),
         }
         if world == 1 and not args.no_cpu_baseline:

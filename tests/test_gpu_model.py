@@ -347,10 +347,20 @@ def test_pipeline_hands_latents_to_a_caller_supplied_vae():
         bare(latents=lat0.clone(), output_type="pt", **args)
 
 
+def _frame_channel_worst(out, ref):
+    """Worst rel-L2 over single (frame, channel) slices of [1, T, C, H, W] - the second, local, bound of the forward goldens."""
+    d = (out.float() - ref.float()).flatten(3).norm(dim=3)
+    return float((d / ref.float().flatten(3).norm(dim=3).clamp_min(1e-6)).max())
+
+
 def test_full_depth_2b_vs_oracle_and_batch_consistency():
     """BASELINE configs[1] at its real depth: all 30 blocks of CogVideoX-2B (bench weights / inputs, S=3226) through the HIP path
-    against the fp32 CPU oracle (rel-L2 <= 2e-2; measured 1.45e-2), and the B=4 launch configuration (other GEMM
-    tiles, other attention grid) against four B=1 calls, clip by clip."""
+    against the fp32 CPU oracle, and the B=4 launch configuration (other GEMM tiles, other attention grid, other packed-operand plan)
+    against four B=1 calls, clip by clip.
+    Round 6 (VERDICT r5 #4a/b): THREE clips at their own timesteps are compared with the oracle - t = 500, and the two hard ends of the
+    trailing schedule, t = 999 (pure noise, alpha_bar = 0) and t = 259 - rel-L2 <= 2e-2 AND worst single (frame, channel) <= 4e-2, both
+    printed; the batch check is ``torch.equal`` (every kernel is deterministic and batch independent; the kernels a one-clip call takes
+    in place of the four-clip ones are held to them bit for bit in tests/test_gpu_kernels.py)."""
     import os
     import bench
     dev = torch.device("cuda:0")
@@ -361,19 +371,118 @@ def test_full_depth_2b_vs_oracle_and_batch_consistency():
     ts = torch.tensor([500, 999, 19, 259], device=dev)
     with torch.no_grad():
         model.action_embed.forced_mask = torch.zeros(4, dtype=torch.bool)
-        out4 = model(x, prompt, {"actions": actions}, ts, return_dict=False)[0].float().cpu()
+        out4 = model(x, prompt, {"actions": actions}, ts, return_dict=False)[0].cpu()
         model.action_embed.forced_mask = torch.zeros(1, dtype=torch.bool)
-        singles = [model(x[b:b + 1], prompt[b:b + 1], {"actions": actions[b:b + 1]}, ts[b:b + 1], return_dict=False)[0].float().cpu()
+        singles = [model(x[b:b + 1], prompt[b:b + 1], {"actions": actions[b:b + 1]}, ts[b:b + 1], return_dict=False)[0].cpu()
                    for b in range(4)]
+    diffs = [float((out4[b:b + 1].float() - singles[b].float()).abs().max()) for b in range(4)]
+    print("B=4 vs 4 x B=1, max |diff| per clip: " + " ".join(f"{d:.3e}" for d in diffs))
     for b in range(4):
-        assert rel_l2(out4[b:b + 1], singles[b]) <= 5e-3, b
+        assert torch.equal(out4[b:b + 1], singles[b]), (b, diffs)
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+    torch.set_num_threads(max(1, min(32, (os.cpu_count() or 2) // 2)))
+    for b in (0, 1, 3):
+        with torch.no_grad():
+            ref = dit.dit_forward(sd, dict(model.config), x[b:b + 1].float().cpu(), prompt[b:b + 1].float().cpu(), ts[b:b + 1].cpu(),
+                                  actions=actions[b:b + 1].float().cpu(), is_mask=torch.zeros(1, dtype=torch.bool))[0]
+        err, worst = rel_l2(singles[b].float(), ref), _frame_channel_worst(singles[b], ref)
+        print(f"full-depth clip {b} t={int(ts[b])}: rel-L2(HIP, fp32 oracle) = {err:.4e}, worst (frame, channel) = {worst:.4e}")
+        assert err <= 2e-2 and worst <= 4e-2, (b, err, worst)
+
+
+def test_full_depth_condfull_2b_vs_oracle():
+    """BASELINE configs[3] at its real depth (VERDICT r5 #4c): the occupancy-conditioned CogVideoX-2B (visual_guidance, depth + label maps
+    through the shared patch-embed, ``initial_combine_linear`` 3840 -> 1920; cogvideox_control.py:828-858) - all 30 blocks, one clip, vs the
+    fp32 oracle.  Until now full depth was only checked by "the loss descends"; the guidance fuse vs the oracle at one block."""
+    import os
+    import bench
+    dev = torch.device("cuda:0")
+    torch.manual_seed(43)
+    model = bench.build_model({**bench.CFG_2B, "visual_guidance": True, "num_control_keys": 2}, dev)
+    model.action_embed.forced_mask = torch.zeros(1, dtype=torch.bool)
+    lat, img, prompt, actions = bench.synthetic_inputs(1, dev, BF)
+    g = torch.Generator().manual_seed(44)
+    depths = torch.randn(1, 5, 32, 40, 60, generator=g).to(dev, BF)
+    labels = torch.randn(1, 5, 32, 40, 60, generator=g).to(dev, BF)
+    x = torch.cat([lat, img], dim=2)
+    ts = torch.tensor([739], device=dev)
     with torch.no_grad():
-        ref = dit.dit_forward(sd, dict(model.config), x[:1].float().cpu(), prompt[:1].float().cpu(), ts[:1].cpu(),
-                              actions=actions[:1].float().cpu(), is_mask=torch.zeros(1, dtype=torch.bool))[0]
-    err = rel_l2(singles[0], ref)
-    print(f"full-depth rel-L2(HIP, fp32 oracle) = {err:.4e}")
+        out = model(x, prompt, {"actions": actions, "depths": depths, "labels": labels}, ts, return_dict=False)[0].cpu()
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    torch.set_num_threads(max(1, min(32, (os.cpu_count() or 2) // 2)))
+    with torch.no_grad():
+        ref = dit.dit_forward(sd, dict(model.config), x.float().cpu(), prompt.float().cpu(), ts.cpu(), actions=actions.float().cpu(),
+                              is_mask=torch.zeros(1, dtype=torch.bool), depths=depths.float().cpu(), labels=labels.float().cpu())[0]
+    err, worst = rel_l2(out.float(), ref), _frame_channel_worst(out, ref)
+    print(f"full-depth configs[3]: rel-L2(HIP, fp32 oracle) = {err:.4e}, worst (frame, channel) = {worst:.4e}")
+    assert err <= 2e-2 and worst <= 4e-2
+
+
+def test_trained_like_qk_layernorm_mixes_static_and_online_softmax_layers():
+    """VERDICT r5 weak #2 / #4d: the headline rides the fixed-shift softmax, valid while the qk-LayerNorm bound stays <= 90 log2 units.  No
+    checkpoint is reachable, so trained-LIKE statistics are drawn: 6 full-width blocks (D = 1920, S = 3226) whose per-layer
+    max|gamma_q gamma_k| (one outlier channel per layer) grows from 1 to 14 - the first layers stay on the static kernel (packed output -> d8 out-projection), the last
+    ones fall to the online kernel (row-major output -> t8 out-projection) inside ONE forward - against the fp32 oracle."""
+    import math
+    import bench
+    dev = torch.device("cuda:0")
+    model = bench.build_model({**bench.CFG_2B, "num_layers": 6}, dev)
+    model.action_embed.forced_mask = torch.zeros(1, dtype=torch.bool)
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for i, blk in enumerate(model.transformer_blocks):
+            tgt = [1.0, 2.5, 5.0, 8.0, 11.0, 14.0][i]
+            cstar = int(torch.randint(0, 64, (1,), generator=g))      # ONE outlier channel carries the layer's max |gamma_q gamma_k| (the way
+            for n_ in (blk.attn1.norm_q, blk.attn1.norm_k):           # trained LayerNorm gains look): the bound grows, typical scores do not
+                w_ = (1.0 + 0.1 * torch.randn(64, generator=g)).abs().clamp(max=1.0)
+                w_[cstar] = math.sqrt(tgt)
+                n_.weight.copy_(w_.to(dev, BF))
+                n_.bias.copy_((0.3 * torch.randn(64, generator=g)).to(dev, BF))
+    census = model.softmax_kernel_census(rope=False)
+    print("census:", census)
+    assert census["layers_static"] >= 2 and census["layers_online"] >= 2, census
+    lat, img, prompt, actions = bench.synthetic_inputs(1, dev, BF)
+    x = torch.cat([lat, img], dim=2)
+    ts = torch.tensor([419], device=dev)
+    with torch.no_grad():
+        out = model(x, prompt, {"actions": actions}, ts, return_dict=False)[0].cpu()
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        ref = dit.dit_forward(sd, dict(model.config), x.float().cpu(), prompt.float().cpu(), ts.cpu(), actions=actions.float().cpu(),
+                              is_mask=torch.zeros(1, dtype=torch.bool))[0]
+    err, worst = rel_l2(out.float(), ref), _frame_channel_worst(out, ref)
+    print(f"mixed static / online layers: rel-L2 = {err:.4e}, worst (frame, channel) = {worst:.4e}")
+    assert err <= 2e-2 and worst <= 4e-2
+
+
+def test_one_block_480x640_vs_oracle():
+    """A shape the shipped configs use and no test touched (VERDICT r5 missing #5): config/traj_image_bridge2_480-640_2b_finetune.yaml
+    (480 x 640 x 17 frames -> latents 5 x 60 x 80, 6000 video + 226 text tokens, S = 6226) at CogVideoX-2B width, one block, two clips (M =
+    12452: the tile planner and the attention grid have never seen it) vs the fp32 oracle."""
+    dev = torch.device("cuda:0")
+    from orv_amd.cogvideox_control import CogVideoXTransformer3DModelTraj
+    torch.manual_seed(11)
+    cfg = dict(num_layers=1, in_channels=32, sample_height=60, sample_width=80, sample_frames=17, modulate_encoder_hidden_states=True)
+    m = CogVideoXTransformer3DModelTraj(**cfg)
+    for n_, p in m.named_parameters():
+        if p.ndim >= 2:
+            p.data.normal_(0, 0.02)
+        p.data.copy_(p.data.to(BF).float())
+    B = 2
+    x = torch.randn(B, 5, 32, 60, 80).to(BF).float()
+    e = (torch.randn(B, 226, 4096) * 0.2).to(BF).float()
+    a = torch.randn(B, 16, 7).to(BF).float()
+    ts = torch.tensor([620, 40])
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = dit.dit_forward(sd, dict(m.config), x, e, ts, actions=a, is_mask=torch.zeros(B, dtype=torch.bool))[0]
+    m = m.to(dev, BF).eval()
+    m.action_embed.forced_mask = torch.zeros(B, dtype=torch.bool)
+    with torch.no_grad():
+        out = m(x.to(dev, BF), e.to(dev, BF), {"actions": a.to(dev)}, ts.to(dev), return_dict=False)[0]
+    assert out.shape == ref.shape == (B, 5, 16, 60, 80)
+    err = rel_l2(out, ref)
+    print(f"480x640 one block: rel-L2 = {err:.4e}")
     assert err <= 2e-2
 
 

@@ -293,7 +293,11 @@ def test_attention_score_bound_holds_on_random_layernorm_outputs():
         with torch.no_grad():
             for p_, sc in ((at.norm_q.weight, 1.0), (at.norm_q.bias, 0.5), (at.norm_k.weight, 1.0), (at.norm_k.bias, 0.5)):
                 p_.copy_(torch.randn(64, generator=g) * sc * (0.3 + trial * 0.3))
-        bound = at.score_bound(0.125)
+        bound, bound_plain = at.score_bound(0.125), at.score_bound(0.125, rope=False)
+        # round 6: per-channel (no RoPE) <= per-pair (any rotation) <= the round-5 product of per-vector maxima
+        gq_, bq_, gk_, bk_ = (t.detach() for t in (at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias))
+        old = 1.02 * 0.125 * 1.4426950408889634 * float((8 * gq_.abs().max() + bq_.norm()) * (8 * gk_.abs().max() + bk_.norm()))
+        assert bound_plain <= bound * (1 + 1e-6) and bound <= old * (1 + 1e-6), (bound_plain, bound, old)
         x = torch.randn(4000, 64, generator=g) * torch.rand(4000, 1, generator=g) * 10
         x[:64] = torch.eye(64) * 100                           # one-hot rows: xhat puts almost all its norm on one channel
         x[64:128] = torch.sign(at.norm_q.weight.detach() * at.norm_k.weight.detach()) * torch.rand(64, 64, generator=g)
@@ -302,9 +306,14 @@ def test_attention_score_bound_holds_on_random_layernorm_outputs():
             qq, kk = ln(x, at.norm_q), ln(x, at.norm_k)
             ang = torch.rand(4000, 32, generator=g) * 6.28
             rot = lambda v, a: torch.stack([v[:, 0::2] * a.cos() - v[:, 1::2] * a.sin(), v[:, 0::2] * a.sin() + v[:, 1::2] * a.cos()], -1).flatten(1)
-            for a_, b_ in ((qq, kk), (rot(qq, ang), rot(kk, ang.flip(0)))):
+            # adversarial rows for the per-channel term: all of xhat's norm on the channel (pair) where |gamma_q gamma_k| peaks
+            cstar = int((gq_ * gk_).abs().argmax())
+            x[128:130] = 0
+            x[128, cstar], x[129, cstar ^ 1] = 50.0, -50.0
+            qq, kk = ln(x, at.norm_q), ln(x, at.norm_k)
+            for a_, b_, bd in ((qq, kk, bound_plain), (qq, kk, bound), (rot(qq, ang), rot(kk, ang.flip(0)), bound)):
                 s = (a_ @ b_.t()).abs().max().item() * 0.125 * 1.4426950408889634
-                assert s <= bound, (trial, s, bound)
+                assert s <= bd, (trial, s, bd)
     many = [Attention(128, 2, 64, True, True) for _ in range(5)]
     prime_score_bounds(many, 0.125)                            # batched form == per-module form
     for m in many:
