@@ -589,9 +589,13 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             plan["ffn"] = True
         # out-projection (K = D: 30 K-tiles, epilogue-heavy): where the row-major model picks the 256 x 192 t8 tile (B = 4: -6 %) and where the
         # 256 x 128 d8 tiles fit ONE round of the CUs (B = 1: 0.037 -> 0.033 ms); in between (B = 2: 390 tiles) the row-major kernel wins
-        if ops.gemm_kernel_name(M, D, D, 2, a_packed=True) is not None:
+        kn_out = ops.gemm_kernel_name(M, D, D, 2, a_packed=True)
+        if kn_out is not None:
             one_round = D % 128 == 0 and -(-M // 256) * (D // 128) <= _num_cus()
-            if ops.gemm_kernel_name(M, D, D, 2) == t8_192 or one_round:
+            want_out = os.environ.get("ORV_PACKED_OUT", "auto")
+            # round 6: measured again with the 192-row d8 tiles (gemm_d8r192_kernel: 510 tiles of 192 x 128 at two clips) - the row-major kernel
+            # still wins there (0.0603 vs 0.0610 ms, step 22.41 vs 22.50 ms, profiles/r6_gemm_d8_r192.txt); ORV_PACKED_OUT = 0 / 1 force it
+            if want_out == "1" or (want_out == "auto" and (ops.gemm_kernel_name(M, D, D, 2) == t8_192 or one_round)):
                 plan["out"] = True
         # the LayerNorm outputs (A of q | k | v and of FFN1): the producer is a row-per-wave VALU kernel whose packed store scatters 16-byte
         # pieces - a loss at B = 4 and B = 2 (profiles/r5_model_ab_packed_ln.txt, r5_packed_qkv_b1.txt: +2.7 % / +1.2 % per step).  At ONE clip the
@@ -600,7 +604,8 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         if D <= 2048 and D % 192 == 0:
             want = os.environ.get("ORV_PACKED_QKV", _PACKED_QKV_DEFAULT)
             single_round = -(-M // 192) * (2 * D // 256) <= _num_cus()
-            if (want == "1" or (want == "auto" and single_round)) and ops.gemm_kernel_name(M, 3 * D, D, 4, a_packed=True) is not None:
+            kn_qkv = ops.gemm_kernel_name(M, 3 * D, D, 4, a_packed=True)
+            if (want == "1" or (want == "auto" and single_round)) and kn_qkv is not None:
                 plan["qkv"] = True
             if (plan["ffn"] and os.environ.get("ORV_PACKED_FFN1", _PACKED_FFN1_DEFAULT) == "1"
                     and ops.gemm_kernel_name(M, FF, D, 1, a_packed=True, c_packed=True) is not None):

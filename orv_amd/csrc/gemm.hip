@@ -1274,6 +1274,13 @@ struct GemmCand { int ring, bm, bn; float rate; int min_rounds; };
 #define ORV_D8_RATE_128 1.20f
 #endif
 #define D8_RATE_128 ORV_D8_RATE_128
+// 192-row d8 tiles (gemm_d8r192_kernel, round 6): 3/4 of the MFMAs of the 256-row sibling in ~0.81-0.85 of its time
+#ifndef ORV_D8R192_RATE_192
+#define ORV_D8R192_RATE_192 1.12f
+#endif
+#ifndef ORV_D8R192_RATE_128
+#define ORV_D8R192_RATE_128 1.11f
+#endif
 // relative rates of the 192-row t8 tiles (gemm_t8r192_kernel): a tile does 3 / 4 of the MFMAs of its 256-row sibling on 7 / 8 of the LDS-DMA bytes
 #ifndef ORV_T8R192_RATE_256
 #define ORV_T8R192_RATE_256 1.20f
@@ -1340,6 +1347,9 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
         {4, 256, 256, 0.01f, 0},
         // ring = 5: gemm_d8.hip (round 5) - A straight to registers two K-tiles ahead, W through four LDS buffers; needs K % 192 == 0
         {5, 256, 256, D8_RATE_256, 0}, {5, 256, 192, D8_RATE_192, 0}, {5, 256, 128, D8_RATE_128, 0},
+        // the d8 kernel on 192-row tiles (gemm_d8r192_kernel, round 6): the first wave of every SIMD owns two 16-row blocks, the second one.
+        // M = 3226 (one clip): N = 1920 is 255 tiles of 192 x 128 (one FULL round; 256 x 128 leaves 61 CUs idle), q | k | v 510 of 192 x 192
+        {5, 192, 192, ORV_D8R192_RATE_192, 0}, {5, 192, 128, ORV_D8R192_RATE_128, 0},
         // ring = 2: the phased (8-phase, BK = 64) persistent kernel; needs an even number of K-tiles
         // (256x384 does not fit: 192 accumulator + 64 fragment registers of the 256 a wave gets at two waves per SIMD)
         {2, 256, 256, 1.10f, 0}, {2, 256, 128, 0.80f, 0},
@@ -1365,6 +1375,8 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
     if (no_r192 < 0) { const char* e = getenv("ORV_GEMM_R192"); no_r192 = (e && atoi(e) == 0) ? 1 : 0; }
     static int no_d8 = -1;       // ORV_GEMM_D8=0: A/B switch for the d8 kernel
     if (no_d8 < 0) { const char* e = getenv("ORV_GEMM_D8"); no_d8 = (e && atoi(e) == 0) ? 1 : 0; }
+    static int no_d8r192 = -1;   // ORV_GEMM_D8R192=0: A/B switch for the 192-row d8 tiles
+    if (no_d8r192 < 0) { const char* e = getenv("ORV_GEMM_D8R192"); no_d8r192 = (e && atoi(e) == 0) ? 1 : 0; }
     static int no384 = -1;   // ORV_GEMM_BN384=0: A/B switch for the 384-wide variant
     if (no384 < 0) { const char* e = getenv("ORV_GEMM_BN384"); no384 = (e && atoi(e) == 0) ? 1 : 0; }
     const int ncu = orv_num_cus();
@@ -1383,6 +1395,8 @@ static const GemmCand* choose_tile(int M, int N, int K, int epilogue = 0, int he
         // packed C from row-major A: only the t8 kernel's 256-wide GELU epilogue writes it
         if (cpacked && !packed && !(c.ring == 3 && c.bn == 256 && epilogue == 1)) continue;
         if (c.ring == 5 && (K % 192 != 0 || no_d8)) continue;
+        // 192-row d8 tiles: the packed A (and C) buffers hold ceil(M / 256) * 256 row slots and neither A loads nor the packed store are masked
+        if (c.ring == 5 && c.bm == 192 && (no_d8r192 || epilogue == 3 || (long)((M + 191) / 192) * 192 > (long)((M + 255) / 256) * 256)) continue;
         // epilogue 4 normalises whole 64-wide heads inside a wave (BN / 2 columns) that must not straddle q | k | v
         if (epilogue == 4 && c.ring != 5 && ((c.bm == 192 && c.ring != 3) || (c.bn / 2) % 64 != 0 || (heads * 64) % (c.bn / 2) != 0)) continue;
         if (force_bm && (c.ring != force_ring || c.bm != force_bm || c.bn != force_bn)) continue;
@@ -1426,6 +1440,7 @@ static bool plan_gemm(int M, int N, int K, int epilogue, int heads, const GemmCa
 static void cand_name(const GemmCand* c, int epilogue, char* buf, int len) {
     if (c->ring == 3 && c->bm == 192) snprintf(buf, len, "gemm_t8r192_kernel<%d, %d>", c->bn, epilogue);
     else if (c->ring == 3) snprintf(buf, len, "gemm_t8_kernel<%d, %d>", c->bn, epilogue);
+    else if (c->ring == 5 && c->bm == 192) snprintf(buf, len, "gemm_d8r192_kernel<%d, %d>", c->bn, epilogue);
     else if (c->ring == 5) snprintf(buf, len, "gemm_d8_kernel<%d, %d>", c->bn, epilogue);
     else if (c->ring == 2) snprintf(buf, len, "gemm_ph_kernel<%d, %d>", c->bn, epilogue);
     else if (c->ring) snprintf(buf, len, "gemm_pp_kernel<%d, %d, %d>", c->bn, c->bn == 384 ? 4 : 5, epilogue);
@@ -1467,7 +1482,7 @@ static int gemm_dispatch(GemmArgs a, const GemmCand* best, int epilogue, hipStre
     }
     if (best->ring == 3) return launch_t8(a, best->bn, epilogue, st, best->bm);
     if (best->ring == 4) return launch_t4(a, epilogue, st);
-    if (best->ring == 5) return launch_d8(a, best->bn, epilogue, st);
+    if (best->ring == 5) return launch_d8(a, best->bn, epilogue, st, best->bm);
     if (best->ring == 2) {
         if (best->bn == 256) return launch_ph<256>(a, epilogue, st);
         return launch_ph<128>(a, epilogue, st);

@@ -82,7 +82,8 @@ int launch_t8(const GemmArgs& a, int bn, int epi, hipStream_t st, int bm = 256);
 int launch_t8_tn(const GemmArgs& a, int bn, int accumulate, hipStream_t st);
 // gemm_t8.hip: the four-wave 256 x 256 experiment (ORV_GEMM_TILE=4,256,256)
 int launch_t4(const GemmArgs& a, int epi, hipStream_t st);
-// gemm_d8.hip: gemm_d8_kernel<BN, EPI> (A straight to registers, W through four LDS buffers; BN = 256 or 192, K % 192 == 0)
-int launch_d8(const GemmArgs& a, int bn, int epi, hipStream_t st);
+// gemm_d8.hip: gemm_d8_kernel<BN, EPI> (A straight to registers, W through four LDS buffers; BN = 256, 192 or 128, K % 192 == 0) or, bm = 192,
+// gemm_d8r192_kernel<BN, EPI> (BN = 192 or 128); a.tiles_m must be set for bm
+int launch_d8(const GemmArgs& a, int bn, int epi, hipStream_t st, int bm = 256);
 
 }  // namespace orv_gemm

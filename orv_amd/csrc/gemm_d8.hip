@@ -88,8 +88,8 @@ constexpr bool d8_rlds() {
 #endif
 }
 
-template <int BN, int EPI>
-__device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][BN / 16], const int row0, const int col0, const int lane,
+template <int BN, int EPI, int RB = 2>
+__device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[RB][BN / 16], const int row0, const int col0, const int lane,
                                             char* const scr, const char* const rslab = nullptr) {
     constexpr int NG = BN / 64;
     constexpr bool RLDS = d8_rlds<BN, EPI>();
@@ -103,10 +103,10 @@ __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][B
     }
     const int roff0 = rr8 * 256 + (((2 * c) ^ rr8) << 4), roff1 = rr8 * 256 + (((2 * c + 1) ^ rr8) << 4);      // + j * 2048
 
-    long orow[2][2];
-    bool valid[2][2];
+    long orow[RB][2];
+    bool valid[RB][2];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int m = row0 + rb * 16 + 8 * j + rr8;
@@ -121,7 +121,7 @@ __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][B
     bool gate_lane[2] = {false, false};
     if (EPI == 2 && p.gate) {
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+        for (int rb = 0; rb < RB; ++rb) {
             const int mf = __builtin_amdgcn_readfirstlane(row0 + rb * 16), ml = min(mf + 15, p.M - 1);
             long of = min(mf, p.M - 1), ol = ml;
             if (p.c_rows > 0) {
@@ -137,11 +137,11 @@ __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][B
     }
     // row operands (residual / GELU-adjoint input) of one 64-column group: requested one group ahead
     constexpr int RS = (D8_RSETS == 0) ? (BN <= 192 ? NG : 1) : D8_RSETS;    // D8_RSETS = 0: every group's rows up front where the registers allow (BN <= 192)
-    uint4 r8[RS][2][2];                                 // [set][rb][j]
-    auto load_rows = [&](int cg, uint4 (&dst)[2][2]) {
+    uint4 r8[RS][RB][2];                                // [set][rb][j]
+    auto load_rows = [&](int cg, uint4 (&dst)[RB][2]) {
         const int col8 = col0 + 64 * cg + 8 * c;
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int mc = min(row0 + rb * 16 + 8 * j + rr8, p.M - 1);
@@ -152,11 +152,11 @@ __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][B
             }
     };
     // RLDS: rows of group cg out of the slab (the DMA was issued by the kernel / by the previous group), then the next group's DMA
-    auto take_rows = [&](int cg, uint4 (&dst)[2][2]) {
+    auto take_rows = [&](int cg, uint4 (&dst)[RB][2]) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int j = 0; j < 2; ++j) dst[rb][j] = *(const uint4*)(rslab + (rb * 16 + 8 * j + rr8) * 128 + c * 16);
         if (cg + 1 < NG) {
@@ -205,7 +205,7 @@ __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][B
         for (int e = 0; e < 8; ++e) g8[e] = 1.f;
 
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+        for (int rb = 0; rb < RB; ++rb) {
 #pragma unroll
             for (int blk = 0; blk < 4; ++blk) *(f32x4*)(scr + woff[blk]) = acc[rb][4 * cg + blk];
             float v[2][8];
@@ -296,8 +296,8 @@ __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][B
 // cogvideox_control.py:439-440).  In the accumulator layout lane (r16, g) holds columns 32 P + 8 g + (0..7) of row r16 for the block pair P -
 // that IS packed block (row block, column block col0 / 32 + P) at byte 16 (r16 + 16 g) = 16 lane: one lane-linear, fully contiguous 1-KiB
 // store per block pair, no LDS transpose, no row mask (the buffer has tiles_m * 256 rows; rows >= M hold finite garbage nobody reads).
-template <int BN, int EPI>
-__device__ __forceinline__ void d8_epilogue_packed(const GemmArgs& p, f32x4 (&acc)[2][BN / 16], const int row0, const int col0, const int lane) {
+template <int BN, int EPI, int RB = 2>
+__device__ __forceinline__ void d8_epilogue_packed(const GemmArgs& p, f32x4 (&acc)[RB][BN / 16], const int row0, const int col0, const int lane) {
     const int g = lane >> 4;
     const long nblk = p.ldc / 32;                      // column blocks per row block (ldc = N of the packed matrix)
 #pragma unroll
@@ -307,7 +307,7 @@ __device__ __forceinline__ void d8_epilogue_packed(const GemmArgs& p, f32x4 (&ac
         for (int e = 0; e < 8; ++e) b8[e] = 0.f;
         if (p.bias) d8_unpack8(*(const uint4*)(p.bias + col0 + 32 * P + 8 * g), b8);
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+        for (int rb = 0; rb < RB; ++rb) {
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = acc[rb][2 * P + (e >> 2)][e & 3] + b8[e];
@@ -321,8 +321,16 @@ __device__ __forceinline__ void d8_epilogue_packed(const GemmArgs& p, f32x4 (&ac
     }
 }
 
-template <int BN, int EPI>
-__global__ __launch_bounds__(512) void gemm_d8_kernel(const GemmArgs p) {
+// The kernel body for a wave that owns RB 16-row blocks of a BM-row tile.  BM = 256: every wave RB = 2 (rows 32 wave ..).  BM = 192 (round 6,
+// gemm_d8r192_kernel): the FIRST wave of every SIMD (waves 0-3) owns two row blocks (rows 32 wave ..), the SECOND (waves 4-7) one (rows 128 +
+// 16 (wave - 4) ..) - three row blocks per SIMD instead of four, so a tile costs 3/4 of the matrix time on every SIMD alike.  M = 3226 (one
+// clip) is 17 such row tiles: 255 tiles of 192 x 128 (FFN2 / out-projection: ONE full round instead of 195 of 256 CUs busy), 510 of 192 x 192
+// for q | k | v (two rounds of 3/4 tiles instead of 1.52 rounds of whole ones).  Both roles run the same W stream, barriers and K loop.
+template <int BN, int EPI, int RB, int BM>
+__device__ __forceinline__ void d8_body(const GemmArgs& p, char* const smem) {
+    static_assert(BM == 256 || BM == 192, "tile rows");
+    static_assert(!(d8_rlds<BN, EPI>() && BM != 256), "the residual slab path is written for 32-row waves");
+    constexpr int NA = 2 * RB;                        // A loads per wave and K-tile
     constexpr int NCB = BN / 16;                      // 16-column blocks of the tile (16 / 12)
 #ifndef ORV_D8_CBP256
 #define ORV_D8_CBP256 2
@@ -335,9 +343,9 @@ __global__ __launch_bounds__(512) void gemm_d8_kernel(const GemmArgs p) {
     constexpr int BUFSZ = BN * 128;                   // one K-tile of W: BN rows x 64 k
     constexpr int ND = BN / 64;                       // 1-KiB DMA pieces per wave and K-tile (BN / 8 pieces over 8 waves)
     constexpr int SCR = 4 * BUFSZ;                    // epilogue scratch: 8 waves x 4 KiB behind the four W buffers
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wrb = (BM == 256 || RB == 2) ? 2 * wave : 8 + (wave - 4);      // this wave's first 16-row block inside the tile
     const int ntiles = p.tiles_m * p.tiles_n;
     const int nk = p.K / BK;                          // multiple of 3 (chooser-checked)
 
@@ -346,18 +354,30 @@ __global__ __launch_bounds__(512) void gemm_d8_kernel(const GemmArgs p) {
     // 32 P + 8 (i >> 2) + 4 t + (i & 3) of the tile (t8's permutation: a lane's accumulators are 8 contiguous columns per block pair).
     const int dr = lane >> 3;
     const unsigned voffW = (unsigned)(((long)(8 * (dr >> 2) + (dr & 3)) * p.ldw + (((lane & 7) ^ (dr & 6)) << 3)) * 2);
-    unsigned long long wb[ND];                        // wave-uniform byte address of the piece's first row at k = 0
+    // Stream cursors wrap WITHOUT a branch (round 6).  The base addresses of the tile a cursor will enter next (wbn / abn) are computed at the
+    // top of every compute tile; the wrap inside the K loop is a scalar select.  The old form ran the tile -> address arithmetic (integer
+    // divisions) in a rarely taken branch in the middle of the K loop, with A registers in flight from inline-asm loads: the compiler is free
+    // to copy live registers on such an edge, and for one instantiation of the refactored kernel it did - it copied load destinations before
+    // their data had landed (cdna_hip_programming.md 5.7: an asm load's destination is unprotected until your own wait).
+    unsigned long long wb[ND], wbn[ND];               // wave-uniform byte address of the piece's first row at k = 0: cursor's tile / the next one
     int kW = 0, tW = blockIdx.x;
     const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
-#define D8_SETUP_W(TILE)                                                                                             \
+#define D8_SETUP_W(DST, TILE)                                                                                        \
     {                                                                                                                \
         int tm_, tn_;                                                                                                \
         tile_of_index(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                                                 \
         _Pragma("unroll") for (int j = 0; j < ND; ++j) {                                                             \
             const int q_ = wave * ND + j, cb_ = q_ >> 1;                                                             \
             const int wrow_ = tn_ * BN + 32 * (cb_ >> 1) + 16 * (q_ & 1) + 4 * (cb_ & 1);                            \
-            wb[j] = d8_uniform64((unsigned long long)(uintptr_t)p.W + (unsigned long long)wrow_ * p.ldw * 2);        \
+            DST[j] = d8_uniform64((unsigned long long)(uintptr_t)p.W + (unsigned long long)wrow_ * p.ldw * 2);       \
         }                                                                                                            \
+    }
+#define D8_WRAP_W()                                                                                                  \
+    {                                                                                                                \
+        const bool w_ = ++kW == nk;                                                                                  \
+        kW = w_ ? 0 : kW;                                                                                            \
+        tW += w_ ? (int)gridDim.x : 0;                                                                               \
+        _Pragma("unroll") for (int j = 0; j < ND; ++j) wb[j] = w_ ? wbn[j] : wb[j];                                  \
     }
 #ifdef ORV_D8_ABL_NODMA      // ablation builds (tools/d8_abl.sh, wrong results)
 #define D8_DMA1(OFF, SB, LDS) asm volatile("" :: "v"(OFF), "s"(SB), "s"(LDS));
@@ -371,23 +391,31 @@ __global__ __launch_bounds__(512) void gemm_d8_kernel(const GemmArgs p) {
             const unsigned ld_ = lds0 + (BUFI) * BUFSZ + (wave * ND + j) * 1024;                                     \
             D8_DMA1(voffW, sb_, ld_)                                                                                 \
         }                                                                                                            \
-        if (__builtin_expect(++kW == nk, 0)) { kW = 0; tW += gridDim.x; D8_SETUP_W(tW) }                             \
+        D8_WRAP_W()                                                                                                  \
     }
-    D8_SETUP_W(tW)
+    D8_SETUP_W(wb, tW)
+    D8_SETUP_W(wbn, tW + (int)gridDim.x)
 
     // ---- A stream (straight to registers, packed layout).  Block (row block R, k block c) of 16 rows x 32 k sits at ((R * K / 32) + c) KiB;
     // a wave's two row blocks are R = (tile row + 32 wave) / 16 + rb, K-tile kt = blocks 2 kt, 2 kt + 1; lane l takes bytes [16 l, 16 l + 16).
     unsigned voffA[2];
     const unsigned long long rowblk = (unsigned long long)p.K * 32;     // bytes of one 16-row block row
-    unsigned long long ab;                                               // wave-uniform byte address of block (R(rb = 0), 0)
+    unsigned long long ab, abn;                                          // wave-uniform byte address of block (R(rb = 0), 0): cursor's tile / the next one
     int kA = 0, tA = blockIdx.x;
     voffA[0] = (unsigned)lane * 16;
     voffA[1] = (unsigned)lane * 16 + (unsigned)rowblk;
-#define D8_SETUP_A(TILE)                                                                                             \
+#define D8_SETUP_A(DST, TILE)                                                                                        \
     {                                                                                                                \
         int tm_, tn_;                                                                                                \
         tile_of_index(p, min((TILE), ntiles - 1), ntiles, tm_, tn_);                                                 \
-        ab = d8_uniform64((unsigned long long)(uintptr_t)p.A + (unsigned long long)(tm_ * 16 + wave * 2) * rowblk);  \
+        DST = d8_uniform64((unsigned long long)(uintptr_t)p.A + (unsigned long long)(tm_ * (BM / 16) + wrb) * rowblk); \
+    }
+#define D8_WRAP_A()                                                                                                  \
+    {                                                                                                                \
+        const bool w_ = ++kA == nk;                                                                                  \
+        kA = w_ ? 0 : kA;                                                                                            \
+        tA += w_ ? (int)gridDim.x : 0;                                                                               \
+        ab = w_ ? abn : ab;                                                                                          \
     }
 #ifdef ORV_D8_ABL_NOA
 #define D8_LOADA(DST, OFF, SB, IMM) asm volatile("" : "=v"(DST) : "v"(OFF), "s"(SB));
@@ -398,22 +426,23 @@ __global__ __launch_bounds__(512) void gemm_d8_kernel(const GemmArgs p) {
     {                                                                                                                \
         const unsigned long long sa_ = ab + (unsigned long long)kA * 2048;                                           \
         D8_LOADA(SET[0], voffA[0], sa_, 0) D8_LOADA(SET[1], voffA[0], sa_, 1024)                                     \
-        D8_LOADA(SET[2], voffA[1], sa_, 0) D8_LOADA(SET[3], voffA[1], sa_, 1024)                                     \
-        if (__builtin_expect(++kA == nk, 0)) { kA = 0; tA += gridDim.x; D8_SETUP_A(tA) }                             \
+        if constexpr (RB == 2) { D8_LOADA(SET[NA - 2], voffA[1], sa_, 0) D8_LOADA(SET[NA - 1], voffA[1], sa_, 1024) } \
+        D8_WRAP_A()                                                                                                  \
     }
-    D8_SETUP_A(tA)
+    D8_SETUP_A(ab, tA)
+    D8_SETUP_A(abn, tA + (int)gridDim.x)
 
     // ---- W fragment reads: row i = l & 15 of a block = piece i >> 3, row i & 7; k chunk (4 kh + (l >> 4)) ^ (i & 6): k half 1 = bit 6 flipped
     const int fro = ((lane & 15) >> 3) * 1024 + (lane & 7) * 128 + (((lane >> 4) ^ (lane & 6)) << 4);
     const char* const rd0 = smem + fro;
     const char* const rd1 = smem + (fro ^ 64);
 
-    f32x4 acc[2][NCB];
+    f32x4 acc[RB][NCB];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < RB; ++a)
 #pragma unroll
         for (int b = 0; b < NCB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 a0[4], a1[4], a2[4];                       // A register sets: [rb * 2 + kh]
+    bf16x8 a0[NA], a1[NA], a2[NA];                    // A register sets: [rb * 2 + kh]
     bf16x8 fx[CBP][2];                                // W fragments of the current phase (rolling, see D8_READ1)
 
 #define D8_FENCE() __builtin_amdgcn_sched_barrier(0);
@@ -431,10 +460,10 @@ __global__ __launch_bounds__(512) void gemm_d8_kernel(const GemmArgs p) {
 #endif
 #ifdef ORV_D8_ABL_NOMFMA
 #define D8_MFMA1(T, KH, AS, PH)                                                                                      \
-    _Pragma("unroll") for (int rb = 0; rb < 2; ++rb) asm volatile("" : "+v"(acc[rb][(PH) * CBP + (T)]) : "v"(fx[T][KH]), "v"(AS[rb * 2 + (KH)]));
+    _Pragma("unroll") for (int rb = 0; rb < RB; ++rb) asm volatile("" : "+v"(acc[rb][(PH) * CBP + (T)]) : "v"(fx[T][KH]), "v"(AS[rb * 2 + (KH)]));
 #else
 #define D8_MFMA1(T, KH, AS, PH)                                                                                      \
-    _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)                                                                 \
+    _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                                \
         acc[rb][(PH) * CBP + (T)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[T][KH], AS[rb * 2 + (KH)], acc[rb][(PH) * CBP + (T)], 0, 0, 0);
 #endif
     // One vector-memory instruction of this K-tile's group: slots 0 .. ND - 1 = the W pieces of K-tile u + 3 (into buffer DBUF), slots ND ..
@@ -446,20 +475,22 @@ __global__ __launch_bounds__(512) void gemm_d8_kernel(const GemmArgs p) {
         const unsigned long long sb_ = wb[(S) < ND ? (S) : 0] + (unsigned long long)kW * 128;                        \
         const unsigned ld_ = lds0 + (DBUF) * BUFSZ + (wave * ND + (S)) * 1024;                                       \
         D8_DMA1(voffW, sb_, ld_)                                                                                     \
-        if ((S) == ND - 1) { if (__builtin_expect(++kW == nk, 0)) { kW = 0; tW += gridDim.x; D8_SETUP_W(tW) } }      \
-    } else if ((S) < ND + 4) {                                                                                       \
+        if ((S) == ND - 1) D8_WRAP_W()                                                                               \
+    } else if ((S) < ND + NA) {                                                                                      \
         const unsigned long long sa_ = ab + (unsigned long long)kA * 2048;                                           \
         if ((S) == ND) D8_LOADA(ANEW[0], voffA[0], sa_, 0)                                                           \
         if ((S) == ND + 1) D8_LOADA(ANEW[1], voffA[0], sa_, 1024)                                                    \
-        if ((S) == ND + 2) D8_LOADA(ANEW[2], voffA[1], sa_, 0)                                                       \
-        if ((S) == ND + 3) { D8_LOADA(ANEW[3], voffA[1], sa_, 1024)                                                  \
-            if (__builtin_expect(++kA == nk, 0)) { kA = 0; tA += gridDim.x; D8_SETUP_A(tA) } }                       \
+        if constexpr (RB == 2) {                                                                                     \
+            if ((S) == ND + 2) D8_LOADA(ANEW[NA - 2], voffA[1], sa_, 0)                                              \
+            if ((S) == ND + 3) D8_LOADA(ANEW[NA - 1], voffA[1], sa_, 1024)                                           \
+        }                                                                                                            \
+        if ((S) == ND + NA - 1) D8_WRAP_A()                                                                          \
     }
-    // the ND + 4 slots of a K-tile are spread evenly over its 2 NCB steps (one step = one W fragment = two MFMAs): slot i sits behind
-    // step ((2 i + 1) * 2 NCB) / (2 (ND + 4))
+    // the ND + NA slots of a K-tile are spread evenly over its 2 NCB steps (one step = one W fragment = RB MFMAs): slot i sits behind
+    // step ((2 i + 1) * 2 NCB) / (2 (ND + NA))
 #define D8_STEP_SLOT(PH, S, ANEW, DBUF)                                                                              \
-    _Pragma("unroll") for (int i_ = 0; i_ < ND + 4; ++i_)                                                            \
-        if ((PH) * 2 * CBP + (S) == ((2 * i_ + 1) * 2 * NCB) / (2 * (ND + 4))) { D8_SLOT(i_, ANEW, DBUF) }
+    _Pragma("unroll") for (int i_ = 0; i_ < ND + NA; ++i_)                                                           \
+        if ((PH) * 2 * CBP + (S) == ((2 * i_ + 1) * 2 * NCB) / (2 * (ND + NA))) { D8_SLOT(i_, ANEW, DBUF) }
     // phase PH of a K-tile: RBUF / RPH = buffer offset and phase the re-requested fragments belong to
 #define D8_PHASE(RBUF, RPH, ACUR, ANEW, PH, DBUF)                                                                    \
     _Pragma("unroll") for (int s_ = 0; s_ < 2 * CBP; ++s_) {                                                         \
@@ -468,9 +499,13 @@ __global__ __launch_bounds__(512) void gemm_d8_kernel(const GemmArgs p) {
         D8_STEP_SLOT(PH, s_, ANEW, DBUF) D8_FENCE()                                                                  \
     }
 #ifdef ORV_D8_ABL_NOWAIT     // ablation (wrong results): is the K loop waiting for its own loads?
-#define D8_WAIT(ACUR) asm volatile("" : "+v"(ACUR[0]), "+v"(ACUR[1]), "+v"(ACUR[2]), "+v"(ACUR[3]));
+#define D8_WAIT(ACUR)                                                                                                \
+    if constexpr (RB == 2) asm volatile("" : "+v"(ACUR[0]), "+v"(ACUR[1]), "+v"(ACUR[2]), "+v"(ACUR[3]));            \
+    else asm volatile("" : "+v"(ACUR[0]), "+v"(ACUR[1]));
 #else
-#define D8_WAIT(ACUR) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ACUR[0]), "+v"(ACUR[1]), "+v"(ACUR[2]), "+v"(ACUR[3]) : "n"(ND + 4) : "memory");
+#define D8_WAIT(ACUR)                                                                                                \
+    if constexpr (RB == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ACUR[0]), "+v"(ACUR[1]), "+v"(ACUR[2]), "+v"(ACUR[3]) : "n"(ND + NA) : "memory"); \
+    else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ACUR[0]), "+v"(ACUR[1]) : "n"(ND + NA) : "memory");
 #endif
     // One K-tile u.  ACUR: the A set it computes with; ANEW: the set K-tile u - 1 used, refilled for K-tile u + 2.  bufc = u & 3.
     //   wait: this wave's group of two K-tiles ago = { W pieces of K-tile u + 1, A of K-tile u } (the group of K-tile u - 1 stays in flight)
@@ -493,17 +528,20 @@ __global__ __launch_bounds__(512) void gemm_d8_kernel(const GemmArgs p) {
     D8_ISSUE_W(0)
     D8_ISSUE_W(1) D8_ISSUE_A(a0)
     D8_ISSUE_W(2) D8_ISSUE_A(a1)
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (ND + 4)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (ND + NA)) : "memory");
     D8_FENCE() __builtin_amdgcn_s_barrier(); D8_FENCE()
     _Pragma("unroll") for (int s_ = 0; s_ < 2 * CBP; ++s_) { D8_READ1(s_ % CBP, s_ / CBP, 0, 0) }
     D8_FENCE()
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // each cursor wraps exactly once per compute tile (nk >= 3 K-tiles, the cursors run 3 / 2 K-tiles ahead): the tile it enters then
+        D8_SETUP_W(wbn, tW + (int)gridDim.x)
+        D8_SETUP_A(abn, tA + (int)gridDim.x)
         for (int kt = 0; kt < nk; kt += 3) {
             if (d8_rlds<BN, EPI>() && kt + 3 >= nk) {      // the epilogue's first residual rows: in flight under the last three K-tiles
                 int tm_, tn_;
                 tile_of_index(p, tile, ntiles, tm_, tn_);
-                d8_issue_rows(p, tm_ * 256 + wave * 32, tn_ * BN, lane, smem + SCR + 8 * 4096 + wave * 4096);
+                d8_issue_rows(p, tm_ * BM + wrb * 16, tn_ * BN, lane, smem + SCR + 8 * 4096 + wave * 4096);
             }
             D8_KTILE(a0, a2)
             D8_KTILE(a1, a0)
@@ -511,10 +549,10 @@ __global__ __launch_bounds__(512) void gemm_d8_kernel(const GemmArgs p) {
         }
         int tm, tn;
         tile_of_index(p, tile, ntiles, tm, tn);
-        if ((EPI == 0 || EPI == 1) && p.c_packed) d8_epilogue_packed<BN, EPI>(p, acc, tm * 256 + wave * 32, tn * BN, lane);
-        else d8_epilogue<BN, EPI>(p, acc, tm * 256 + wave * 32, tn * BN, lane, smem + SCR + wave * 4096, smem + SCR + 8 * 4096 + wave * 4096);
+        if ((EPI == 0 || EPI == 1) && p.c_packed) d8_epilogue_packed<BN, EPI, RB>(p, acc, tm * BM + wrb * 16, tn * BN, lane);
+        else d8_epilogue<BN, EPI, RB>(p, acc, tm * BM + wrb * 16, tn * BN, lane, smem + SCR + wave * 4096, smem + SCR + 8 * 4096 + wave * 4096);
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < RB; ++a)
 #pragma unroll
             for (int b = 0; b < NCB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -524,23 +562,39 @@ __global__ __launch_bounds__(512) void gemm_d8_kernel(const GemmArgs p) {
 }
 
 template <int BN, int EPI>
+__global__ __launch_bounds__(512) void gemm_d8_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    d8_body<BN, EPI, 2, 256>(p, smem);
+}
+// 192-row tiles: the two waves of a SIMD are the two roles (waves w and w + 4 share a SIMD: a workgroup's waves go to the SIMDs cyclically)
+template <int BN, int EPI>
+__global__ __launch_bounds__(512) void gemm_d8r192_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4) d8_body<BN, EPI, 2, 192>(p, smem);
+    else d8_body<BN, EPI, 1, 192>(p, smem);
+}
+
+template <int BN, int EPI, int BM>
 int launch_d8_one(const GemmArgs& a, hipStream_t st) {
     constexpr int smem = 4 * BN * 128 + 8 * 4096 + (d8_rlds<BN, EPI>() ? 8 * 4096 : 0);     // four W buffers + the epilogue scratch (160 KiB at BN = 256) + the residual slabs
+    void (*kern)(const GemmArgs);
+    if constexpr (BM == 256) kern = gemm_d8_kernel<BN, EPI>;
+    else kern = gemm_d8r192_kernel<BN, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_d8_kernel<BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
     int grid = min(a.tiles_m * a.tiles_n, orv_num_cus());
     if (a.grid_cap > 0) grid = min(grid, a.grid_cap);
-    hipLaunchKernelGGL((gemm_d8_kernel<BN, EPI>), dim3(grid), dim3(512), smem, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a);
     return orv_check_launch("orv_gemm_bf16");
 }
 
 }  // namespace
 
 namespace orv_gemm {
-int launch_d8(const GemmArgs& a, int bn, int epi, hipStream_t st) {
+int launch_d8(const GemmArgs& a, int bn, int epi, hipStream_t st, int bm) {
     if (!a.a_packed || (long)a.N * a.ldw * 2 >= (1L << 32) || a.K % 192 != 0 || a.lda != a.K) {
         orv_set_error("orv_gemm_bf16: the d8 kernel needs a packed A (a_packed, lda == K), K %% 192 == 0 and W below 4 GiB (lda=%ld N=%d ldw=%ld K=%d)",
                       a.lda, a.N, a.ldw, a.K);
@@ -550,28 +604,53 @@ int launch_d8(const GemmArgs& a, int bn, int epi, hipStream_t st) {
         orv_set_error("orv_gemm_bf16: packed C needs epilogue 0 / 1, ldc == N, no row map, no Y");
         return ORV_EINVAL;
     }
+    if (bm == 192) {
+        // 192-row tiles (gemm_d8r192_kernel): the packed A (and packed C) buffers hold orv_packed_rows(M) = ceil(M / 256) * 256 row slots and
+        // neither the A loads nor the packed store are masked - the 192-row tiling must stay inside them (the chooser checks the same)
+        if ((long)a.tiles_m * 192 > ((long)a.M + 255) / 256 * 256) {
+            orv_set_error("orv_gemm_bf16: 192-row d8 tiles would read past the packed row slots (M=%d)", a.M);
+            return ORV_EINVAL;
+        }
+        if (bn == 128) {
+            switch (epi) {
+                case 0: return launch_d8_one<128, 0, 192>(a, st);
+                case 1: return launch_d8_one<128, 1, 192>(a, st);
+                case 2: return launch_d8_one<128, 2, 192>(a, st);
+                case 4: return launch_d8_one<128, 4, 192>(a, st);
+            }
+        } else if (bn == 192) {
+            switch (epi) {
+                case 0: return launch_d8_one<192, 0, 192>(a, st);
+                case 1: return launch_d8_one<192, 1, 192>(a, st);
+                case 2: return launch_d8_one<192, 2, 192>(a, st);
+                case 4: return launch_d8_one<192, 4, 192>(a, st);
+            }
+        }
+        orv_set_error("orv_gemm_bf16: no 192-row d8 kernel for BN=%d epilogue %d", bn, epi);
+        return ORV_EINVAL;
+    }
     if (bn == 256) {
         switch (epi) {
-            case 0: return launch_d8_one<256, 0>(a, st);
-            case 1: return launch_d8_one<256, 1>(a, st);
-            case 2: return launch_d8_one<256, 2>(a, st);
-            case 3: return launch_d8_one<256, 3>(a, st);
-            case 4: return launch_d8_one<256, 4>(a, st);
+            case 0: return launch_d8_one<256, 0, 256>(a, st);
+            case 1: return launch_d8_one<256, 1, 256>(a, st);
+            case 2: return launch_d8_one<256, 2, 256>(a, st);
+            case 3: return launch_d8_one<256, 3, 256>(a, st);
+            case 4: return launch_d8_one<256, 4, 256>(a, st);
         }
     } else if (bn == 128) {
         switch (epi) {
-            case 0: return launch_d8_one<128, 0>(a, st);
-            case 1: return launch_d8_one<128, 1>(a, st);
-            case 2: return launch_d8_one<128, 2>(a, st);
-            case 4: return launch_d8_one<128, 4>(a, st);
+            case 0: return launch_d8_one<128, 0, 256>(a, st);
+            case 1: return launch_d8_one<128, 1, 256>(a, st);
+            case 2: return launch_d8_one<128, 2, 256>(a, st);
+            case 4: return launch_d8_one<128, 4, 256>(a, st);
         }
     } else if (bn == 192) {
         switch (epi) {
-            case 0: return launch_d8_one<192, 0>(a, st);
-            case 1: return launch_d8_one<192, 1>(a, st);
-            case 2: return launch_d8_one<192, 2>(a, st);
-            case 3: return launch_d8_one<192, 3>(a, st);
-            case 4: return launch_d8_one<192, 4>(a, st);
+            case 0: return launch_d8_one<192, 0, 256>(a, st);
+            case 1: return launch_d8_one<192, 1, 256>(a, st);
+            case 2: return launch_d8_one<192, 2, 256>(a, st);
+            case 3: return launch_d8_one<192, 3, 256>(a, st);
+            case 4: return launch_d8_one<192, 4, 256>(a, st);
         }
     }
     orv_set_error("orv_gemm_bf16: no d8 kernel for BN=%d epilogue %d", bn, epi);

@@ -340,11 +340,18 @@ def gaussian_sample(moments, eps, scale):
 
 
 # ---- backward (training) ----------------------------------------------------------------------------------------------
+_TPAD = 64 if os.environ.get("ORV_TRANSPOSE_PAD", "128") == "64" else 128      # A/B switch: 64 = the round-1..5 padding
+
+
 def transpose(src, R, C, ld_dst=None, out=None, ld_src=None, colsum=None):
-    """[R, C] bf16 -> [C, ld_dst] (ld_dst = R rounded up to 64, zero padded): K-contiguous operand for dgrad/wgrad.
+    """[R, C] bf16 -> [C, ld_dst] (zero padded): K-contiguous operand for dgrad/wgrad.  ld_dst defaults to the row stride of ``out`` when
+    one is given, else to R rounded up to 128 - the t8 GEMM kernels need K % 128 == 0, and a contraction padded to 64 only
+    (CogVideoX1.5-5B at B = 4: 7048 tokens -> 7104) sent every weight-gradient GEMM of configs[4] to the older ring kernel (round 6:
+    profiles/r6_train_5b_ckpt_kernel_stats_summary.txt, 17 % of the step in gemm_pp_kernel).
     ``colsum`` (fp32 [C], accumulated into): the column sums of ``src`` from the same pass (bias gradient beside dY^T)."""
     _need(src, BF16, "src")
-    ld_dst = ld_dst or (R + 63) // 64 * 64
+    if ld_dst is None:
+        ld_dst = int(out.stride(0)) if out is not None else (R + _TPAD - 1) // _TPAD * _TPAD
     if out is None:
         out = torch.empty(C, ld_dst, dtype=BF16, device=src.device)
     if colsum is not None:

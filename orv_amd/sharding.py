@@ -56,7 +56,11 @@ class FlatGradReducer:
 
     The reference gets this from DDP's bucket hooks (accelerate, `train_cogvideox_control_to_video_sft.py:750,1093`).  Here
     runs are coalesced up to ``max_elems`` (256 MB of bf16) and launched once they reach ``min_elems`` (16 MB): xGMI rings are
-    per-link bound, so messages stay large, and a 2B step issues ~60 collectives instead of DDP's ~140 buckets of 25 MB.
+    per-link bound, so messages stay large.  Measured bookkeeping of a 2B step (``bench.py --mode train`` exchange object, two ranks):
+    121 collectives for 3.39 GB, i.e. four per block - the two FeedForward weights (29.5 MB each) leave during the backward as soon as the block
+    closes, the block's remaining segments (attention weights 7.4 MB each, below ``min_elems`` on their own because the not-yet-final bias
+    segments sit between them; the two AdaLN linears, final only when the modulation tables close) leave in ``finish`` as two contiguous
+    runs per block - against DDP's ~140 buckets of 25 MB.  (Rounds 3-5 quoted "~60" here: that was the design estimate, not the count.)
     """
 
     def __init__(self, flat: torch.Tensor, seg_start, min_elems: int = 8 << 20, max_elems: int = 128 << 20, group=None):

@@ -29,11 +29,17 @@ def close(got, ref, rtol=2e-2, afrac=1.5e-2):
 def test_transpose_and_colsum():
     from orv_amd import ops
     dev = _dev()
-    for R, C in [(100, 64), (3226, 1920), (777, 192)]:
+    for R, C in [(100, 64), (3226, 1920), (777, 192), (200, 72)]:
         x = q(torch.randn(R, C))
         t = ops.transpose(x.to(dev, BF), R, C)
-        ld = (R + 63) // 64 * 64
+        ld = (R + 127) // 128 * 128                     # round 6: the contraction index is padded to the t8 kernels' K % 128 == 0
         assert t.shape == (C, ld)
+        t64 = ops.transpose(x.to(dev, BF), R, C, ld_dst=(R + 63) // 64 * 64)      # an explicit stride is honoured
+        assert t64.shape == (C, (R + 63) // 64 * 64) and torch.equal(t64[:, :R], t[:, :R])
+        if R % 8 == 0:                                   # out= given: its row stride is the destination stride (the source needs columns % 8)
+            back = torch.full((R, (C + 63) // 64 * 64 + 64), 7.0, dtype=BF, device=dev)
+            ops.transpose(t[:, :R].contiguous(), C, R, out=back)
+            assert torch.equal(back[:, :C].float().cpu(), x) and torch.all(back[:, C:] == 0)
         assert torch.equal(t[:, :R].float().cpu(), x.t()) and torch.all(t[:, R:] == 0)
         out = torch.zeros(C, dtype=torch.float32, device=dev)
         ops.colsum(x.to(dev, BF), out, R, C)

@@ -992,6 +992,90 @@ def test_pack_rows16_is_index_exact_and_invertible(M, K):
     assert torch.equal(ops.unpack_rows16(p, M, K).view(torch.int16), a.view(torch.int16))
 
 
+@pytest.mark.parametrize("bn", [192, 128])
+def test_d8_192_row_tiles_are_bit_identical_to_the_256_row_kernel(bn):
+    """gemm_d8r192_kernel (round 6): the d8 kernel on 192-row tiles - the first wave of every SIMD owns two 16-row blocks, the second one -
+    changes WHICH wave computes a row, not how an output element is accumulated: every epilogue (bias, GELU, gated residual with token
+    groups + row scatter, fused qk LayerNorm with the Y side output, packed C) must agree with gemm_d8_kernel bit for bit, on ragged M,
+    single- and multi-round grids.  Shapes whose 192-row tiling would leave the packed row slots (ceil(M / 256) * 256) are refused."""
+    from orv_amd import ops
+    from orv_amd._lib import lib
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(90 + bn)
+    N = bn * 3
+
+    def same(a, b, what):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (what, (a.float() - b.float()).abs().max().item())
+
+    def pinned(bm, fn):
+        lib().orv_gemm_force_tile(5, bm, bn)
+        try:
+            return fn()
+        finally:
+            lib().orv_gemm_force_tile(0, 0, 0)
+
+    for M, K in [(100, 384), (3226, 1920), (3226 * 2, 384), (12904, 576), (70001, 192)]:
+        assert -(-M // 192) * 192 <= -(-M // 256) * 256
+        A = torch.randn(M, K, device=dev, generator=g).to(BF)
+        W = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(BF)
+        bias = torch.randn(N, device=dev, generator=g).to(BF)
+        R = torch.randn(M, N, device=dev, generator=g).to(BF)
+        Ap = ops.pack_rows16(A, M, K)
+        assert pinned(192, lambda: ops.gemm_kernel_name(M, N, K, 0, a_packed=True)) == f"gemm_d8r192_kernel<{bn}, 0>"
+        for epi in (0, 1, 2):
+            def run():
+                C = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+                Y = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+                ops.gemm(Ap, W, bias, C, M, N, K, epilogue=epi, Y=Y, a_packed=True, **(dict(R=R, ldr=N) if epi == 2 else {}))
+                return C, Y
+            (c0, y0), (c1, y1) = pinned(256, run), pinned(192, run)
+            assert torch.isfinite(c1.float()).all()
+            same(c0, c1, (bn, M, K, epi, "C")), same(y0, y1, (bn, M, K, epi, "Y"))
+        # packed C (the FFN1 -> FFN2 hand-off): compare the unpacked rows [0, M)
+        def run_pc():
+            Cp = torch.zeros(ops.packed_rows(M), N, dtype=BF, device=dev)
+            ops.gemm(Ap, W, bias, Cp, M, N, K, epilogue=1, a_packed=True, c_packed=True)
+            return ops.unpack_rows16(Cp, M, N)
+        same(pinned(256, run_pc), pinned(192, run_pc), (bn, M, K, "packed C"))
+    # 192-row tiles that would run past the packed row slots are refused (M = 500: 3 x 192 = 576 > 512)
+    with pytest.raises(RuntimeError):
+        pinned(192, lambda: ops.gemm_kernel_name(500, N, 384, 0, a_packed=True) or (_ for _ in ()).throw(RuntimeError("no kernel")))
+    # gated residual with token groups (gate rows change inside 16-row blocks) + row scatter into a joint buffer
+    seq, n_text, per_group, Bn = 500, 19, 37, 3
+    Mv, K = (seq - n_text) * Bn, 384
+    assert -(-Mv // 192) * 192 <= -(-Mv // 256) * 256
+    A = torch.randn(Mv, K, device=dev, generator=g).to(BF)
+    W = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(BF)
+    bias = torch.randn(N, device=dev, generator=g).to(BF)
+    n_groups = 1 + (seq - n_text + per_group - 1) // per_group
+    gate = torch.randn(Bn, n_groups, N, device=dev, generator=g)
+    base = torch.randn(Bn * seq, N, device=dev, generator=g).to(BF)
+    Ap = ops.pack_rows16(A, Mv, K)
+
+    def fn_gate():
+        C = base.clone()
+        ops.gemm(Ap, W, bias, C, Mv, N, K, epilogue=2, R=C, ldr=N, gate=gate, gate_b=n_groups * N, gate_g=N,
+                 grp=ops.Groups(seq, n_text, per_group), cmap=ops.RowMap(seq - n_text, seq, n_text), a_packed=True)
+        return C
+    same(pinned(256, fn_gate), pinned(192, fn_gate), (bn, "gate + cmap"))
+    # fused qk LayerNorm (a wave owns whole rows, 64 columns = one head, in both row layouts)
+    heads = 2 if bn == 128 else 3
+    Nq, M, K = 3 * heads * 64, 3226, 384
+    A = torch.randn(M, K, device=dev, generator=g).to(BF)
+    W = (torch.randn(Nq, K, device=dev, generator=g) / K ** 0.5).to(BF)
+    bias = torch.randn(Nq, device=dev, generator=g).to(BF)
+    aff = [torch.randn(64, device=dev, generator=g).to(BF) for _ in range(4)]
+    Ap = ops.pack_rows16(A, M, K)
+
+    def fn_qk():
+        C = torch.full((M, Nq), float("nan"), dtype=BF, device=dev)
+        Y = torch.full((M, Nq), float("nan"), dtype=BF, device=dev)
+        ops.gemm(Ap, W, bias, C, M, Nq, K, epilogue=4, Y=Y, qknorm=(aff[0], aff[1], aff[2], aff[3], 1e-6, 0.18, heads), a_packed=True)
+        return C, Y
+    (c0, y0), (c1, y1) = pinned(256, fn_qk), pinned(192, fn_qk)
+    same(c0, c1, (bn, "qk LayerNorm C")), same(y0, y1, (bn, "qk LayerNorm Y"))
+
+
 @pytest.mark.parametrize("bn", [256, 192])
 def test_d8_gemm_on_packed_a_is_bit_identical_to_t8(bn):
     """gemm_d8_kernel (A straight to registers from the packed layout, W through four LDS buffers, one barrier per K-tile) accumulates every
@@ -1014,7 +1098,7 @@ def test_d8_gemm_on_packed_a_is_bit_identical_to_t8(bn):
         bias = torch.randn(N, device=dev, generator=g).to(BF)
         R = torch.randn(M, N, device=dev, generator=g).to(BF)
         Ap = ops.pack_rows16(A, M, K)
-        assert ops.gemm_kernel_name(M, N, K, 0, a_packed=True).startswith("gemm_d8_kernel<")
+        assert ops.gemm_kernel_name(M, N, K, 0, a_packed=True).startswith("gemm_d8")        # gemm_d8_kernel or gemm_d8r192_kernel
         for epi in (0, 1, 2, 3):
             outs = []
             for packed in (False, True):

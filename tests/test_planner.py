@@ -35,4 +35,11 @@ def test_packed_plan_per_batch():
     assert p1 == {"ffn": True, "out": True, "qkv": True, "ffn1": False}       # one clip: q | k | v in ONE d8 launch from the packed LayerNorm output
     assert p2 == {"ffn": True, "out": False, "qkv": False, "ffn1": False}
     assert p4 == {"ffn": True, "out": True, "qkv": False, "ffn1": False}
-    assert ops.gemm_kernel_name(S, 3 * D, D, 4, a_packed=True) == "gemm_d8_kernel<192, 4>"
+    # round 6: the packed GEMMs of one and two clips take the 192-row d8 tiles (255 / 510 tiles of 192 x 128 = full rounds for N = 1920, 510 of
+    # 192 x 192 for q | k | v at one clip); the headline batch keeps the 256-row tiles (test above)
+    assert ops.gemm_kernel_name(S, 3 * D, D, 4, a_packed=True) == "gemm_d8r192_kernel<192, 4>"
+    for B in (1, 2):
+        assert ops.gemm_kernel_name(B * S, D, 4 * D, 2, a_packed=True) == "gemm_d8r192_kernel<128, 2>", B
+    assert ops.gemm_kernel_name(S, D, D, 2, a_packed=True) == "gemm_d8r192_kernel<128, 2>"
+    # a 192-row tiling that would run past the packed row slots (ceil(M / 256) * 256) is not offered: M = 500 -> 3 x 192 = 576 > 512
+    assert ops.gemm_kernel_name(500, D, 4 * D, 2, a_packed=True) == "gemm_d8_kernel<128, 2>"
