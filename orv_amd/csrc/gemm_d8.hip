@@ -512,9 +512,32 @@ __device__ __forceinline__ void d8_body(const GemmArgs& p, char* const smem) {
     //   barrier: every wave's pieces of K-tile u + 1 have landed, every wave is done with the buffer of K-tile u - 1
     //   NPH phases; the last one re-requests K-tile u + 1's first fragments (complete since the barrier above);
     //   this K-tile's group (W pieces of K-tile u + 3 into the buffer of K-tile u - 1, A of K-tile u + 2) is issued slot by slot
+    // -DORV_D8_ABL_LNA (ablation, right results): what would it cost to apply the LayerNorm-modulate to the A operand on its way into the MFMA
+    // (drop the 1.39 ms LayerNorm pass, the producing epilogues emit row statistics)?  Every A element of the K-tile just waited
+    // for goes through the arithmetic that fusion needs - unpack, (x - mean) rstd as one FMA with per-row constants, * (1 + scale) + shift as
+    // one FMA with per-column constants, round to bf16 - with IDENTITY constants taken from the argument block (the compiler cannot fold them).
+    // The per-column factor loads (a second small LDS / L2 stream per K-tile and token group) are NOT included: a lower bound of the cost.
+#ifdef ORV_D8_ABL_LNA
+    const float lna_rs = p.qn_eps == 12345.f ? 2.f : 1.f, lna_nm = p.qn_eps == 12345.f ? 1.f : 0.f;      // per-row: rstd, -mean rstd
+    float lna_g[8], lna_s[8];                                                                             // per-column: 1 + scale, shift
+    _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) { lna_g[e_] = p.qn_premul == 54321.f ? 3.f + e_ : 1.f; lna_s[e_] = p.qn_premul == 54321.f ? 1.f : 0.f; }
+#define D8_LNA(ACUR)                                                                                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < NA; ++i_) {                                                              \
+        union { bf16x8 v; uint32_t u[4]; } c_; c_.v = ACUR[i_];                                                      \
+        _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_) {                                                           \
+            const float lo_ = __builtin_fmaf(__builtin_fmaf(bf2f(c_.u[w_] & 0xffff), lna_rs, lna_nm), lna_g[2 * w_], lna_s[2 * w_]);          \
+            const float hi_ = __builtin_fmaf(__builtin_fmaf(bf2f(c_.u[w_] >> 16), lna_rs, lna_nm), lna_g[2 * w_ + 1], lna_s[2 * w_ + 1]);     \
+            c_.u[w_] = pack2bf(lo_, hi_);                                                                            \
+        }                                                                                                            \
+        ACUR[i_] = c_.v;                                                                                             \
+    }
+#else
+#define D8_LNA(ACUR)
+#endif
 #define D8_KTILE(ACUR, ANEW)                                                                                         \
     {                                                                                                                \
         D8_WAIT(ACUR)                                                                                                \
+        D8_LNA(ACUR)                                                                                                 \
         D8_FENCE() __builtin_amdgcn_s_barrier(); D8_FENCE()                                                          \
         const int cur_ = bufc * BUFSZ, nxt_ = ((bufc + 1) & 3) * BUFSZ, dbuf_ = (bufc + 3) & 3;                      \
         _Pragma("unroll") for (int pp_ = 0; pp_ < NPH; ++pp_) {                                                      \

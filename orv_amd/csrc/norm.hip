@@ -233,6 +233,24 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(const bf16_t* src, bf16_t
 #endif
 // PACKED: y in the P16 layout (include/orv_mi355.h orv_gemm_t: the A operand of gemm_d8) - chunk c of row r is 16-byte slot (c & 3) * 16 + (r & 15)
 // of block (r >> 4, c >> 2).  A wave instruction then writes 64 scattered 16-byte pieces (four per KiB block) instead of 1 KiB of one row.
+// A/B switches (tools/variants.sh): -DORV_LNR_NT_LOAD / -DORV_LNR_NT_STORE = non-temporal x loads / y stores
+__device__ __forceinline__ uint4 lnr_load(const bf16_t* p) {
+#ifdef ORV_LNR_NT_LOAD
+    typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
+    const nt_u32x4 v = __builtin_nontemporal_load((const nt_u32x4*)p);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+#else
+    return *(const uint4*)p;
+#endif
+}
+__device__ __forceinline__ void lnr_store(bf16_t* p, const uint4 u) {
+#ifdef ORV_LNR_NT_STORE
+    typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(nt_u32x4{u.x, u.y, u.z, u.w}, (nt_u32x4*)p);
+#else
+    *(uint4*)p = u;
+#endif
+}
 template <int CH, bool PACKED = false>
 __global__ __launch_bounds__(256, ORV_LNR_WAVES) void ln_mod_rows_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t* __restrict__ y, long ldy,
                                                              const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
@@ -256,7 +274,7 @@ __global__ __launch_bounds__(256, ORV_LNR_WAVES) void ln_mod_rows_kernel(const b
     long cur_off = -1;
     uint4 raw[CH];
 #pragma unroll
-    for (int i = 0; i < CH; ++i) raw[i] = *(const uint4*)(x + (long)r0 * ldx + ce[i] * 8);
+    for (int i = 0; i < CH; ++i) raw[i] = lnr_load(x + (long)r0 * ldx + ce[i] * 8);
     for (int row = r0; row < r1; ++row) {
         const int b = row / seq, sidx = row % seq;
         const long off = b * mod_b + orv_group_of(sidx, n_text, per_group) * mod_g;
@@ -295,7 +313,7 @@ __global__ __launch_bounds__(256, ORV_LNR_WAVES) void ln_mod_rows_kernel(const b
         {   // row r + 1 is fetched into the registers row r was just unpacked from
             const int rn = min(row + 1, rows - 1);
 #pragma unroll
-            for (int i = 0; i < CH; ++i) raw[i] = *(const uint4*)(x + (long)rn * ldx + ce[i] * 8);
+            for (int i = 0; i < CH; ++i) raw[i] = lnr_load(x + (long)rn * ldx + ce[i] * 8);
         }
         const float mean = wave_sum_valu(s) / (float)D;
         float sq = 0.f;
@@ -317,7 +335,7 @@ __global__ __launch_bounds__(256, ORV_LNR_WAVES) void ln_mod_rows_kernel(const b
             uint4 u;
             u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]); u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
             if (PACKED) *(uint4*)(y + ((((long)(row >> 4) * (D >> 5) + (ce[i] >> 2)) << 9) + ((((ce[i] & 3) << 4) + (row & 15)) << 3))) = u;
-            else *(uint4*)(yr + ce[i] * 8) = u;       // lanes past the row end re-store the last chunk's identical bytes
+            else lnr_store(yr + ce[i] * 8, u);       // lanes past the row end re-store the last chunk's identical bytes
         }
     }
 }
