@@ -572,8 +572,13 @@ __device__ __forceinline__ void d8_body(const GemmArgs& p, char* const smem) {
         }
         int tm, tn;
         tile_of_index(p, tile, ntiles, tm, tn);
+#ifdef ORV_D8_ABL_NOEPI      // ablation (wrong results): the kernel without its epilogue = what PERFECTLY hidden epilogues would leave
+        _Pragma("unroll") for (int a_ = 0; a_ < RB; ++a_)
+            _Pragma("unroll") for (int b_ = 0; b_ < NCB; ++b_) asm volatile("" :: "v"(acc[a_][b_]));      // every MFMA stays
+#else
         if ((EPI == 0 || EPI == 1) && p.c_packed) d8_epilogue_packed<BN, EPI, RB>(p, acc, tm * BM + wrb * 16, tn * BN, lane);
         else d8_epilogue<BN, EPI, RB>(p, acc, tm * BM + wrb * 16, tn * BN, lane, smem + SCR + wave * 4096, smem + SCR + 8 * 4096 + wave * 4096);
+#endif
 #pragma unroll
         for (int a = 0; a < RB; ++a)
 #pragma unroll
