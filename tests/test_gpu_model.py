@@ -431,6 +431,45 @@ def test_full_depth_condfull_2b_vs_oracle():
     assert err <= 2e-2 and worst <= 4e-2
 
 
+def test_full_depth_5b_forward_vs_oracle():
+    """BASELINE configs[4] at its real depth ("configs[4] checked vs the oracle at 1 / 4 blocks only"): CogVideoX1.5-5B - 42
+    blocks, D = 3072, 48 heads, FF = 12288, p_t = 2, RoPE (the training helper's tables), ofs embedding - on one DROID-shaped clip (latents
+    [1, 8, 32, 32, 48] -> S = 1762) through the HIP path against the fp32 oracle.  Same bars as the 2B test: rel-L2 <= 2e-2, worst single
+    (frame, channel) <= 4e-2 or 1.25 x what the oracle in the reference's own bf16 arithmetic leaves."""
+    import os
+    import bench
+    from orv_amd.utils import prepare_rotary_positional_embeddings
+    dev = torch.device("cuda:0")
+    model = bench.build_model({**bench.CFG_5B, "num_layers": 42}, dev)
+    model.action_embed.forced_mask = torch.zeros(1, dtype=torch.bool)
+    lat, img, prompt, actions = bench.synthetic_inputs(1, dev, BF, frames=8, h=32, w=48)
+    x = torch.cat([lat, img], dim=2)
+    ts = torch.tensor([611], device=dev)
+    rope = prepare_rotary_positional_embeddings(height=32 * 8, width=48 * 8, num_frames=8, vae_scale_factor_spatial=8, patch_size=2, patch_size_t=2,
+                                                attention_head_dim=64, device=dev)
+    ofs = torch.full((1,), 2.0, device=dev, dtype=BF)
+    with torch.no_grad():
+        out = model(x, prompt, {"actions": actions}, ts, ofs=ofs, image_rotary_emb=rope, return_dict=False)[0].cpu()
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    torch.set_num_threads(max(1, min(32, (os.cpu_count() or 2) // 2)))
+    rope_c = tuple(r.float().cpu() for r in rope)
+    kw = dict(actions=actions.float().cpu(), is_mask=torch.zeros(1, dtype=torch.bool))
+    with torch.no_grad():
+        ref = dit.dit_forward(sd, dict(model.config), x.float().cpu(), prompt.float().cpu(), ts.cpu(), image_rotary_emb=rope_c,
+                              ofs=ofs.float().cpu(), **kw)[0]
+    err, worst = rel_l2(out.float(), ref), _frame_channel_worst(out, ref)
+    print(f"full-depth configs[4] (5B): rel-L2(HIP, fp32 oracle) = {err:.4e}, worst (frame, channel) = {worst:.4e}")
+    bound = 4e-2
+    if worst > bound:
+        with torch.no_grad():
+            ref16 = dit.dit_forward({k: v.to(BF) for k, v in sd.items()}, dict(model.config), x.cpu(), prompt.cpu(), ts.cpu(), image_rotary_emb=rope_c,
+                                    ofs=ofs.cpu(), actions=actions.cpu().to(BF), is_mask=kw["is_mask"])[0].float()
+        w16 = _frame_channel_worst(ref16, ref)
+        print(f"    bf16 oracle vs fp32 oracle: rel-L2 = {rel_l2(ref16, ref):.4e}, worst (frame, channel) = {w16:.4e}")
+        bound = max(bound, 1.25 * w16)
+    assert out.shape == ref.shape and err <= 2e-2 and worst <= bound, (err, worst, bound)
+
+
 def test_trained_like_qk_layernorm_mixes_static_and_online_softmax_layers():
     """VERDICT r5 weak #2 / #4d: the headline rides the fixed-shift softmax, valid while the qk-LayerNorm bound stays <= 90 log2 units.  No
     checkpoint is reachable, so trained-LIKE statistics are drawn: 6 full-width blocks (D = 1920, S = 3226) whose per-layer
