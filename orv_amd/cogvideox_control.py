@@ -403,6 +403,14 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
             self.initial_combine_linear.bias.data.zero_()
 
     def _set_trainable_parameters(self):
+        # Data-parallel bookkeeping hint (orv_amd.optim.FusedAdamW): the six big weights of a block are the gradients that are FINAL when the
+        # hand-written backward leaves the block (training.backward's grad_hook) - biases / LayerNorm affines are converted at the very end,
+        # the AdaLN linears close with the modulation tables.  Tagged, they are laid out first and contiguously in the optimizer's flat
+        # gradient buffer, so a block's early gradients leave as ONE 88-MB all-reduce during the backward (xGMI rings are per-link bound:
+        # few, large messages) instead of two early + two late pieces.
+        for blk in self.transformer_blocks:
+            for lin in (blk.attn1.to_q, blk.attn1.to_k, blk.attn1.to_v, blk.attn1.to_out[0], blk.ff.net[0].proj, blk.ff.net[2]):
+                lin.weight._orv_grad_early = True
         if self.config.multiview:
             for p in self.parameters():
                 p.requires_grad_(False)

@@ -28,7 +28,12 @@ _AR_CHUNK = 128 * 1024 * 1024   # bf16 elements per all-reduce call (256 MB: lar
 class FusedAdamW:
     def __init__(self, params: Iterable[torch.nn.Parameter], lr=1e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=1e-3,
                  max_grad_norm: float = 1.0):
-        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        ps = [p for p in params if p.requires_grad]
+        # flat-buffer order: parameters the model tagged as "gradient final when its block's backward ends" first (model order: a block's
+        # six weights are contiguous), everything else behind them - see CogVideoXTransformer3DModelTraj._set_trainable_parameters and
+        # sharding.FlatGradReducer.  Untagged parameter lists (any other model) keep their order.
+        self.params: List[torch.nn.Parameter] = ([p for p in ps if getattr(p, "_orv_grad_early", False)]
+                                                 + [p for p in ps if not getattr(p, "_orv_grad_early", False)])
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.step_count = 0
         self.param_groups = [{"lr": lr, "params": self.params}]      # lr schedulers poke param_groups[0]["lr"]

@@ -56,11 +56,12 @@ class FlatGradReducer:
 
     The reference gets this from DDP's bucket hooks (accelerate, `train_cogvideox_control_to_video_sft.py:750,1093`).  Here
     runs are coalesced up to ``max_elems`` (256 MB of bf16) and launched once they reach ``min_elems`` (16 MB): xGMI rings are
-    per-link bound, so messages stay large.  Measured bookkeeping of a 2B step (``bench.py --mode train`` exchange object, two ranks):
-    121 collectives for 3.39 GB, i.e. four per block - the two FeedForward weights (29.5 MB each) leave during the backward as soon as the block
-    closes, the block's remaining segments (attention weights 7.4 MB each, below ``min_elems`` on their own because the not-yet-final bias
-    segments sit between them; the two AdaLN linears, final only when the modulation tables close) leave in ``finish`` as two contiguous
-    runs per block - against DDP's ~140 buckets of 25 MB.  (Rounds 3-5 quoted "~60" here: that was the design estimate, not the count.)
+    per-link bound, so messages stay large.  Round 6: the optimizer lays the six big weights of every block out first and contiguously (the model
+    tags them: they are the gradients that are final when the backward leaves the block), so a block's early gradients are ONE run of 88 MB (2B)
+    that leaves during the backward; biases / LayerNorm affines / AdaLN linears / embeddings (final at the end) follow as one tail that
+    ``finish`` sends in 256-MB pieces: 30 + ~4 collectives per 2B step.  Rounds 3-5 interleaved both kinds in model order: 121 collectives, four
+    per block (two early FeedForward weights, two late runs), the attention weights exposed in ``finish`` (`profiles/r5_multi_rank_check.txt`)
+    - against DDP's ~140 buckets of 25 MB.
     """
 
     def __init__(self, flat: torch.Tensor, seg_start, min_elems: int = 8 << 20, max_elems: int = 128 << 20, group=None):

@@ -598,6 +598,62 @@ def test_full_depth_2b_two_dpm_steps_vs_oracle_loop(monkeypatch):
     assert all(e <= 5e-2 for e in errs), errs
 
 
+def test_full_depth_2b_last_three_dpm_steps_vs_oracle_loop(monkeypatch):
+    """The END of the 50-step DPM++ schedule at full size ("the loop test covers 2 of 50 steps" - the first two): steps 48,
+    49 and 50 (t = 59, 39, 19) from seeded latents - a first-order step (no history), a SECOND-order step (`old_pred_original_sample` in use,
+    lambda ratios of the low-noise end), and the FINAL step, where `prev_timestep < 0` switches to `final_alpha_cumprod` and the solver drops
+    to first order again (oracle/leaf.py, diffusers' CogVideoXDPMScheduler.step).  HIP bf16 loop body against the fp32 oracle's, same
+    pre-drawn noise on both sides; per-step latents rel-L2 <= 5e-2 (the bound of the golden loops)."""
+    import os
+    import bench
+    from oracle import leaf
+    from orv_amd import schedulers
+    dev = torch.device("cuda:0")
+    model = bench.build_model(dict(bench.CFG_2B), dev)
+    model.action_embed.forced_mask = torch.zeros(1, dtype=torch.bool)
+    lat, img, prompt, actions = bench.synthetic_inputs(1, dev, BF)
+    kw = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+              set_alpha_to_one=True, prediction_type="v_prediction", rescale_betas_zero_snr=True, snr_shift_scale=3.0,
+              timestep_spacing="trailing")
+    first, n_steps = 47, 3
+    g = torch.Generator().manual_seed(321)
+    draws = [torch.randn(lat.shape, generator=g).to(BF).float() for _ in range(2 * n_steps)]
+    q_hip, q_ref = list(draws), list(draws)
+    monkeypatch.setattr(schedulers, "_randn_like", lambda sample, generator: q_hip.pop(0).to(sample.device, torch.float32))
+    monkeypatch.setattr(leaf, "randn_tensor", lambda shape, generator=None, device=None, dtype=None: q_ref.pop(0).to(dtype))
+    sched = schedulers.CogVideoXDPMScheduler(**kw)
+    sched.set_timesteps(50)
+    ts = sched.timesteps.tolist()
+    assert ts[first:] == [59, 39, 19]
+    trace, latents, old_x0 = [], lat.clone(), None
+    with torch.no_grad():
+        for i in range(first, first + n_steps):
+            t = ts[i]
+            v = model(hidden_states=torch.cat([latents, img], dim=2), encoder_hidden_states=prompt,
+                      timestep=torch.full((1,), t, device=dev, dtype=torch.int64), controls_or_guidances={"actions": actions},
+                      return_dict=False)[0]
+            latents, old_x0 = sched.step(v, old_x0, t, ts[i - 1] if i > first else None, latents)
+            trace.append(latents.float().cpu())
+    sd = {k: v_.detach().float().cpu() for k, v_ in model.state_dict().items()}
+    torch.set_num_threads(max(1, min(32, (os.cpu_count() or 2) // 2)))
+    osched = leaf.CogVideoXDPMScheduler(**kw)
+    osched.set_timesteps(50)
+    ots = osched.timesteps
+    ref, x, old = [], lat.float().cpu(), None
+    with torch.no_grad():
+        for i in range(first, first + n_steps):                                       # oracle/pipeline.denoise's loop body, from step `first`
+            t = ots[i]
+            vin = torch.cat([osched.scale_model_input(x, t), img.float().cpu()], dim=2)
+            npred = dit.dit_forward(sd, dict(model.config), vin, prompt.float().cpu(), t.expand(1), actions=actions.float().cpu(),
+                                    is_mask=torch.zeros(1, dtype=torch.bool))[0].float()
+            x, old = osched.step(npred, old, t, ots[i - 1] if i > first else None, x, generator=None)
+            ref.append(x.clone())
+    assert len(q_hip) == len(q_ref) < len(draws)                                      # both sides consumed the same draws
+    errs = [rel_l2(a_, b_) for a_, b_ in zip(trace, ref)]
+    print("[full-depth loop, last steps] per-step rel-L2(HIP bf16, fp32 oracle) = " + " ".join(f"{e:.3e}" for e in errs))
+    assert all(e <= 5e-2 for e in errs), errs
+
+
 @pytest.mark.parametrize("variant", ["visual_guidance", "multiview"])
 def test_full_width_guidance_and_multiview_vs_oracle(variant):
     """BASELINE configs[3] / the paper's stage 3 at CogVideoX-2B widths (D=1920, 30 heads, 40x60 latents), one block:

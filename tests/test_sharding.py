@@ -88,3 +88,35 @@ def test_two_rank_gradient_allreduce():
     assert all(p.exitcode == 0 for p in procs)
     assert nf == 3 and torch.allclose(flat, torch.arange(10000, dtype=torch.float32) * 1.5)
     assert nr == 2 + 1 + 2 + 4 and torch.allclose(buf, torch.arange(10000, dtype=torch.float32) * 1.5)
+
+
+def test_block_gradients_leave_as_one_collective_per_block():
+    """Round 6: FusedAdamW lays the parameters the model tags as "final when the block's backward ends" (the six big weights of a block) out
+    first and contiguously, so FlatGradReducer sends ONE run per block during the backward and one tail in finish() - not two early + two late
+    pieces per block (121 collectives per 2B step in rounds 3-5).  CPU, no process group: the reducer counts what it would send."""
+    import torch
+    from orv_amd.cogvideox_control import CogVideoXTransformer3DModelTraj
+    from orv_amd.optim import FusedAdamW
+    from orv_amd.sharding import FlatGradReducer
+    L = 3
+    m = CogVideoXTransformer3DModelTraj(num_attention_heads=2, attention_head_dim=64, in_channels=8, out_channels=4, num_layers=L,
+                                        text_embed_dim=32, time_embed_dim=32, sample_width=12, sample_height=8, sample_frames=9,
+                                        max_text_seq_length=8).to(torch.bfloat16)
+    opt = FusedAdamW(m.parameters(), lr=1e-3)
+    early = [p for p in opt.params if getattr(p, "_orv_grad_early", False)]
+    assert len(early) == 6 * L and opt.params[:len(early)] == early                      # tagged first, model order kept
+    assert sorted(map(id, opt.params)) == sorted(id(p) for p in m.parameters() if p.requires_grad)
+    opt._build()
+    f = opt._flat
+    index = {id(p): i for i, p in enumerate(opt.params)}
+    red = FlatGradReducer(f["g"], f["reduce_starts"], min_elems=1, max_elems=1 << 40)
+    for blk in reversed(list(m.transformer_blocks)):                                      # the backward walks the blocks from the last to the first
+        before = red.n_collectives
+        ws = [blk.attn1.to_q.weight, blk.attn1.to_k.weight, blk.attn1.to_v.weight, blk.attn1.to_out[0].weight,
+              blk.ff.net[0].proj.weight, blk.ff.net[2].weight]
+        seg = sorted(index[id(w)] for w in ws)
+        assert seg == list(range(seg[0], seg[0] + 6))                                     # contiguous in the flat buffer
+        red.ready(seg)
+        assert red.n_collectives == before + 1                                            # one run, one collective
+    n = red.finish(average=False)
+    assert n == L + 1                                                                     # + ONE tail: everything that is final at the end
