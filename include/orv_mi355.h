@@ -171,13 +171,6 @@ typedef struct {
      * 0 / 1, no cmap / Y) - the FeedForward hidden state between cogvideox_control.py:439 and :440 never exists row-major.  Producers:
      * orv_pack_rows16, orv_layernorm_modulate (out_packed), orv_gemm_bf16 (c_packed), orv_attention_fwd* (out_packed). */
     int a_packed, c_packed;
-    /* epilogue 4 only (round 6): rotary position embedding applied behind the qk LayerNorm, as the reference's processor does for RoPE models
-     * (cogvideox_control.py:250-254: apply_rotary_emb on the video tokens of q and k): rope_cos / rope_sin = fp32 tables [rope_seq - rope_n_text, 64]
-     * (orv/utils.py:196-239), row m of the call is token m % rope_seq of its clip, tokens < rope_n_text (text) are not rotated.  The normalised
-     * value is rounded to bf16 first (the reference's LayerNorm output), rotated in fp32, then q gets qn_premul: orv_gemm_bf16 (epilogue 0) +
-     * orv_qkv_prep with RoPE in ONE launch (CogVideoX1.5-5B: one pass over the 130-MB q | k | v less per layer).  NULL: no rotation.  Served by
-     * the t8 / d8 kernels only; other tile choices return an error (the caller keeps the two-launch form). */
-    const float *rope_cos, *rope_sin; int rope_n_text, rope_seq;
 } orv_gemm_t;
 int orv_gemm_bf16(const orv_gemm_t* g, void* stream);
 /* Row slots of a packed P16 buffer for `rows` rows (rounded up to the 256-row GEMM tile). */

@@ -27,8 +27,7 @@ class Gemm(Structure):
                 ("R", c_void_p), ("ldr", c_int), ("r_mod", c_int), ("gate", c_void_p), ("gate_b", c_long),
                 ("gate_g", c_long), ("grp", Groups), ("cmap", RowMap), ("Y", c_void_p), ("ldy", c_int),
                 ("qn_gamma_q", c_void_p), ("qn_beta_q", c_void_p), ("qn_gamma_k", c_void_p), ("qn_beta_k", c_void_p),
-                ("qn_eps", c_float), ("qn_premul", c_float), ("qn_heads", c_int), ("a_packed", c_int), ("c_packed", c_int),
-                ("rope_cos", c_void_p), ("rope_sin", c_void_p), ("rope_n_text", c_int), ("rope_seq", c_int)]
+                ("qn_eps", c_float), ("qn_premul", c_float), ("qn_heads", c_int), ("a_packed", c_int), ("c_packed", c_int)]
 
 
 class Conv(Structure):

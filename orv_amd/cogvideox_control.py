@@ -722,13 +722,6 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
         if rope is None and _FUSE_QKNORM:
             ops.gemm(xn, wqkv, bqkv, qkv, M, 3 * D, D, epilogue=4, Y=raw,
                      qknorm=(nq.weight, nq.bias, nk.weight, nk.bias, at.eps, scale * LOG2E, heads), a_packed=a_packed)
-        elif (rope is not None and _FUSE_QKNORM and _FUSE_ROPE and rope[0].shape[0] == S - n_text
-              and ops.gemm_rope_fusable(M, 3 * D, D, a_packed=a_packed)):
-            # round 6: RoPE models (CogVideoX1.5-5B, the scratch configs) - norm_q / norm_k AND apply_rotary_emb (:243-254) ride in the projection's
-            # epilogue: one launch and one pass over q | k | v less per layer than projection + orv_qkv_prep
-            ops.gemm(xn, wqkv, bqkv, qkv, M, 3 * D, D, epilogue=4, Y=raw,
-                     qknorm=(nq.weight, nq.bias, nk.weight, nk.bias, at.eps, scale * LOG2E, heads), a_packed=a_packed,
-                     rope=(rope[0], rope[1], n_text, S))
         else:
             dst = qkv if raw is None else raw
             ops.gemm(xn, wqkv, bqkv, dst, M, 3 * D, D, a_packed=a_packed)
@@ -943,10 +936,6 @@ class CogVideoXTransformer3DModelTraj(nn.Module):
 # sampler pipeline (:1090-1489)
 # ------------------------------------------------------------------------------------------------------------------
 _FUSE_QKNORM = os.environ.get("ORV_FUSED_QKNORM", "1") != "0"      # A/B switch: 0 = projection + orv_qkv_prep
-# RoPE models: norm_q / norm_k + apply_rotary_emb in the projection's epilogue (orv_gemm_t.rope_cos, round 6).  Built, parity-green, measured LEVEL
-# on configs[4] (CogVideoX1.5-5B SFT step 332.8 vs 333.4 ms checkpointed, 266.3 vs 264.1 resident, profiles/r6_rope_epilogue.txt: the register-form
-# LayerNorm + rotation epilogue costs the t8 tile what the separate 97-us orv_qkv_prep pass costs the step) - opt-in, the two-launch form stays.
-_FUSE_ROPE = os.environ.get("ORV_FUSED_ROPE", "0") == "1"
 
 
 def _chains() -> int:

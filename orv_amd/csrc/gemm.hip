@@ -1530,10 +1530,6 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
     a.a_packed = g->a_packed; a.c_packed = g->c_packed;
     a.qn_gq = (const bf16_t*)g->qn_gamma_q; a.qn_bq = (const bf16_t*)g->qn_beta_q; a.qn_gk = (const bf16_t*)g->qn_gamma_k;
     a.qn_bk = (const bf16_t*)g->qn_beta_k; a.qn_eps = g->qn_eps; a.qn_premul = g->qn_premul; a.qn_heads = g->qn_heads;
-    a.rope_cos = g->epilogue == 4 ? g->rope_cos : nullptr; a.rope_sin = g->epilogue == 4 ? g->rope_sin : nullptr;
-    a.rope_n_text = g->rope_n_text; a.rope_seq = g->rope_seq;
-    ORV_REQUIRE((a.rope_cos == nullptr) == (a.rope_sin == nullptr) && (!a.rope_cos || (g->rope_seq > 0 && g->rope_n_text >= 0 && g->rope_n_text <= g->rope_seq)),
-                "orv_gemm_bf16: rope_cos / rope_sin go together and need 0 <= rope_n_text <= rope_seq, rope_seq > 0");
     if (g->epilogue == 4) {
         ORV_REQUIRE(g->qn_heads > 0 && (g->N == 3 * g->qn_heads * 64 || g->N == 2 * g->qn_heads * 64),
                     "orv_gemm_bf16: epilogue 4 needs N = 3 * heads * 64 (q | k | v) or 2 * heads * 64 (q | k) (N=%d heads=%d)", g->N, g->qn_heads);
@@ -1562,8 +1558,6 @@ extern "C" int orv_gemm_bf16(const orv_gemm_t* g, void* stream) {
     ORV_REQUIRE(!g->c_packed || g->a_packed || g->epilogue == 1, "orv_gemm_bf16: packed C from a row-major A needs epilogue 1 (the t8 GELU epilogue)");
     ORV_REQUIRE(plan_gemm(g->M, g->N, g->K, g->epilogue, g->qn_heads, first, second, wide, g->a_packed != 0, g->c_packed != 0),
                 "orv_gemm_bf16: no tile configuration for N=%d (ORV_GEMM_TILE override?)", g->N);
-    ORV_REQUIRE(!a.rope_cos || ((first->ring == 3 || first->ring == 5) && (!second || second->ring == 3 || second->ring == 5)),
-                "orv_gemm_bf16: the RoPE form of epilogue 4 is served by the t8 / d8 kernels only (this shape takes another kernel: use epilogue 0 + orv_qkv_prep)");
     if (!second) return gemm_dispatch(a, first, g->epilogue, st);
     const int nqk = 2 * g->qn_heads * 64;
     GemmArgs q = a;

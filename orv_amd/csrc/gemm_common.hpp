@@ -30,7 +30,6 @@ struct GemmArgs {
     // epilogue 4 (fused qk LayerNorm of the QKV projection): norm_q / norm_k affine [64], eps, q pre-multiplier, heads
     const bf16_t *qn_gq, *qn_bq, *qn_gk, *qn_bk; float qn_eps, qn_premul; int qn_heads;
     int a_packed, c_packed;   // A / C in the packed P16 layout (include/orv_mi355.h orv_gemm_t; gemm_d8.hip)
-    const float *rope_cos, *rope_sin; int rope_n_text, rope_seq;   // epilogue 4: RoPE behind the qk LayerNorm (orv_gemm_t)
     int tiles_m, tiles_n;
     int dbg;  // ORV_GEMM_DBG: 1 = skip main-loop loads, 2 = skip MFMAs (ablation only)
     // Walk the tile list from its end.  A GEMM's A operand was written by the kernel just before it, lowest rows first; the big ones
@@ -74,28 +73,6 @@ __device__ __forceinline__ void tile_of_block(const GemmArgs& p, int& tm, int& t
 __device__ __forceinline__ float qkln_sq(float x, float sq) { return __builtin_fmaf(x, x, sq); }
 __device__ __forceinline__ float qkln_affine(float x, float rstd, float ga, float be, float post) {
     return __builtin_fmaf(x * rstd, ga, be) * post;
-}
-
-// Epilogue 4 with RoPE (orv_gemm_t.rope_cos): this lane's 8 consecutive channels c0 .. c0 + 7 of a 64-wide q / k head row - rotation pairs
-// (2 i, 2 i + 1) are lane-local.  Arithmetic of orv_qkv_prep (norm.hip): the normalised value is rounded to bf16 (the reference's LayerNorm
-// output dtype, cogvideox_control.py:243-247), rotated in fp32 (:250-254; text tokens are not), then the softmax pre-multiplier of q.
-__device__ __forceinline__ void qkln_rope8(float (&w)[8], const GemmArgs& p, long row, int c0, float post) {
-    const int tok = (int)(row % p.rope_seq);
-    if (tok >= p.rope_n_text) {
-        const float* cp = p.rope_cos + (long)(tok - p.rope_n_text) * 64 + c0;
-        const float* sp = p.rope_sin + (long)(tok - p.rope_n_text) * 64 + c0;
-        const float4 c0v = *(const float4*)cp, c1v = *(const float4*)(cp + 4), s0v = *(const float4*)sp, s1v = *(const float4*)(sp + 4);
-        const float cs[8] = {c0v.x, c0v.y, c0v.z, c0v.w, c1v.x, c1v.y, c1v.z, c1v.w};
-        const float sn[8] = {s0v.x, s0v.y, s0v.z, s0v.w, s1v.x, s1v.y, s1v.z, s1v.w};
-#pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-            const float a = bf2f(f2bf(w[e])), b = bf2f(f2bf(w[e + 1]));
-            w[e] = a * cs[e] - b * sn[e];
-            w[e + 1] = b * cs[e + 1] + a * sn[e + 1];
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) w[e] *= post;
 }
 
 // gemm_t8.hip: launches gemm_t8_kernel<BN, EPI> (bm = 256) or gemm_t8r192_kernel<BN, EPI> (bm = 192), BN = 256 or 192; a.tiles_m / a.tiles_n

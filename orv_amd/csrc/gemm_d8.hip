@@ -258,10 +258,8 @@ __device__ __forceinline__ void d8_epilogue(const GemmArgs& p, f32x4 (&acc)[RB][
                         sq = d8_sum_quad(sq);
                         const float sq_up = d8_shr4(sq);
                         const float rstd = rsqrtf((c < 4 ? sq : sq_up) * (1.f / 64.f) + p.qn_eps);
-                        const bool rope = p.rope_cos != nullptr;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) w[e] = qkln_affine(w[e], rstd, ga[e], be[e], rope ? 1.f : post);
-                        if (rope) qkln_rope8(w, p, orow[rb][j], 8 * c, post);
+                        for (int e = 0; e < 8; ++e) w[e] = qkln_affine(w[e], rstd, ga[e], be[e], post);
                     }
                 }
                 if (EPI == 1) {

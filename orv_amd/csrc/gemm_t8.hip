@@ -125,15 +125,10 @@ __device__ __forceinline__ void t8_epilogue(const GemmArgs& p, f32x4 (&acc)[2][M
 #pragma unroll
                         for (int e = 0; e < 8; ++e) { v[P][e] -= mean; sq = qkln_sq(v[P][e], sq); }      // explicit fma chain: gemm_common.hpp
                     const float rstd = rsqrtf(sum_xor32(sum_xor16(sq)) * (1.f / 64.f) + p.qn_eps);
-                    const bool rope = p.rope_cos != nullptr;                 // uniform
 #pragma unroll
                     for (int P = 0; P < NP; ++P)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[P][e] = qkln_affine(v[P][e], rstd, ga[P][e], be[P][e], rope ? 1.f : post);
-                    if (rope) {
-#pragma unroll
-                        for (int P = 0; P < NP; ++P) qkln_rope8(v[P], p, orow, 32 * P + 8 * g, post);
-                    }
+                        for (int e = 0; e < 8; ++e) v[P][e] = qkln_affine(v[P][e], rstd, ga[P][e], be[P][e], post);
                 }
                 if (valid && st_ok) {
 #pragma unroll
@@ -423,10 +418,8 @@ __device__ __forceinline__ void t8_epilogue_lds(const GemmArgs& p, f32x4 (&acc)[
 #pragma unroll
                         for (int e = 0; e < 8; ++e) { w[e] -= mean; sq = qkln_sq(w[e], sq); }
                         const float rstd = rsqrtf(sum8(sq) * (1.f / 64.f) + p.qn_eps);
-                        const bool rope = p.rope_cos != nullptr;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) w[e] = qkln_affine(w[e], rstd, ga[e], be[e], rope ? 1.f : post);
-                        if (rope) qkln_rope8(w, p, orow[mb][j], 8 * c, post);
+                        for (int e = 0; e < 8; ++e) w[e] = qkln_affine(w[e], rstd, ga[e], be[e], post);
                     }
                 }
                 if (EPI == 1) {

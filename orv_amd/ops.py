@@ -216,19 +216,11 @@ def gemm_kernel_name(M, N, K, epilogue=0, a_packed=False, c_packed=False) -> Opt
     return buf.value.decode()
 
 
-def gemm_rope_fusable(M, N, K, a_packed=False) -> bool:
-    """Does ``gemm(..., epilogue=4, rope=...)`` have a kernel for this shape?  (The RoPE form of the fused qk-LayerNorm epilogue lives in the t8
-    and d8 kernels; shapes the tile chooser sends elsewhere keep the two-launch form: projection + ``qkv_prep``.)"""
-    name = gemm_kernel_name(M, N, K, 4, a_packed=a_packed)
-    return name is not None and all(part.strip().startswith(("gemm_t8", "gemm_d8")) for part in name.split("+"))
-
-
 def gemm(A, W, bias, C, M, N, K, epilogue=0, R=None, r_mod=0, gate=None, gate_b=0, gate_g=0, grp: Optional[Groups] = None,
          cmap: Optional[RowMap] = None, lda=None, ldw=None, ldc=None, ldr=None, Y=None, ldy=None, qknorm=None,
-         a_packed=False, c_packed=False, rope=None):
+         a_packed=False, c_packed=False):
     """``qknorm`` = (gamma_q, beta_q, gamma_k, beta_k, eps, q_premul, heads) with ``epilogue=4``: the QKV projection with the
-    per-head qk LayerNorm fused; ``rope`` = (cos, sin, n_text, seq) adds the rotary embedding of the video tokens behind it (fp32 tables
-    [seq - n_text, 64]; t8 / d8 kernels only - check ``gemm_rope_fusable``).  ``a_packed`` / ``c_packed``: A is read / C is written in the packed P16 layout
+    per-head qk LayerNorm fused (no RoPE).  ``a_packed`` / ``c_packed``: A is read / C is written in the packed P16 layout
     (include/orv_mi355.h ``orv_gemm_t``; buffers of ``packed_rows(M)`` row slots)."""
     _need(A, BF16, "A"), _need(W, BF16, "W"), _need(C, BF16, "C")
     g = Gemm()
@@ -244,12 +236,6 @@ def gemm(A, W, bias, C, M, N, K, epilogue=0, R=None, r_mod=0, gate=None, gate_b=
     g.cmap = cmap or RowMap(0, 0, 0)
     g.Y, g.ldy = _p(Y), ldy or N
     g.a_packed, g.c_packed = int(bool(a_packed)), int(bool(c_packed))
-    if rope is not None:
-        rc, rs, n_text, seq = rope
-        _need(rc, torch.float32, "rope cos"), _need(rs, torch.float32, "rope sin")
-        if epilogue != 4 or rc.shape != rs.shape or rc.shape[-1] != 64 or rc.numel() != (int(seq) - int(n_text)) * 64:
-            raise ValueError("gemm: rope needs epilogue 4 and fp32 tables [seq - n_text, 64]")
-        g.rope_cos, g.rope_sin, g.rope_n_text, g.rope_seq = _p(rc), _p(rs), int(n_text), int(seq)
     with _timed(("gemm", M, N, K, epilogue) + ((int(bool(a_packed)), int(bool(c_packed))) if (a_packed or c_packed) else ())):
         check(lib().orv_gemm_bf16(g, _stream()), "orv_gemm_bf16")
     return C

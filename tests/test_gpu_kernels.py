@@ -456,74 +456,6 @@ def test_qkv_gemm_with_fused_qk_layernorm(M, H):
     assert d.max().item() <= 2e-2 * scale and d.mean().item() <= 2e-3 * scale
 
 
-@pytest.mark.parametrize("kind", ["t8", "d8", "d8r192"])
-def test_qkv_gemm_with_fused_qk_layernorm_and_rope(kind):
-    """Round 6: epilogue 4 with RoPE (orv_gemm_t.rope_cos: norm_q / norm_k AND apply_rotary_emb of the video tokens in the projection's epilogue,
-    cogvideox_control.py:243-254) against the pair it replaces - epilogue 0 + orv_qkv_prep with the same tables - and against an fp32 torch
-    statement of the reference's order (LayerNorm -> bf16 -> rotation in fp32 -> q pre-multiplier); text tokens stay un-rotated, the Y side
-    output is the raw projection, v is stored as is.  Two clips with ragged row counts; the t8 kernel (row-major A) and the d8 kernels (packed A)."""
-    from orv_amd import ops
-    from orv_amd._lib import lib
-    dev = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(77)
-    H, D = 4, 256                       # N = 768 = 3 x 256 (t8 / d8 at BN = 256) = 4 x 192 = 6 x 128 (d8)
-    B, S, n_text = 2, 1613, 226
-    M, K = B * S, 384                   # K % 128 == 0 (t8) and K % 192 == 0 (d8)
-    x = torch.randn(M, K, generator=g).to(dev, BF)
-    W = (torch.randn(3 * D, K, generator=g) * 0.05).to(dev, BF)
-    bias = (torch.randn(3 * D, generator=g) * 0.1).to(dev, BF)
-    gq, bq, gk, bk = ((torch.randn(64, generator=g) * 0.2 + (1.0 if i % 2 == 0 else 0.0)).to(dev, BF) for i in range(4))
-    ang = torch.rand(S - n_text, 32, generator=g) * 6.28
-    cos = ang.cos().repeat_interleave(2, 1).contiguous().to(dev)
-    sin = ang.sin().repeat_interleave(2, 1).contiguous().to(dev)
-    premul = 0.125 * 1.4426950408889634
-    s_pad = (S + 63) // 64 * 64
-    # the two-launch form
-    raw = torch.empty(M, 3 * D, dtype=BF, device=dev)
-    ops.gemm(x, W, bias, raw, M, 3 * D, K)
-    ref = torch.empty_like(raw)
-    ops.qkv_prep(ref, None, gq, bq, gk, bk, (cos, sin), B, S, H, n_text, s_pad, 1e-6, q_premul=premul, src=raw)
-    # fp32 torch statement on the fp32 projection
-    y32 = x.float() @ W.float().t() + bias.float()
-    def want(y, gam, bet, post):
-        v = torch.nn.functional.layer_norm(y.view(M, H, 64), (64,), gam.float(), bet.float(), 1e-6).to(BF).float()
-        tok = (torch.arange(M, device=dev) % S)
-        c = torch.ones(M, 64, device=dev); sn = torch.zeros(M, 64, device=dev)
-        vid = tok >= n_text
-        c[vid], sn[vid] = cos[tok[vid] - n_text], sin[tok[vid] - n_text]
-        rot = torch.stack([-v[..., 1::2], v[..., 0::2]], -1).flatten(-2)
-        return ((v * c[:, None] + rot * sn[:, None]) * post).reshape(M, D)
-    q32, k32 = want(y32[:, :D], gq, bq, premul), want(y32[:, D:2 * D], gk, bk, 1.0)
-    tile = {"t8": (3, 256, 256), "d8": (5, 256, 192), "d8r192": (5, 192, 128)}[kind]
-    packed = kind != "t8"
-    a = ops.pack_rows16(x, M, K) if packed else x
-    out = torch.full((M, 3 * D), float("nan"), dtype=BF, device=dev)
-    y = torch.full((M, 3 * D), float("nan"), dtype=BF, device=dev)
-    lib().orv_gemm_force_tile(*tile)
-    try:
-        assert ops.gemm_rope_fusable(M, 3 * D, K, a_packed=packed)
-        ops.gemm(a, W, bias, out, M, 3 * D, K, epilogue=4, Y=y, qknorm=(gq, bq, gk, bk, 1e-6, premul, H), a_packed=packed,
-                 rope=(cos, sin, n_text, S))
-    finally:
-        lib().orv_gemm_force_tile(0, 0, 0)
-    assert torch.equal(y, raw) and torch.equal(out[:, 2 * D:], raw[:, 2 * D:])          # raw projection / v: bit for bit
-    scale = ref[:, :2 * D].float().abs().max().item()
-    d = (out[:, :2 * D].float() - ref[:, :2 * D].float()).abs()
-    assert d.max().item() <= 2e-2 * scale and d.mean().item() <= 2e-3 * scale, (d.max().item(), d.mean().item(), scale)
-    close(out[:, :D], q32)
-    close(out[:, D:2 * D], k32)
-    # text rows really are un-rotated, video rows really are rotated: against the un-rotated fused epilogue
-    plain = torch.empty_like(out)
-    lib().orv_gemm_force_tile(*tile)
-    try:
-        ops.gemm(a, W, bias, plain, M, 3 * D, K, epilogue=4, qknorm=(gq, bq, gk, bk, 1e-6, premul, H), a_packed=packed)
-    finally:
-        lib().orv_gemm_force_tile(0, 0, 0)
-    rows = torch.arange(M, device=dev) % S
-    assert torch.equal(out[rows < n_text, :2 * D], plain[rows < n_text, :2 * D])
-    assert not torch.equal(out[rows >= n_text, :2 * D], plain[rows >= n_text, :2 * D])
-
-
 @pytest.mark.parametrize("N,K,epi", [(5760, 1920, 0), (7680, 1920, 1), (1920, 7680, 2), (5760, 1920, 4)])
 def test_ring_gemm_is_deterministic_under_repetition(N, K, epi):
     """Race screen for the persistent ring GEMM (counted vmcnt waits, DMA stream running across tile boundaries, epilogue
