@@ -222,6 +222,10 @@ class FusedAdamW:
     def load_state_dict(self, sd):
         layout = [int(p.numel()) for p in self.params]
         if sd.get("numels") is not None and list(sd["numels"]) != layout:
+            if sorted(sd["numels"]) == sorted(layout):
+                raise ValueError("FusedAdamW.load_state_dict: same parameters, another flat-buffer ORDER - the checkpoint predates round 6, which "
+                                 "lays the block weights out first (one all-reduce per block); its moments cannot be mapped by position.  Resume "
+                                 "the parameters from the model checkpoint and restart the moments, or load with the build that wrote it")
             raise ValueError("FusedAdamW.load_state_dict: the checkpoint was written for a different set of trainable parameters "
                              f"({len(sd['numels'])} segments vs {len(layout)} here, or different sizes)")
         self.step_count = int(sd["step"])
