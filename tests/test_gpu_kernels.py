@@ -1076,6 +1076,42 @@ def test_d8_192_row_tiles_are_bit_identical_to_the_256_row_kernel(bn):
     same(c0, c1, (bn, "qk LayerNorm C")), same(y0, y1, (bn, "qk LayerNorm Y"))
 
 
+@pytest.mark.parametrize("N,K,epi", [(1920, 7680, 2), (1920, 1920, 2), (5760, 1920, 4), (7680, 1920, 1)])
+def test_d8_kernels_are_deterministic_under_repetition(N, K, epi):
+    """Race screen for the d8 kernels at the shapes the one-clip step takes them (gemm_d8r192_kernel: M = 3226) and at the headline shape
+    (gemm_d8_kernel: M = 12904): hand-counted vmcnt waits, A registers in flight across the tile boundary, branch-free cursor wraps, one
+    barrier per K-tile - 20 back-to-back launches must agree bit for bit (a read of an in-flight register or a buffer reused one barrier early
+    shows up as run-to-run differences long before it shows up as a wrong mean)."""
+    from orv_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(N + K + epi)
+    for M in (3226, 12904):
+        name = ops.gemm_kernel_name(M, N, K, epi, a_packed=True, c_packed=(epi == 1))
+        assert name is not None and name.startswith("gemm_d8"), name
+        x = torch.randn(M, K, generator=g).to(dev, BF)
+        W = (torch.randn(N, K, generator=g) * 0.03).to(dev, BF)
+        bias = (torch.randn(N, generator=g) * 0.1).to(dev, BF)
+        xp = ops.pack_rows16(x, M, K)
+        kw = {}
+        if epi == 2:
+            kw = dict(R=torch.randn(M, N, generator=g).to(dev, BF), ldr=N, gate=torch.randn(M // 3226, 6, N, generator=g).to(dev),
+                      gate_b=6 * N, gate_g=N, grp=ops.groups(3226, 226, 600))
+        if epi == 4:
+            one = torch.ones(64, dtype=BF, device=dev)
+            kw = dict(qknorm=(one, None, one, None, 1e-6, 0.18, N // 192))
+        outs = []
+        for _ in range(20):
+            out = torch.empty(ops.packed_rows(M) if epi == 1 else M, N, dtype=BF, device=dev)
+            ops.gemm(xp, W, bias, out, M, N, K, epilogue=epi, a_packed=True, c_packed=(epi == 1), **kw)
+            outs.append(out)
+        torch.cuda.synchronize()
+        first = ops.unpack_rows16(outs[0], M, N) if epi == 1 else outs[0]
+        assert torch.isfinite(first.float()).all(), (name, M)
+        for o in outs[1:]:
+            oo = ops.unpack_rows16(o, M, N) if epi == 1 else o
+            assert torch.equal(oo, first), (name, M)
+
+
 @pytest.mark.parametrize("bn", [256, 192])
 def test_d8_gemm_on_packed_a_is_bit_identical_to_t8(bn):
     """gemm_d8_kernel (A straight to registers from the packed layout, W through four LDS buffers, one barrier per K-tile) accumulates every
