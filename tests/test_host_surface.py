@@ -370,3 +370,25 @@ def test_graph_weights_key_sees_replaced_parameters():
     assert k3 != k2
     lin.weight.data = lin.weight.data.clone()                           # storage move: data_ptr
     assert gt._weights_version() != k3
+
+
+def test_softmax_kernel_census_follows_the_qk_layernorm_gains():
+    """``model.softmax_kernel_census()`` (round 6; `bench.py` prints it as `attention_softmax`): which layers' CURRENT norm_q / norm_k parameters
+    keep the fixed-shift softmax kernel (bound <= orv_attention_static_limit) and which fall to the online kernel.  Host arithmetic + one C-ABI
+    constant: runs without a GPU."""
+    import torch
+    from orv_amd.cogvideox_control import CogVideoXTransformer3DModelTraj
+    m = CogVideoXTransformer3DModelTraj(num_attention_heads=2, attention_head_dim=64, in_channels=8, out_channels=4, num_layers=4, text_embed_dim=32,
+                                        time_embed_dim=32, sample_width=12, sample_height=8, sample_frames=9, max_text_seq_length=8)
+    c0 = m.softmax_kernel_census()
+    assert c0["layers_static"] == 4 and c0["layers_online"] == 0 and c0["static_limit_log2"] == 90.0
+    assert abs(c0["max_bound_log2"] - 1.02 * 64 * 0.125 * 1.4426950408889634) < 0.02          # gamma 1, beta 0: 64 x scale x log2 e
+    with torch.no_grad():
+        m.transformer_blocks[1].attn1.norm_q.weight[7] = 5.0          # one outlier channel in q AND the same channel in k: 25 x 64 x 0.18 > 90
+        m.transformer_blocks[1].attn1.norm_k.weight[7] = 5.0
+        m.transformer_blocks[2].attn1.norm_q.weight[7] = 5.0          # outliers in DIFFERENT channels: the per-channel bound keeps the layer static
+        m.transformer_blocks[2].attn1.norm_k.weight[40] = 5.0
+    c1 = m.softmax_kernel_census()
+    assert c1["layers_static"] == 3 and c1["layers_online"] == 1, c1
+    c2 = m.softmax_kernel_census(rope=True)                           # per pair (7 and 40 are in different pairs too)
+    assert c2["layers_static"] == 3 and c2["layers_online"] == 1, c2
