@@ -668,8 +668,23 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(const BwdArgs p)
 // (16 MFMAs, ds_read_b128; -lse / -delta of the tile's 64 query rows enter through the accumulator init, from LDS) } ;
 // Y_t = { P = exp2(S), dS = P dP, bf16 pack of both }.  Q' tiles (+ the lse vector): four slots, staged by waves 0-3; dO tiles (+ the delta
 // vector): three slots, staged by waves 4-7; both two tiles ahead, from the vector segment.
+// -DORV_BW_FRAGBUF (round 6 experiment): the transposed fragments (dO^T, Q'^T) of k-steps 1-3 are the SAME for all eight waves, and every wave
+// fetched them with 24 ds_read_b64_tr_b16 in its matrix segment - the segment that is bound by the per-wave LDS instruction rate
+// (tools/probe_lds_bcast.cpp).  Here the four waves of the FIRST half produce them once per tile in their vector segment (three fragments each:
+// six transposing reads + three ds_write_b128 into a "fragment-major" slot, fragment f of lane l at f KiB + 16 l), and every wave reads them
+// back in its matrix segment with 12 ds_read_b128: 64 -> 52 LDS instructions per tile and wave where it counts.  Two slots of 12 KiB (tile t - 1 is
+// still read by the second half while the first half writes tile t).
+#ifdef ORV_BW_FRAGBUF
+constexpr int DKV_FRAG0 = 7 * TILE + 7 * 256, DKV_FRAG_SLOT = 12 * 1024, DKV_SMEM = DKV_FRAG0 + 2 * DKV_FRAG_SLOT;
+#else
+constexpr int DKV_SMEM = 0;
+#endif
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p) {
+#ifdef ORV_BW_FRAGBUF
+    extern __shared__ __attribute__((aligned(16))) char smem[];              // Q' slots 0-3 | dO slots 0-2 | lse x4 | delta x3 | fragment slots x2
+#else
     __shared__ __attribute__((aligned(16))) char smem[7 * TILE + 7 * 256];   // Q' slots 0-3 | dO slots 0-2 | lse x4 | delta x3
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wq = wave & 3;
@@ -772,8 +787,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p
         if (t > 0) {
             const char* sQp = smem + ((t - 1) & 3) * TILE;               // Q' and dO of the previous tile, transposed reads
             const char* sOp = smem + 4 * TILE + ((t - 1) % 3) * TILE;
+#ifdef ORV_BW_FRAGBUF
+            const char* fb = smem + DKV_FRAG0 + ((t - 1) & 1) * DKV_FRAG_SLOT + lane * 16;
+            o2 = *(const bf16x8*)(fb + 0 * 1024); o3 = *(const bf16x8*)(fb + 3 * 1024);
+            g2_ = *(const bf16x8*)(fb + 6 * 1024); g3_ = *(const bf16x8*)(fb + 9 * 1024);
+#else
             o2 = tr_pair(sOp + 2048 + t00, sOp + 2048 + t01); o3 = tr_pair(sOp + 2048 + t10, sOp + 2048 + t11);
             g2_ = tr_pair(sQp + 2048 + t00, sQp + 2048 + t01); g3_ = tr_pair(sQp + 2048 + t10, sQp + 2048 + t11);
+#endif
         }
         BW_FENCE()
         stage_q();
@@ -785,14 +806,25 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p
             dv[0] = BW_MFMA(o0, pf[0].v, dv[0]); dv[1] = BW_MFMA(o1, pf[0].v, dv[1]);
             dk[0] = BW_MFMA(g0_, dsf[0].v, dk[0]); dk[1] = BW_MFMA(g1_, dsf[0].v, dk[1]);
             BW_FENCE()
+#ifdef ORV_BW_FRAGBUF
+            const char* fb = smem + DKV_FRAG0 + ((t - 1) & 1) * DKV_FRAG_SLOT + lane * 16;
+            o0 = *(const bf16x8*)(fb + 1 * 1024); o1 = *(const bf16x8*)(fb + 4 * 1024);
+            g0_ = *(const bf16x8*)(fb + 7 * 1024); g1_ = *(const bf16x8*)(fb + 10 * 1024);
+#else
             o0 = tr_pair(sOp + 4096 + t00, sOp + 4096 + t01); o1 = tr_pair(sOp + 4096 + t10, sOp + 4096 + t11);
             g0_ = tr_pair(sQp + 4096 + t00, sQp + 4096 + t01); g1_ = tr_pair(sQp + 4096 + t10, sQp + 4096 + t11);
+#endif
             BW_FENCE()
             dv[0] = BW_MFMA(o2, pf[1].v, dv[0]); dv[1] = BW_MFMA(o3, pf[1].v, dv[1]);
             dk[0] = BW_MFMA(g2_, dsf[1].v, dk[0]); dk[1] = BW_MFMA(g3_, dsf[1].v, dk[1]);
             BW_FENCE()
+#ifdef ORV_BW_FRAGBUF
+            o2 = *(const bf16x8*)(fb + 2 * 1024); o3 = *(const bf16x8*)(fb + 5 * 1024);
+            g2_ = *(const bf16x8*)(fb + 8 * 1024); g3_ = *(const bf16x8*)(fb + 11 * 1024);
+#else
             o2 = tr_pair(sOp + 6144 + t00, sOp + 6144 + t01); o3 = tr_pair(sOp + 6144 + t10, sOp + 6144 + t11);
             g2_ = tr_pair(sQp + 6144 + t00, sQp + 6144 + t01); g3_ = tr_pair(sQp + 6144 + t10, sQp + 6144 + t11);
+#endif
             BW_FENCE()
             dv[0] = BW_MFMA(o0, pf[2].v, dv[0]); dv[1] = BW_MFMA(o1, pf[2].v, dv[1]);
             dk[0] = BW_MFMA(g0_, dsf[2].v, dk[0]); dk[1] = BW_MFMA(g1_, dsf[2].v, dk[1]);
@@ -829,9 +861,24 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p
         }
         __builtin_amdgcn_s_setprio(0);
     };
+    // fragment (operand op = wq >> 1: 0 = dO^T, 1 = Q'^T; d block db = wq & 1; k-step ks) of tile t -> slot t & 1, index (op * 2 + db) * 3 + ks - 1
+    auto produce_frags = [&](int t) {
+#ifdef ORV_BW_FRAGBUF
+        const int op = wq >> 1, db = wq & 1;
+        const char* base = op == 0 ? smem + 4 * TILE + (t % 3) * TILE : smem + (t & 3) * TILE;
+        const int ta = db ? t10 : t00, tb = db ? t11 : t01;
+        char* fdst = smem + DKV_FRAG0 + (t & 1) * DKV_FRAG_SLOT + (op * 2 + db) * 3 * 1024 + lane * 16;
+        const bf16x8 f1 = tr_pair(base + 2048 + ta, base + 2048 + tb), f2 = tr_pair(base + 4096 + ta, base + 4096 + tb),
+                     f3 = tr_pair(base + 6144 + ta, base + 6144 + tb);
+        *(bf16x8*)(fdst) = f1; *(bf16x8*)(fdst + 1024) = f2; *(bf16x8*)(fdst + 2048) = f3;
+#endif
+    };
     auto seg_y = [&](int t) {
         prefetch_g(t);
         BW_FENCE()
+#ifdef ORV_BW_FRAGBUF
+        if (grp == 0) { produce_frags(t); BW_FENCE() }
+#endif
 #ifdef ORV_BW_ABL_NOY
         asm volatile("" ::"v"(sS[0]), "v"(sS[1]), "v"(dP[0]), "v"(dP[1]));
         return;
@@ -893,6 +940,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const BwdArgs p
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 BW_BAR()
                 stage(t + 2);
+                produce_frags(t);                                // a wave without keys still owns its share of the fragment slot
                 BW_BAR()
             }
         }
@@ -1106,6 +1154,10 @@ extern "C" int orv_attention_bwd(const void* qkv, int ld_qkv, const void* qT, co
     a.dout = (const bf16_t*)dout; a.ld_do = ld_out; a.neg_lse2 = neg_lse2; a.neg_delta = neg_delta;
     a.dqkv = (bf16_t*)dqkv; a.ld_dqkv = ld_dqkv; a.B = B; a.S = S; a.H = H; a.s_pad = s_pad; a.scale = scale;
     dim3 grid(((S + 255) / 256) * H * B);   // 1-D: orv_xcd_item hands head-major items to the XCDs
+    if (pp && DKV_SMEM > 0) {
+        static bool attr_done = false;
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_SMEM); attr_done = true; }
+    }
     if (pp) {
         // The two passes are independent (dQ | dK, dV: disjoint columns of dqkv) and each is 1560 one-per-CU workgroups = 6.09 -> 7
         // rounds of 256 CUs at B = 4: launched on two streams the dispatcher fills the empty part of one pass's last round with
@@ -1119,7 +1171,7 @@ extern "C" int orv_attention_bwd(const void* qkv, int ld_qkv, const void* qT, co
         const bool forked = side && hipEventRecord(side->ev_fork, st) == hipSuccess &&
                             hipStreamWaitEvent(side->stream, side->ev_fork, 0) == hipSuccess;
         if (forked) {
-            hipLaunchKernelGGL(attn_bwd_dkv_pp_kernel, grid, dim3(512), 0, side->stream, a);
+            hipLaunchKernelGGL(attn_bwd_dkv_pp_kernel, grid, dim3(512), DKV_SMEM, side->stream, a);
             hipLaunchKernelGGL(attn_bwd_dq_pp_kernel, grid, dim3(512), 0, st, a);
             if (hipEventRecord(side->ev_join, side->stream) != hipSuccess || hipStreamWaitEvent(st, side->ev_join, 0) != hipSuccess) {
                 // the join could not be queued: dqkv must not be consumed before the side pass is done
@@ -1130,7 +1182,7 @@ extern "C" int orv_attention_bwd(const void* qkv, int ld_qkv, const void* qT, co
         } else {
             (void)hipGetLastError();
             hipLaunchKernelGGL(attn_bwd_dq_pp_kernel, grid, dim3(512), 0, st, a);
-            hipLaunchKernelGGL(attn_bwd_dkv_pp_kernel, grid, dim3(512), 0, st, a);
+            hipLaunchKernelGGL(attn_bwd_dkv_pp_kernel, grid, dim3(512), DKV_SMEM, st, a);
         }
     } else {
         hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(512), 0, st, a);
