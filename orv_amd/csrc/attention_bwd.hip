@@ -668,12 +668,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(const BwdArgs p)
 // (16 MFMAs, ds_read_b128; -lse / -delta of the tile's 64 query rows enter through the accumulator init, from LDS) } ;
 // Y_t = { P = exp2(S), dS = P dP, bf16 pack of both }.  Q' tiles (+ the lse vector): four slots, staged by waves 0-3; dO tiles (+ the delta
 // vector): three slots, staged by waves 4-7; both two tiles ahead, from the vector segment.
-// -DORV_BW_FRAGBUF (round 6 experiment): the transposed fragments (dO^T, Q'^T) of k-steps 1-3 are the SAME for all eight waves, and every wave
+// Shared fragment buffer (round 6; -DORV_BW_NO_FRAGBUF builds the round-5 form for A/B): the transposed fragments (dO^T, Q'^T) of k-steps 1-3 are the SAME for all eight waves, and every wave
 // fetched them with 24 ds_read_b64_tr_b16 in its matrix segment - the segment that is bound by the per-wave LDS instruction rate
 // (tools/probe_lds_bcast.cpp).  Here the four waves of the FIRST half produce them once per tile in their vector segment (three fragments each:
 // six transposing reads + three ds_write_b128 into a "fragment-major" slot, fragment f of lane l at f KiB + 16 l), and every wave reads them
 // back in its matrix segment with 12 ds_read_b128: 64 -> 52 LDS instructions per tile and wave where it counts.  Two slots of 12 KiB (tile t - 1 is
 // still read by the second half while the first half writes tile t).
+#ifndef ORV_BW_NO_FRAGBUF
+#define ORV_BW_FRAGBUF 1
+#endif
 #ifdef ORV_BW_FRAGBUF
 constexpr int DKV_FRAG0 = 7 * TILE + 7 * 256, DKV_FRAG_SLOT = 12 * 1024, DKV_SMEM = DKV_FRAG0 + 2 * DKV_FRAG_SLOT;
 #else
